@@ -1,0 +1,76 @@
+// Shared device/host helpers for the gfx950 (CDNA4, wave64) kernels of libsdvar_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#define SDVAR_OK 0
+#define SDVAR_ERR_ARG 1
+#define SDVAR_ERR_HIP 2
+#define SDVAR_ERR_STATE 3
+
+namespace sdvar {
+
+void set_error(const char* fmt, ...);
+
+#define SDVAR_CHECK_ARG(cond, ...)                        \
+    do {                                                  \
+        if (!(cond)) {                                    \
+            sdvar::set_error(__VA_ARGS__);                \
+            return SDVAR_ERR_ARG;                         \
+        }                                                 \
+    } while (0)
+
+#define SDVAR_HIP(call)                                                                         \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            sdvar::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return SDVAR_ERR_HIP;                                                               \
+        }                                                                                       \
+    } while (0)
+
+#define SDVAR_LAUNCH_CHECK() SDVAR_HIP(hipGetLastError())
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- wave64 reductions (DPP/shuffle based; every lane gets the result) -------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// XCD-aware remap of a 1-D block id: blocks that share an XCD (bid % 8 equal) get a contiguous range of logical
+// ids, so neighbouring tiles hit the same per-XCD L2 (bijective for any grid size; cdna_hip_programming.md T1).
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, x = bid & 7;
+    const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + (bid >> 3);
+}
+
+// ---- Philox4x32-10 (must match sdvar_amd/noise.py bit for bit) ----------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                              uint32_t out[4]) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+}  // namespace sdvar

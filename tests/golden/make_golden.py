@@ -1,0 +1,341 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE (imported from /root/reference, CPU) on seeded weights.
+
+Run in the build container only:   PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+The reference never travels to the GPU box; only the small .npz outputs (data) are committed.  While generating,
+the same inputs are pushed through oracle/var_oracle.py and the script aborts unless the oracle agrees with the
+reference (ids bit-exact, logits <= 1e-6) - that is the pin the oracle header refers to.
+
+Seams used to observe the unmodified reference code:
+  * models.var.sample_with_top_k_top_p_ is wrapped to record (cfg logits, ids) per stage;
+  * vae.fhat_to_img is wrapped to record the final f_hat;
+  * for the "portable noise" goldens torch.multinomial is replaced, for the duration of one call, by its exact
+    equivalent argmax(p/q) (re-verified below on this host) with q from sdvar_amd.noise (Philox), because
+    torch's CPU exponential_ stream is CPU-vendor dependent and could not be replayed on the GPU box.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+OUT = os.path.join(ROOT, "tests", "golden")
+
+import models as ref_models                      # noqa: E402  (the reference)
+import models.var as ref_var                     # noqa: E402
+from oracle import var_oracle as orc             # noqa: E402
+from sdvar_amd.ladder import LADDER_256, LADDER_512   # noqa: E402
+from sdvar_amd.noise import exponential_noise    # noqa: E402
+from sdvar_amd.weights import var_state_dict, vae_state_dict  # noqa: E402
+
+# MKL/oneDNN pick kernels by buffer alignment and thread split, so two CPU runs of the *same* fp32 graph differ in
+# the last bits (measured here: up to ~1e-6 of the logit range between the reference modules and the oracle).
+LOGIT_RTOL = 5e-6
+torch.set_grad_enabled(False)
+torch.set_num_threads(8)
+
+
+def digest(t: torch.Tensor):
+    t = t.double()
+    return np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().item()], dtype=np.float64)
+
+
+class Recorder:
+    """Wraps the reference sampler (helpers.py:6-19) as seen from models/var.py."""
+    def __init__(self):
+        self.orig = ref_var.sample_with_top_k_top_p_
+        self.cfg_logits, self.ids = [], []
+
+    def __enter__(self):
+        def wrapped(logits_BlV, *a, **kw):
+            self.cfg_logits.append(logits_BlV.clone())
+            out = self.orig(logits_BlV, *a, **kw)
+            self.ids.append(out[:, :, 0].clone())
+            return out
+        ref_var.sample_with_top_k_top_p_ = wrapped
+        return self
+
+    def __exit__(self, *exc):
+        ref_var.sample_with_top_k_top_p_ = self.orig
+
+
+class PortableMultinomial:
+    """torch.multinomial -> argmax(p/q) with q from the portable Philox stream, one `draw` per call."""
+    def __init__(self, seed, B, V):
+        self.seed, self.B, self.V, self.draw = seed, B, V, 0
+
+    def __enter__(self):
+        self.orig = torch.multinomial
+        def mn(p, num_samples=1, replacement=False, generator=None):
+            assert num_samples == 1 and p.shape[1] == self.V
+            l = p.shape[0] // self.B
+            q = torch.from_numpy(exponential_noise(self.seed, self.draw, self.B, l, self.V)).view(-1, self.V)
+            self.draw += 1
+            return torch.argmax(p / q, dim=-1, keepdim=True)
+        torch.multinomial = mn
+        return self
+
+    def __exit__(self, *exc):
+        torch.multinomial = self.orig
+
+
+def capture_fhat(vae):
+    box = {}
+    orig = vae.fhat_to_img
+    def wrapped(f_hat):
+        box["f_hat"] = f_hat.clone()
+        return orig(f_hat)
+    vae.fhat_to_img = wrapped
+    return box, (lambda: setattr(vae, "fhat_to_img", orig))
+
+
+def build_ref(depth, patch_nums, mode, seed):
+    vae, var = ref_models.build_vae_var(device="cpu", patch_nums=patch_nums, depth=depth)
+    sd_var = var_state_dict(depth, patch_nums, mode, seed)
+    sd_vae = vae_state_dict(patch_nums, mode, seed)
+    var.load_state_dict(sd_var, strict=True)       # proves the key/shape contract of sdvar_amd.weights
+    vae.load_state_dict(sd_vae, strict=True)
+    var.eval(); vae.eval()
+    return vae, var, sd_var, sd_vae
+
+
+def check_multinomial_equivalence():
+    g = torch.Generator(); g.manual_seed(5)
+    p = torch.rand(37, 4096).softmax(-1)
+    a = torch.multinomial(p, 1, replacement=True, generator=g)[:, 0]
+    g.manual_seed(5)
+    b = torch.argmax(p / torch.empty_like(p).exponential_(1, generator=g), -1)
+    assert torch.equal(a, b), "F6 does not hold on this host"
+
+
+def plain_ar_fixture(name, depth, patch_nums, B, labels, cfg, top_k, top_p, g_seed, mode, wseed, store_logits_rows=2):
+    t0 = time.time()
+    vae, var, sd_var, sd_vae = build_ref(depth, patch_nums, mode, wseed)
+    label_B = torch.tensor(labels, dtype=torch.int64)
+    V = 4096
+    model = orc.OracleVAR(sd_var, depth, patch_nums)
+    quant = orc.OracleQuant(sd_vae, patch_nums)
+    out = dict(depth=depth, patch_nums=np.array(patch_nums), B=B, labels=np.array(labels), cfg=cfg, top_k=top_k, top_p=top_p,
+               g_seed=g_seed, mode=mode, wseed=wseed,
+               w_digest=digest(sd_var["head.weight"]), vae_digest=digest(sd_vae["quantize.embedding.weight"]))
+
+    # (a) the reference with its own generator on THIS host
+    box, undo = capture_fhat(vae)
+    with Recorder() as rec:
+        img = var.autoregressive_infer_cfg(B=B, label_B=label_B, g_seed=g_seed, cfg=cfg, top_k=top_k, top_p=top_p)
+    g = torch.Generator(); g.manual_seed(g_seed)
+    tr = orc.plain_ar(model, quant, label_B, cfg, top_k, top_p, orc.torch_noise(g))
+    dmax_a = dmax_b = 0.0
+    for s in range(len(patch_nums)):
+        assert torch.equal(rec.ids[s], tr.ids[s]), f"{name}: oracle ids differ from reference at stage {s} (host stream)"
+        d = (rec.cfg_logits[s] - tr.cfg_logits[s]).abs().max().item()
+        dmax_a = max(dmax_a, d / max(1.0, rec.cfg_logits[s].abs().max().item()))
+    assert dmax_a <= LOGIT_RTOL, (name, dmax_a)
+    assert (box["f_hat"] - tr.f_hat).abs().max().item() <= 1e-5
+    img_o = orc.decode_image(sd_vae, tr.f_hat)
+    assert (img - img_o).abs().max().item() <= 1e-4, (img - img_o).abs().max().item()
+    out["host_ids"] = np.concatenate([i.numpy().astype(np.int16) for i in rec.ids], axis=1)
+    g.manual_seed(g_seed)
+    out["host_noise_probe"] = torch.empty(1, 64).exponential_(1, generator=g).numpy()
+
+    # (b) the reference with the portable noise stream
+    with Recorder() as rec, PortableMultinomial(g_seed, B, V):
+        img = var.autoregressive_infer_cfg(B=B, label_B=label_B, g_seed=g_seed, cfg=cfg, top_k=top_k, top_p=top_p)
+    undo()
+    nfn = orc.array_noise(lambda draw, B_, l, V_: exponential_noise(g_seed, draw, B_, l, V_))
+    tr = orc.plain_ar(model, quant, label_B, cfg, top_k, top_p, nfn)
+    margins = []
+    for s, pn in enumerate(patch_nums):
+        assert torch.equal(rec.ids[s], tr.ids[s]), f"{name}: oracle ids differ from reference at stage {s} (portable)"
+        d = (rec.cfg_logits[s] - tr.cfg_logits[s]).abs().max().item()
+        dmax_b = max(dmax_b, d / max(1.0, rec.cfg_logits[s].abs().max().item()))
+        # top-2 margin of p/q per token: how close the argmax was to flipping (relative gap)
+        _, masked = orc.sample_topk_topp(rec.cfg_logits[s], top_k, top_p, nfn(s, B, pn * pn, V))
+        r = masked.softmax(-1).view(-1, V) / nfn(s, B, pn * pn, V)
+        top2 = r.topk(2, dim=-1)[0]
+        margins.append(((top2[:, 0] - top2[:, 1]) / top2[:, 0]).min().item())
+    assert dmax_b <= LOGIT_RTOL, (name, dmax_b)
+    assert (box["f_hat"] - tr.f_hat).abs().max().item() <= 1e-5
+    out["oracle_vs_ref_logit_relerr"] = np.array([dmax_a, dmax_b])
+    out["ids"] = np.concatenate([i.numpy().astype(np.int16) for i in rec.ids], axis=1)          # (B, L)
+    out["min_rel_margin"] = np.array(margins)
+    out["cfg_logits_digest"] = np.stack([digest(c) for c in rec.cfg_logits])
+    out["cfg_logits_rows"] = np.stack([c[0, :1, :].numpy() for c in rec.cfg_logits])           # (S,1,V) token 0 of image 0
+    out["cfg_logits_last_rows"] = rec.cfg_logits[-1][:, :store_logits_rows].numpy()              # (B,rows,V)
+    out["f_hat"] = box["f_hat"].numpy()
+    out["img_digest"] = digest(img)
+    out["img_small"] = torch.nn.functional.adaptive_avg_pool2d(img, 8).numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"[golden] {name}: ok in {time.time() - t0:.1f}s  min margin {min(margins):.2e}  oracle-vs-ref logits rel err {dmax_a:.2e}/{dmax_b:.2e}")
+
+
+def sampler_fixture():
+    """helpers.py:6-19 known answers on synthetic logits, incl. ties at the k-th value and top_k/top_p off."""
+    from models.helpers import sample_with_top_k_top_p_ as ref_sampler
+    rng = np.random.Generator(np.random.Philox(key=[11, 22]))
+    B, l, V = 2, 5, 4096
+    cases = []
+    for ci, (tk, tp, scale) in enumerate([(900, 0.96, 3.0), (0, 0.96, 3.0), (900, 0.0, 3.0), (0, 0.0, 1.0), (1, 0.0, 2.0), (50, 0.5, 6.0), (4096, 0.999, 0.5)]):
+        lg = torch.from_numpy(rng.standard_normal(size=(B, l, V), dtype=np.float32) * np.float32(scale))
+        if ci == 2:   # ties around the k-th largest value
+            srt = lg.sort(-1, descending=True)[0]
+            lg[lg == srt[..., 899:900]] = 0.0
+            lg[..., :7] = srt[..., 899:900]
+        q = torch.from_numpy(exponential_noise(77, ci, B, l, V)).view(-1, V)
+        class _PM:
+            def __enter__(s):
+                s.orig = torch.multinomial
+                torch.multinomial = lambda p, num_samples=1, replacement=False, generator=None: torch.argmax(p / q, -1, keepdim=True)
+            def __exit__(s, *e): torch.multinomial = s.orig
+        work = lg.clone()
+        with _PM():
+            ids_ref = ref_sampler(work, top_k=tk, top_p=tp, rng=None, num_samples=1)[:, :, 0]
+        ids_o, masked_o = orc.sample_topk_topp(lg, tk, tp, q)
+        assert torch.equal(ids_ref, ids_o)
+        assert torch.equal(torch.isinf(work), torch.isinf(masked_o))
+        cases.append(dict(top_k=tk, top_p=tp, scale=scale, ids=ids_ref.numpy(), n_keep=(~torch.isinf(work)).sum(-1).numpy()))
+    np.savez_compressed(os.path.join(OUT, "sampler_cases.npz"),
+                        top_k=np.array([c["top_k"] for c in cases]), top_p=np.array([c["top_p"] for c in cases]),
+                        scale=np.array([c["scale"] for c in cases]), ids=np.stack([c["ids"] for c in cases]),
+                        n_keep=np.stack([c["n_keep"] for c in cases]))
+    print("[golden] sampler_cases ok")
+
+
+def quant_fixture():
+    """quant.py:187-196 + var.py:186-188 for every stage of both ladders (random ids, stress VQVAE weights)."""
+    for lname, pns in (("256", LADDER_256), ("512", LADDER_512)):
+        vae = ref_models.VQVAE(vocab_size=4096, z_channels=32, ch=160, test_mode=True, share_quant_resi=4, v_patch_nums=pns)
+        sd_vae = vae_state_dict(pns, "stress", 1234)
+        vae.load_state_dict(sd_vae, strict=True)
+        quant = orc.OracleQuant(sd_vae, pns)
+        rng = np.random.Generator(np.random.Philox(key=[5, len(pns) + pns[-1]]))
+        B, S = 2, len(pns)
+        f_ref = torch.zeros(B, 32, pns[-1], pns[-1]); f_o = f_ref.clone()
+        nxt_digest, ids_all = [], []
+        for si, pn in enumerate(pns):
+            ids = torch.from_numpy(rng.integers(0, 4096, size=(B, pn * pn)))
+            ids_all.append(ids.numpy().astype(np.int16))
+            h = vae.quantize.embedding(ids).transpose_(1, 2).reshape(B, 32, pn, pn)
+            f_ref, nxt_ref = vae.quantize.get_next_autoregressive_input(si, S, f_ref, h)
+            f_o, nxt_o = quant.next_input(si, f_o, quant.embed_ids(ids, pn))
+            assert (f_ref - f_o).abs().max().item() <= 1e-5 and (nxt_ref - nxt_o).abs().max().item() <= 1e-5
+            assert quant.phi_of(si) == [0, 0, 1, 1, 1, 2, 2, 3, 3, 3][si]
+            nxt_digest.append(digest(nxt_ref))
+        np.savez_compressed(os.path.join(OUT, f"quant_{lname}.npz"), patch_nums=np.array(pns), ids=np.concatenate(ids_all, 1),
+                            f_hat=f_ref.numpy(), next_digest=np.stack(nxt_digest))
+        print(f"[golden] quant_{lname} ok")
+
+
+def sd_fixture():
+    """Reference SDVAR components that run: basic_token_matching known answers, round 1 of
+    draft_generate_batch for gamma 1..3, chunk-verify == stage-wise (I2) with reference modules, sd_test3 hand-off."""
+    pns = LADDER_256
+    dd, dt, B = 4, 6, 2
+    vae, draft, target, sd = ref_models.build_vae_var_speculative_decoding(device="cpu", patch_nums=pns, depth_draft=dd, depth_target=dt)
+    sd_d, sd_t, sd_v = var_state_dict(dd, pns, "stress", 1234), var_state_dict(dt, pns, "stress", 1234), vae_state_dict(pns, "stress", 1234)
+    draft.load_state_dict(sd_d); target.load_state_dict(sd_t); vae.load_state_dict(sd_v)
+    draft.eval(); target.eval()
+    od, ot, oq = orc.OracleVAR(sd_d, dd, pns), orc.OracleVAR(sd_t, dt, pns), orc.OracleQuant(sd_v, pns)
+    labels = torch.tensor([3, 977])
+    out = dict(dd=dd, dt=dt, B=B, labels=labels.numpy())
+    V = 4096
+
+    # -- basic_token_matching (var.py:1160-1227) known answers vs oracle accept_scan
+    class St: pass
+    rng = np.random.Generator(np.random.Philox(key=[9, 9]))
+    kat = []
+    for case in range(6):
+        st = St(); st.current_stage = 4; st.patch_nums = pns
+        toks, lgs = [], []
+        for j in range(3):
+            n = pns[4 + j] ** 2
+            lg = torch.from_numpy(rng.standard_normal(size=(B, n, V), dtype=np.float32))
+            am = lg.argmax(-1)
+            frac = [[1.0, 1.0, 1.0], [1.0, 0.52, 0.2], [0.5, 0.5, 0.49], [0.49, 1.0, 1.0], [1.0, 1.0, 0.0], [0.75, 0.5, 0.5]][case][j]
+            k = int(round(frac * B * n))
+            flat = am.reshape(-1).clone()
+            wrong = (flat + 1) % V
+            flat[k:] = wrong[k:]
+            toks.append(flat.view(B, n)); lgs.append(lg)
+        n_ref = sd.basic_token_matching(toks, lgs, st, B)
+        n_o, matched, total = orc.accept_scan(toks, lgs, 0.5)
+        assert n_ref == n_o, (case, n_ref, n_o)
+        kat.append([n_ref] + matched + total)
+    out["accept_kat"] = np.array(kat)
+
+    # -- draft_generate_batch round 1 (var.py:949-1024) for gamma 1..3 under the portable noise
+    for gamma in (1, 2, 3):
+        state = sd._initialize_inference_state(B, labels, 0, 1.5, gamma)
+        state.top_k, state.top_p = 900, 0.96
+        with PortableMultinomial(0, B, V):
+            toks = sd.draft_generate_batch(state, B)
+        for blk in draft.blocks: blk.attn.kv_caching(False)
+        nfn = orc.array_noise(lambda d, B_, l, V_: exponential_noise(0, d, B_, l, V_))
+        # oracle: the first `gamma` stages of a plain draft AR are the same computation
+        tr = orc.plain_ar(od, oq, labels, 1.5, 900, 0.96, nfn, keep=False)
+        for j in range(gamma):
+            assert torch.equal(toks[j], tr.ids[j]), ("draft_generate_batch", gamma, j)
+        out[f"draft_round1_g{gamma}"] = np.concatenate([t.numpy().astype(np.int16) for t in toks], 1)
+
+    # -- I2: chunk verify == stage-wise, reference modules only, then the oracle's chunk forward against it
+    tr = orc.plain_ar(ot, oq, labels, 1.5, 900, 0.96, nfn, keep=True)
+    cond = target.class_emb(torch.cat((labels, torch.full_like(labels, 1000))))
+    for (s0, n) in ((3, 2), (5, 3), (0, 2), (8, 2)):
+        for blk in target.blocks: blk.attn.kv_caching(True)
+        for s in range(s0):                                   # prefill the cache stage by stage
+            x = tr.x_in[s]
+            for blk in target.blocks: x = blk(x=x, cond_BD=cond, attn_bias=None)
+        bg, ed = ot.begin(s0), int(ot.cum[s0 + n - 1])
+        x = torch.cat(tr.x_in[s0:s0 + n], 1)
+        bias = target.attn_bias_for_masking[:, :, bg:ed, :ed]
+        for blk in target.blocks: x = blk(x=x, cond_BD=cond, attn_bias=bias)
+        lg_chunk = target.get_logits(x, cond)
+        for blk in target.blocks: blk.attn.kv_caching(False)
+        lg_stage = torch.cat(tr.logits[s0:s0 + n], 1)
+        d_ref = (lg_chunk - lg_stage).abs().max().item()
+        assert d_ref <= 1e-4, d_ref
+        # oracle chunk forward
+        ot.kv_reset()
+        for s in range(s0): ot.forward(tr.x_in[s], cond, s, 1)
+        lg_o = ot.forward(torch.cat(tr.x_in[s0:s0 + n], 1), cond, s0, n)
+        ot.kv_reset()
+        d_o = (lg_o - lg_chunk).abs().max().item()
+        assert d_o <= 1e-5, d_o
+        out[f"chunk_{s0}_{n}_digest"] = digest(lg_chunk)
+        out[f"chunk_{s0}_{n}_row"] = lg_chunk[0, -1].numpy()
+    # -- I6: sd_test3 hand-off (var.py:604-865) entry_num 0 / S equals plain target / draft AR
+    for entry, who, omodel in ((0, "target", ot), (10, "draft", od)):
+        with Recorder() as rec, PortableMultinomial(0, B, V):
+            sd.sdvar_autoregressive_infer_cfg_sd_test3(B=B, label_B=labels, g_seed=0, cfg=1.5, top_k=900, top_p=0.96, entry_num=entry, sd_mask=0)
+        tr2 = orc.plain_ar(omodel, oq, labels, 1.5, 900, 0.96, nfn, keep=False)
+        for s in range(10):
+            assert torch.equal(rec.ids[s], tr2.ids[s]), ("sd_test3", entry, s)
+        out[f"handoff_{who}_ids"] = np.concatenate([i.numpy().astype(np.int16) for i in rec.ids], 1)
+    # -- the oracle's speculative loop itself (no runnable reference: values stored to detect drift only)
+    for mode, thr in (("natural", 0.5), ("accept_all", 0.0), ("reject_all", 2.0)):
+        for gamma in (1, 2, 3):
+            tr3 = orc.spec_decode(od, ot, oq, labels, 1.5, gamma, 900, 0.96, nfn, thr=thr)
+            out[f"spec_{mode}_g{gamma}_ids"] = np.concatenate([i.numpy().astype(np.int16) for i in tr3.ids], 1)
+            out[f"spec_{mode}_g{gamma}_stats"] = np.array([tr3.stats["target_calls"], tr3.stats["draft_stage_calls"],
+                                                            tr3.stats["forced_accepts"], tr3.stats["accepted_tokens"]])
+    np.savez_compressed(os.path.join(OUT, "sd_components.npz"), **out)
+    print("[golden] sd_components ok")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["all"]
+    check_multinomial_equivalence()
+    if "all" in which or "sampler" in which: sampler_fixture()
+    if "all" in which or "quant" in which: quant_fixture()
+    if "all" in which or "ar" in which:
+        plain_ar_fixture("ar_d4_256_stress", 4, LADDER_256, 2, [3, 977], 1.5, 900, 0.96, 0, "stress", 1234)
+        plain_ar_fixture("ar_d6_256_stress", 6, LADDER_256, 2, [3, 977], 1.5, 900, 0.96, 0, "stress", 1234)
+        plain_ar_fixture("ar_d4_512_stress", 4, LADDER_512, 1, [417], 3.0, 900, 0.96, 1, "stress", 1234)
+        plain_ar_fixture("ar_d4_256_notopkp", 4, LADDER_256, 2, [1000, 5], 1.5, 0, 0.0, 3, "stress", 1234)
+    if "all" in which or "sd" in which: sd_fixture()
+    if "all" in which or "d16" in which:
+        plain_ar_fixture("ar_d16_256_stress_B1", 16, LADDER_256, 1, [207], 1.5, 900, 0.96, 0, "stress", 1234)
