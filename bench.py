@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/s of the speculative draft->verify sampler, VAR-d16 256^2, B=8 per GPU, d12 draft
+(BASELINE.json configs[1]), random-init weights, synthetic labels.  One process per GPU (torchrun env), weak scaling:
+every rank samples its own B images; the only collective is the RCCL all-gather of the per-rank counters.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      the dominant kernel class of the step (by HIP-event time on the launch stream), algorithmic
+                flops / bytes per launch from DESIGN.md section 4 vs the gfx950 peak
+  cpu_baseline  the CPU oracle (oracle/var_oracle.py, the pinned restatement of the reference's
+                VAR.autoregressive_infer_cfg, target model only, no speculation) timed on this host's cores, N=1 only
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0             # same guide, HBM3E spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU")
+    ap.add_argument("--depth-draft", type=int, default=12)
+    ap.add_argument("--depth-target", type=int, default=16)
+    ap.add_argument("--gamma", type=int, default=2)
+    ap.add_argument("--mode", default="natural", choices=["natural", "accept_all", "reject_all"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-modes", action="store_true")
+    args = ap.parse_args()
+
+    from sdvar_amd import dist as D
+    from sdvar_amd import engine as E
+    from sdvar_amd.ladder import LADDER_256, as_ladder
+    from sdvar_amd.vqvae import VQVAE
+    from sdvar_amd.weights import var_state_dict_device, vae_state_dict
+
+    rank, world, local = D.init_from_env("cuda")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    torch.set_grad_enabled(False)
+    pns, B, lad = LADDER_256, args.batch, as_ladder(LADDER_256)
+    thr = {"natural": 0.5, "accept_all": 0.0, "reject_all": 2.0}
+
+    sd_d = var_state_dict_device(args.depth_draft, pns, dev, seed=1234)
+    sd_t = var_state_dict_device(args.depth_target, pns, dev, seed=1234)
+    sd_v = vae_state_dict(pns, "perf", 1234, with_encoder=False)
+    vae = VQVAE(vocab_size=4096, z_channels=32, ch=160, v_patch_nums=pns, with_encoder=False)
+    vae.load_state_dict(sd_v); vae = vae.to(dev)
+    dc = E.ModelCtx(sd_d, args.depth_draft, pns, B, 1, dev)
+    tc = E.ModelCtx(sd_t, args.depth_target, pns, B, max(args.gamma, 1), dev)
+    qc = E.QuantCtx(sd_v, pns, B, dev)
+    smp = E.Sampler(tc, qc, dc)
+    lo, _ = D.shard_range(B * world, rank, world)
+    labels = ((torch.arange(B) + lo) % 1000).to(dev)
+
+    def step(mode, seed):
+        res = smp.spec_decode(labels, 1.5, args.gamma, 900, 0.96, E.Noise("device", seed, image_offset=lo), thr=thr[mode])
+        img = vae.fhat_to_img(res.f_hat).add_(1).mul_(0.5)          # (B,3,256,256) in [0,1]  (var.py:215)
+        st = dict(res.stats); st["images"] = B
+        return img, st
+
+    def timed(mode, steps, warmup):
+        for i in range(warmup):
+            step(mode, i)
+        D.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tot = {k: 0 for k in D.COUNTER_KEYS}
+        for i in range(steps):
+            _, st = step(mode, 1000 + i)
+            for k in tot: tot[k] += int(st.get(k, 0))
+        agg = D.gather_counters(tot, dev)                            # the one collective: counters only
+        torch.cuda.synchronize(); D.barrier()
+        dt = D.max_over_ranks(time.perf_counter() - t0, dev)
+        return dt, agg
+
+    dt, agg = timed(args.mode, args.steps, args.warmup)
+    value = agg["images"] / dt
+
+    # no-decode rate (sampler only), same mode, shorter
+    def timed_nodecode(steps):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(steps):
+            smp.spec_decode(labels, 1.5, args.gamma, 900, 0.96, E.Noise("device", 2000 + i, image_offset=lo), thr=thr[args.mode])
+        torch.cuda.synchronize()
+        return D.max_over_ranks(time.perf_counter() - t0, dev)
+    nd_steps = max(2, args.steps // 2)
+    dt_nd = timed_nodecode(nd_steps)
+
+    extra = {}
+    if not args.no_extra_modes:
+        for m in ("accept_all", "reject_all", "natural"):
+            if m == args.mode:
+                continue
+            d2, a2 = timed(m, max(2, args.steps // 3), 1)
+            extra[m] = dict(images_per_s=a2["images"] / d2, mean_accepted_tokens_per_step=a2["mean_accepted_tokens_per_step"],
+                            target_calls_per_image_batch=a2["target_calls"] / max(1, a2["images"] // B))
+
+    # ---- roofline leg: HIP events around every launch of one step (launch stream = torch's current stream)
+    E.prof_enable(True)
+    step(args.mode, 4242)
+    prof = E.prof_collect()
+    E.prof_enable(False)
+    classes = {k: v for k, v in prof.items() if v["launches"]}
+    dom = max(classes, key=lambda k: classes[k]["ms"])
+    def roof(name):
+        c = classes[name]
+        sec = c["ms"] * 1e-3
+        if name == "gemm":
+            ach = c["flops"] / sec / 1e12
+            return dict(kernel="gemm_f32_nt_kernel", bound="mfma", achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_F32_MFMA_TFLOPS,
+                        traffic=None, launches=c["launches"], avg_us=c["ms"] * 1e3 / c["launches"])
+        ach = c["bytes"] / sec / 1e9
+        return dict(kernel=name, bound="hbm", achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS, traffic=None,
+                    launches=c["launches"], avg_us=c["ms"] * 1e3 / c["launches"], tflops=c["flops"] / sec / 1e12)
+    roofline = roof(dom)
+    roofline_attn = roof("attention") if "attention" in classes else None
+    class_ms = {k: round(v["ms"], 3) for k, v in classes.items()}
+
+    out = {
+        "metric": "images/s (+ mean accepted tokens/step), VAR-d16 256^2 B=8 per GPU, d12 draft + d16 verify",
+        "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic (random-init weights, labels arange(B)%1000, device Philox noise)",
+        "config": {"workload": f"VAR-d{args.depth_target} 256^2 B={B}/GPU, d{args.depth_draft} draft + d{args.depth_target} verify, gamma={args.gamma}, "
+                               f"cfg=1.5 top_k=900 top_p=0.96, acceptance={args.mode}, incl. VQVAE decode", "parallelism": f"{world} independent batch shards"},
+        "mean_accepted_tokens_per_step": agg["mean_accepted_tokens_per_step"],
+        "target_calls": agg["target_calls"], "draft_stage_calls": agg["draft_stage_calls"], "forced_accepts": agg["forced_accepts"],
+        "images_per_s_no_decode": B * world * nd_steps / dt_nd,
+        "modes": extra, "roofline": roofline, "roofline_verify_attention": roofline_attn, "kernel_class_ms_per_step": class_ms,
+    }
+
+    # ---- CPU baseline (rank 0, N=1): the oracle's plain AR of the TARGET model on the host cores
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import var_oracle as orc
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        sd_cpu = {k: v.cpu() for k, v in sd_t.items()}
+        model, quant = orc.OracleVAR(sd_cpu, args.depth_target, pns), orc.OracleQuant(sd_v, pns)
+        g = torch.Generator(); g.manual_seed(0)
+        t0 = time.perf_counter()
+        tr = orc.plain_ar(model, quant, labels.cpu(), 1.5, 900, 0.96, orc.torch_noise(g), keep=False)
+        t_ar = time.perf_counter() - t0
+        orc.decode_image(sd_v, tr.f_hat)
+        t_all = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": B / t_all, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"1 call of plain autoregressive_infer_cfg (target d{args.depth_target} only, no speculation), B={B}, incl. decode; "
+                                         f"{t_all:.1f}s ({t_ar:.1f}s without decode)", "images_per_s_no_decode": B / t_ar}
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

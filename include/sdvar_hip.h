@@ -1,0 +1,122 @@
+/* libsdvar_hip.so - C ABI of the MI355X (gfx950) speculative draft-verify sampler kernels for VAR.
+ *
+ * The reference (lijrjyan/SDVAR) is pure Python/PyTorch and has no FFI; the boundary it exposes for this path is its
+ * Python API.  Each entry point below replaces the op sequence of the reference lines cited on
+ * it; sdvar_amd/engine.py is the ctypes binding and sdvar_amd/var.py mirrors VAR / SDVAR on top of it.
+ *
+ * Conventions: every pointer is a DEVICE pointer unless marked "host"; tensors are dense row-major fp32, ids int64;
+ * all work is enqueued on the caller's `stream` (a hipStream_t passed as void*, NULL = default stream) and returns
+ * without synchronising; return value 0 = ok, otherwise see sdvar_last_error().  The library never owns caller
+ * memory; the KV cache, adaLN table and workspaces it allocates itself are freed by the *_destroy calls.
+ * One host thread per model object (same contract as the reference's module-attribute caches, basic_var.py:85-87).
+ */
+#ifndef SDVAR_HIP_H
+#define SDVAR_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDVAR_ABI_VERSION 1
+#define SDVAR_MAX_STAGES 16
+
+typedef struct sdvar_model sdvar_model_t;   /* one VAR transformer: weights (borrowed), KV cache, workspaces */
+typedef struct sdvar_quant sdvar_quant_t;   /* VectorQuantizer2 inference side: codebook, Phi convs, resample tables */
+
+typedef struct {
+    int32_t depth;                          /* d: width C = 64 d, heads H = d   (models/__init__.py:26-27) */
+    int32_t n_stages;                       /* S */
+    int32_t patch_nums[SDVAR_MAX_STAGES];   /* the scale ladder                (models/__init__.py:18) */
+    int32_t vocab;                          /* V = 4096 */
+    int32_t cvae;                           /* 32 */
+    int32_t num_classes;                    /* 1000; class_emb has num_classes + 1 rows (var.py:62) */
+    int32_t max_batch;                      /* B; the CFG batch is R = 2B rows (var.py:162,188) */
+    int32_t max_chunk_stages;               /* largest number of stages one forward may cover (gamma) */
+} sdvar_model_desc;
+
+int sdvar_abi_version(void);
+const char* sdvar_last_error(void);        /* host string, valid until the next failing call on this thread */
+
+/* ---- model object -------------------------------------------------------------------------------------------- */
+int sdvar_model_create(const sdvar_model_desc* desc /*host*/, sdvar_model_t** out /*host*/);
+int sdvar_model_destroy(sdvar_model_t* m);
+/* state_dict tensors of models/var.py:56-78: class_emb (num_classes+1, C), pos_start (1,1,C), pos_1LC (1,L,C),
+ * lvl_embed (S,C), word_embed.{weight (C,cvae), bias (C)}.  Builds lvl_pos = lvl_embed[lvl] + pos_1LC (var.py:164). */
+int sdvar_model_bind_embed(sdvar_model_t* m, const float* class_emb, const float* pos_start, const float* pos_1LC,
+                           const float* lvl_embed, const float* word_w, const float* word_b, void* stream);
+/* one AdaLNSelfAttn block (basic_var.py:128-159): ada_lin.1.{weight (6C,C), bias}, attn.mat_qkv.weight (3C,C),
+ * attn.q_bias, attn.v_bias, attn.scale_mul_1H11 (H), attn.proj.{weight,bias}, ffn.fc1.{weight (4C,C),bias},
+ * ffn.fc2.{weight (C,4C),bias}. */
+int sdvar_model_bind_block(sdvar_model_t* m, int32_t block, const float* ada_w, const float* ada_b, const float* qkv_w,
+                           const float* q_bias, const float* v_bias, const float* scale_mul, const float* proj_w,
+                           const float* proj_b, const float* fc1_w, const float* fc1_b, const float* fc2_w,
+                           const float* fc2_b, void* stream);
+/* head_nm.ada_lin.1.{weight (2C,C), bias}, head.{weight (V,C), bias}  (basic_var.py:165-174, var.py:116-117) */
+int sdvar_model_bind_head(sdvar_model_t* m, const float* nm_w, const float* nm_b, const float* head_w, const float* head_b);
+
+/* Per-call prologue (var.py:162-183, 580-601): cond = class_emb[labels ; uncond], first-token map, adaLN parameters
+ * of every block and of the head hoisted out of the stage loop (basic_var.py:156, :173 - cond never changes), KV
+ * length cursor reset (basic_var.py:87).  labels: (B) int64. */
+int sdvar_model_begin(sdvar_model_t* m, int32_t B, const int64_t* labels, void* stream);
+/* copy the first-token map (R,1,C) into a chunk input x (R, ltot, C) at token 0 */
+int sdvar_model_place_first(sdvar_model_t* m, float* x, int32_t ltot, void* stream);
+/* KV-cache cursor: number of valid keys; set_len(n) with n <= current is the rollback after a rejected round. */
+int sdvar_kv_len(const sdvar_model_t* m);
+int sdvar_kv_set_len(sdvar_model_t* m, int32_t len);
+/* next-stage input embedding + CFG duplication (var.py:186-188): nxt (B, l', cvae) -> x rows b and B+b,
+ * x[(r*ltot + tok_off + t)*C + :] = word_embed(nxt[b][t]) + lvl_pos[begin(s_next) + t]. */
+int sdvar_embed_next(sdvar_model_t* m, const float* nxt, int32_t s_next, float* x, int32_t ltot, int32_t tok_off, void* stream);
+/* All blocks + head over the stages s0 .. s0+n_stages-1 in ONE pass (var.py:195-197; verify chunk var.py:1051-1055
+ * with the mask rows of var.py:108-113 derived from the stage table).  x (R, lsum, C) is the input and is CLOBBERED
+ * (it is the residual stream); logits (R, lsum, V).  Requires kv_len == begin(s0); appends lsum keys. */
+int sdvar_stage_forward(sdvar_model_t* m, float* x, int32_t s0, int32_t n_stages, float* logits, void* stream);
+
+/* ---- quantizer ----------------------------------------------------------------------------------------------- */
+int sdvar_quant_create(int32_t n_stages, const int32_t* patch_nums /*host*/, int32_t cvae, int32_t vocab, int32_t max_batch,
+                       int32_t n_phi, sdvar_quant_t** out /*host*/);
+int sdvar_quant_destroy(sdvar_quant_t* q);
+/* quantize.embedding.weight (V,cvae); quantize.quant_resi.qresi_ls.k.{weight (cvae,cvae,3,3), bias} as host arrays of
+ * n_phi device pointers (quant.py:39, 199-229). */
+int sdvar_quant_bind(sdvar_quant_t* q, const float* codebook, const float* const* phi_w /*host*/, const float* const* phi_b /*host*/);
+/* quant.py:187-196 for stage si: f_hat (B,cvae,HW,HW) += Phi(up(codebook[ids])) in place; nxt (B, pn_{si+1}^2, cvae)
+ * = area_down(f_hat) (not written for the last stage; may be NULL there).  ids[b*ids_stride + p]. */
+int sdvar_quant_next(sdvar_quant_t* q, int32_t si, const int64_t* ids, int32_t ids_stride, float* f_hat, float* nxt, int32_t B, void* stream);
+
+/* ---- sampling / acceptance -------------------------------------------------------------------------------------- */
+/* var.py:199-202 + helpers.py:6-19: CFG with t = cfg*si/(S-1), top-k, top-p, draw = argmax(p/q).
+ * q: explicit Exp(1) noise (B*l, V), or NULL to generate the Philox stream of sdvar_amd/noise.py in-kernel from
+ * (seed, draw, image_offset).  ids_out[b*ids_stride + tok].  dbg_masked: optional (B,l,V) masked logits. */
+int sdvar_cfg_sample(const float* logits, int32_t B, int32_t l, int32_t V, double t, int32_t top_k, double top_p, const float* q,
+                     uint64_t seed, uint32_t draw, uint32_t image_offset, int64_t* ids_out, int32_t ids_stride, float* dbg_masked,
+                     void* stream);
+/* var.py:1062-1067 + 1199-1222 over a verified chunk: per stage CFG (t[j], host doubles) -> argmax_V -> compare with
+ * the draft ids -> matched count; n_accept = leading stages with float32 match rate >= thr.
+ * counts (40 x int32, device): [0..16) matched per stage, [16] n_accept, [17..33) tokens per stage. */
+int sdvar_verify_accept(const float* logits, int32_t B, int32_t lsum, int32_t V, int32_t n_stages, const int32_t* stage_lens /*host*/,
+                        const double* t /*host*/, const int64_t* draft_ids, int32_t ids_stride, double thr, int32_t* counts,
+                        int64_t* argmax_out, void* stream);
+
+/* ---- single operators (kernel-level parity tests and micro-benchmarks) ---------------------------------------------- */
+/* out[M,N] = epi(X[M,K] W[N,K]^T + bias); epi 0 bias, 1 bias+GELU(tanh), 2 res + (.)*gate[row / rows_per_gate] */
+int sdvar_op_gemm(const float* X, int32_t ldx, const float* W, const float* bias, float* out, int32_t ldo, int32_t M, int32_t N, int32_t K,
+                  int32_t epilogue, const float* res, int32_t ldres, const float* gate, int32_t rows_per_gate, int32_t gate_stride, void* stream);
+int sdvar_op_ln_modulate(const float* x, const float* scale, const float* shift, float* out, int32_t rows, int32_t C,
+                         int32_t rows_per_img, int32_t mod_stride, void* stream);
+int sdvar_op_qk_norm_append(const float* qkv, const float* scale_mul, float* q_out, float* k_cache, float* v_cache, int32_t R, int32_t l,
+                            int32_t H, int32_t Lmax, int32_t pos0, void* stream);
+/* q (R,H,l,64), caches (R,H,Lmax,64) with Ktot valid keys, out (R,l,H*64); queries >= qbeg[j] see keys < vis[j] */
+int sdvar_op_attention(const float* q, const float* k_cache, const float* v_cache, float* out, int32_t R, int32_t H, int32_t l, int32_t Lmax,
+                       int32_t Ktot, int32_t n_stages, const int32_t* qbeg /*host*/, const int32_t* vis /*host*/, void* stream);
+int sdvar_op_noise_fill(float* q, int32_t B, int32_t l, int32_t V, uint64_t seed, uint32_t draw, uint32_t image_offset, void* stream);
+
+/* ---- per-kernel-class timing with HIP events on the launch stream (bench.py roofline leg) ----------------------------- */
+#define SDVAR_PROF_CLASSES 8   /* 0 gemm, 1 attention, 2 ln_modulate, 3 qk_norm_append, 4 sampler, 5 verify, 6 quant, 7 embed/misc */
+int sdvar_prof_enable(int32_t on);
+/* synchronises the recorded events and accumulates: ms, launches, algorithmic flops, algorithmic bytes per class */
+int sdvar_prof_collect(double* ms /*host[8]*/, int64_t* launches /*host[8]*/, double* flops /*host[8]*/, double* bytes /*host[8]*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDVAR_HIP_H */

@@ -1,0 +1,468 @@
+// C ABI of libsdvar_hip.so (declared in include/sdvar_hip.h): model / quantizer objects, the stage-forward driver that
+// strings the kernels together on one stream, and the single-operator entry points used by the parity tests.
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/sdvar_hip.h"
+#include "common.h"
+
+namespace sdvar {
+
+// kernels (gemm.hip, elementwise.hip, attention.hip, sampler.hip, quant.hip)
+int gemm_f32_nt(const float* X, int ldx, const float* W, const float* bias, float* out, int ldo, int M, int N, int K, int epi,
+                const float* res, int ldres, const float* gate, int rows_per_gate, int gate_stride, hipStream_t stream);
+int ln_modulate(const float* x, const float* scale, const float* shift, float* out, int rows, int C, int rows_per_img, int mod_stride, hipStream_t stream);
+int qk_norm_append(const float* qkv, const float* scale_mul, float* q_out, float* k_cache, float* v_cache, int R, int l, int H, int Lmax, int pos0, hipStream_t stream);
+int silu_rows(const float* x, float* y, int n, hipStream_t stream);
+int prologue(const long long* labels, const float* class_emb, const float* pos_start, const float* lvl_pos, float* cond, float* x0, int B, int C, int num_classes, hipStream_t stream);
+int build_lvl_pos(const float* lvl_embed, const float* pos, const int* stage_of_tok, float* out, int L, int C, hipStream_t stream);
+int embed_next(const float* nxt, const float* Ww, const float* bw, const float* lvl_pos, float* x, int B, int l, int C, int t0, int ltot, int tok_off, hipStream_t stream);
+int attention_f32(const float* q, const float* kc, const float* vc, float* out, int R, int H, int l, int Lmax, int Ktot, int n_chunk, const int* qbeg, const int* vis, hipStream_t stream);
+int cfg_sample(const float* logits, int B, int l, int V, float one_plus_t, float t, int top_k, int use_top_p, float top_p_thr, const float* q, uint64_t seed,
+               uint32_t draw, uint32_t image_offset, long long* ids, int ids_stride, float* dbg_masked, hipStream_t stream);
+int noise_fill(float* q, int B, int l, int V, uint64_t seed, uint32_t draw, uint32_t image_offset, hipStream_t stream);
+int verify_accept(const float* logits, int B, int lsum, int V, int n_chunk, const int* qbeg, const float* one_plus_t, const float* t, const long long* draft_ids,
+                  int ids_stride, double thr, int* counts, long long* argmax_out, hipStream_t stream);
+int quant_next(const long long* ids, int ids_stride, const float* codebook, const float* Wup, const float* phi_w, const float* phi_b, const float* Wdn,
+               float* up_scratch, float* f_hat, float* nxt, int B, int pn, int pn_next, int HW, int Cv, int last, hipStream_t stream);
+
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_GATED_RES = 2 };
+
+static thread_local char g_err[1024] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ---- event timing per kernel class -----------------------------------------------------------------------------------
+struct ProfRec { int cls; hipEvent_t e0, e1; double flops, bytes; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static double g_ms[SDVAR_PROF_CLASSES], g_fl[SDVAR_PROF_CLASSES], g_by[SDVAR_PROF_CLASSES];
+static long long g_n[SDVAR_PROF_CLASSES];
+
+struct ProfScope {
+    bool on; ProfRec r; hipStream_t s;
+    ProfScope(int cls, double flops, double bytes, hipStream_t stream) : on(g_prof_on), s(stream) {
+        if (!on) return;
+        r.cls = cls; r.flops = flops; r.bytes = bytes;
+        (void)hipEventCreate(&r.e0); (void)hipEventCreate(&r.e1);
+        (void)hipEventRecord(r.e0, s);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(r.e1, s);
+        g_prof.push_back(r);
+    }
+};
+
+template <typename T>
+static int dmalloc(T** p, size_t n) {
+    *p = nullptr;
+    SDVAR_HIP(hipMalloc((void**)p, n * sizeof(T)));
+    return SDVAR_OK;
+}
+#define SDVAR_TRY(call) do { int rc_ = (call); if (rc_ != SDVAR_OK) return rc_; } while (0)
+
+struct BlockW {
+    const float *ada_w, *ada_b, *qkv_w, *scale_mul, *proj_w, *proj_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+    float* qkv_bias;     // owned: [q_bias, 0, v_bias]  (basic_var.py:93)
+    float *kc, *vc;      // owned KV cache (Rmax, H, L, 64)
+    bool bound;
+};
+
+}  // namespace sdvar
+
+using namespace sdvar;
+
+struct sdvar_model {
+    sdvar_model_desc d;
+    int C, H, L, Rmax, lmax, S;
+    int lens[SDVAR_MAX_STAGES], cum[SDVAR_MAX_STAGES];
+    // borrowed
+    const float *class_emb, *pos_start, *word_w, *word_b, *nm_w, *nm_b, *head_w, *head_b;
+    std::vector<BlockW> blk;
+    bool embed_bound, head_bound;
+    // owned
+    float *lvl_pos, *cond, *cond_silu, *x0, *ada, *ada_head;
+    float *xn, *qkv, *qbuf, *att, *hid;
+    int* stage_of_tok;
+    // run state
+    int B, kv_len;
+    bool begun;
+};
+
+struct sdvar_quant {
+    int S, Cv, V, maxB, HW, n_phi;
+    int pn[SDVAR_MAX_STAGES], phi_of[SDVAR_MAX_STAGES];
+    float* Wup[SDVAR_MAX_STAGES];
+    float* Wdn[SDVAR_MAX_STAGES];
+    std::vector<std::vector<float>> hWup, hWdn;
+    float* up_scratch;
+    const float* codebook;
+    const float* phi_w[8];
+    const float* phi_b[8];
+    bool bound;
+};
+
+static inline int begin_of(const sdvar_model* m, int s) { return s == 0 ? 0 : m->cum[s - 1]; }
+
+extern "C" {
+
+int sdvar_abi_version(void) { return SDVAR_ABI_VERSION; }
+const char* sdvar_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------------------------------------------- model object
+int sdvar_model_create(const sdvar_model_desc* desc, sdvar_model_t** out) {
+    SDVAR_CHECK_ARG(desc && out, "model_create: null argument");
+    SDVAR_CHECK_ARG(desc->depth >= 1 && desc->depth <= 64, "model_create: depth %d", desc->depth);
+    SDVAR_CHECK_ARG(desc->n_stages >= 1 && desc->n_stages <= SDVAR_MAX_STAGES, "model_create: n_stages %d", desc->n_stages);
+    SDVAR_CHECK_ARG(desc->vocab > 0 && desc->vocab <= 4096 && desc->vocab % 4 == 0, "model_create: vocab %d", desc->vocab);
+    SDVAR_CHECK_ARG(desc->cvae == 32, "model_create: cvae must be 32 (got %d)", desc->cvae);
+    SDVAR_CHECK_ARG(desc->max_batch >= 1 && desc->num_classes >= 1, "model_create: batch/classes");
+    SDVAR_CHECK_ARG(desc->max_chunk_stages >= 1 && desc->max_chunk_stages <= SDVAR_MAX_STAGES, "model_create: max_chunk_stages %d", desc->max_chunk_stages);
+    sdvar_model* m = new sdvar_model();
+    m->d = *desc;
+    m->C = 64 * desc->depth; m->H = desc->depth; m->S = desc->n_stages; m->Rmax = 2 * desc->max_batch;
+    int c = 0;
+    for (int s = 0; s < m->S; ++s) {
+        if (desc->patch_nums[s] < 1 || desc->patch_nums[s] > 64) { delete m; set_error("model_create: patch_nums[%d]=%d", s, desc->patch_nums[s]); return SDVAR_ERR_ARG; }
+        m->lens[s] = desc->patch_nums[s] * desc->patch_nums[s]; c += m->lens[s]; m->cum[s] = c;
+    }
+    m->L = c;
+    // the largest chunk is a window of max_chunk_stages consecutive stages; stage lengths are non-decreasing
+    m->lmax = 0;
+    for (int s = 0; s < m->S; ++s) {
+        int t = 0;
+        for (int j = s; j < m->S && j < s + desc->max_chunk_stages; ++j) t += m->lens[j];
+        if (t > m->lmax) m->lmax = t;
+    }
+    m->blk.resize(desc->depth);
+    for (auto& b : m->blk) memset(&b, 0, sizeof(b));
+    m->embed_bound = m->head_bound = m->begun = false;
+    m->B = 0; m->kv_len = 0;
+    const size_t C = m->C, R = m->Rmax, M = R * (size_t)m->lmax;
+    std::vector<int> sot(m->L);
+    for (int s = 0, t = 0; s < m->S; ++s) for (int i = 0; i < m->lens[s]; ++i) sot[t++] = s;
+    SDVAR_TRY(dmalloc(&m->stage_of_tok, (size_t)m->L));
+    SDVAR_HIP(hipMemcpy(m->stage_of_tok, sot.data(), sizeof(int) * m->L, hipMemcpyHostToDevice));
+    SDVAR_TRY(dmalloc(&m->lvl_pos, (size_t)m->L * C));
+    SDVAR_TRY(dmalloc(&m->cond, R * C));
+    SDVAR_TRY(dmalloc(&m->cond_silu, R * C));
+    SDVAR_TRY(dmalloc(&m->x0, R * C));
+    SDVAR_TRY(dmalloc(&m->ada, (size_t)desc->depth * R * 6 * C));
+    SDVAR_TRY(dmalloc(&m->ada_head, R * 2 * C));
+    SDVAR_TRY(dmalloc(&m->xn, M * C));
+    SDVAR_TRY(dmalloc(&m->qkv, M * 3 * C));
+    SDVAR_TRY(dmalloc(&m->qbuf, M * C));
+    SDVAR_TRY(dmalloc(&m->att, M * C));
+    SDVAR_TRY(dmalloc(&m->hid, M * 4 * C));
+    for (auto& b : m->blk) {
+        SDVAR_TRY(dmalloc(&b.qkv_bias, 3 * C));
+        SDVAR_TRY(dmalloc(&b.kc, R * (size_t)m->H * m->L * 64));
+        SDVAR_TRY(dmalloc(&b.vc, R * (size_t)m->H * m->L * 64));
+    }
+    *out = m;
+    return SDVAR_OK;
+}
+
+int sdvar_model_destroy(sdvar_model_t* m) {
+    if (!m) return SDVAR_OK;
+    float* bufs[] = {m->lvl_pos, m->cond, m->cond_silu, m->x0, m->ada, m->ada_head, m->xn, m->qkv, m->qbuf, m->att, m->hid};
+    for (float* p : bufs) if (p) (void)hipFree(p);
+    if (m->stage_of_tok) (void)hipFree(m->stage_of_tok);
+    for (auto& b : m->blk) { if (b.qkv_bias) (void)hipFree(b.qkv_bias); if (b.kc) (void)hipFree(b.kc); if (b.vc) (void)hipFree(b.vc); }
+    delete m;
+    return SDVAR_OK;
+}
+
+int sdvar_model_bind_embed(sdvar_model_t* m, const float* class_emb, const float* pos_start, const float* pos_1LC, const float* lvl_embed,
+                           const float* word_w, const float* word_b, void* stream) {
+    SDVAR_CHECK_ARG(m && class_emb && pos_start && pos_1LC && lvl_embed && word_w && word_b, "bind_embed: null argument");
+    m->class_emb = class_emb; m->pos_start = pos_start; m->word_w = word_w; m->word_b = word_b;
+    SDVAR_TRY(build_lvl_pos(lvl_embed, pos_1LC, m->stage_of_tok, m->lvl_pos, m->L, m->C, (hipStream_t)stream));
+    m->embed_bound = true;
+    return SDVAR_OK;
+}
+
+int sdvar_model_bind_block(sdvar_model_t* m, int32_t i, const float* ada_w, const float* ada_b, const float* qkv_w, const float* q_bias,
+                           const float* v_bias, const float* scale_mul, const float* proj_w, const float* proj_b, const float* fc1_w,
+                           const float* fc1_b, const float* fc2_w, const float* fc2_b, void* stream) {
+    SDVAR_CHECK_ARG(m && i >= 0 && i < m->d.depth, "bind_block: block index %d", i);
+    SDVAR_CHECK_ARG(ada_w && ada_b && qkv_w && q_bias && v_bias && scale_mul && proj_w && proj_b && fc1_w && fc1_b && fc2_w && fc2_b, "bind_block: null tensor");
+    BlockW& b = m->blk[i];
+    b.ada_w = ada_w; b.ada_b = ada_b; b.qkv_w = qkv_w; b.scale_mul = scale_mul; b.proj_w = proj_w; b.proj_b = proj_b;
+    b.fc1_w = fc1_w; b.fc1_b = fc1_b; b.fc2_w = fc2_w; b.fc2_b = fc2_b;
+    const size_t C = m->C;
+    hipStream_t s = (hipStream_t)stream;
+    SDVAR_HIP(hipMemsetAsync(b.qkv_bias, 0, 3 * C * sizeof(float), s));
+    SDVAR_HIP(hipMemcpyAsync(b.qkv_bias, q_bias, C * sizeof(float), hipMemcpyDeviceToDevice, s));
+    SDVAR_HIP(hipMemcpyAsync(b.qkv_bias + 2 * C, v_bias, C * sizeof(float), hipMemcpyDeviceToDevice, s));
+    b.bound = true;
+    return SDVAR_OK;
+}
+
+int sdvar_model_bind_head(sdvar_model_t* m, const float* nm_w, const float* nm_b, const float* head_w, const float* head_b) {
+    SDVAR_CHECK_ARG(m && nm_w && nm_b && head_w && head_b, "bind_head: null argument");
+    m->nm_w = nm_w; m->nm_b = nm_b; m->head_w = head_w; m->head_b = head_b; m->head_bound = true;
+    return SDVAR_OK;
+}
+
+static int check_bound(const sdvar_model* m) {
+    if (!m) { set_error("null model"); return SDVAR_ERR_ARG; }
+    if (!m->embed_bound || !m->head_bound) { set_error("model weights not bound (embed=%d head=%d)", (int)m->embed_bound, (int)m->head_bound); return SDVAR_ERR_STATE; }
+    for (size_t i = 0; i < m->blk.size(); ++i) if (!m->blk[i].bound) { set_error("block %zu weights not bound", i); return SDVAR_ERR_STATE; }
+    return SDVAR_OK;
+}
+
+int sdvar_model_begin(sdvar_model_t* m, int32_t B, const int64_t* labels, void* stream) {
+    SDVAR_TRY(check_bound(m));
+    SDVAR_CHECK_ARG(B >= 1 && B <= m->d.max_batch && labels, "model_begin: B=%d (max %d)", B, m->d.max_batch);
+    hipStream_t s = (hipStream_t)stream;
+    const int C = m->C, R = 2 * B;
+    m->B = B; m->kv_len = 0;
+    {
+        ProfScope ps(7, 0, 0, s);
+        SDVAR_TRY(prologue((const long long*)labels, m->class_emb, m->pos_start, m->lvl_pos, m->cond, m->x0, B, C, m->d.num_classes, s));
+        SDVAR_TRY(silu_rows(m->cond, m->cond_silu, R * C, s));
+    }
+    // adaLN parameters of every block: stage-invariant, computed once per call instead of once per stage
+    for (int i = 0; i < m->d.depth; ++i) {
+        ProfScope ps(0, 2.0 * R * 6.0 * C * C, 4.0 * (6.0 * C * C + R * 7.0 * C), s);
+        SDVAR_TRY(gemm_f32_nt(m->cond_silu, C, m->blk[i].ada_w, m->blk[i].ada_b, m->ada + (size_t)i * m->Rmax * 6 * C, 6 * C, R, 6 * C, C, EPI_BIAS,
+                              nullptr, 0, nullptr, 0, 0, s));
+    }
+    {
+        ProfScope ps(0, 2.0 * R * 2.0 * C * C, 4.0 * (2.0 * C * C + R * 3.0 * C), s);
+        SDVAR_TRY(gemm_f32_nt(m->cond_silu, C, m->nm_w, m->nm_b, m->ada_head, 2 * C, R, 2 * C, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, s));
+    }
+    m->begun = true;
+    return SDVAR_OK;
+}
+
+int sdvar_model_place_first(sdvar_model_t* m, float* x, int32_t ltot, void* stream) {
+    SDVAR_CHECK_ARG(m && m->begun && x && ltot >= 1, "place_first: model not begun or bad args");
+    SDVAR_HIP(hipMemcpy2DAsync(x, (size_t)ltot * m->C * sizeof(float), m->x0, (size_t)m->C * sizeof(float), (size_t)m->C * sizeof(float), 2 * m->B,
+                               hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return SDVAR_OK;
+}
+
+int sdvar_kv_len(const sdvar_model_t* m) { return m ? m->kv_len : -1; }
+
+int sdvar_kv_set_len(sdvar_model_t* m, int32_t len) {
+    SDVAR_CHECK_ARG(m && len >= 0 && len <= m->kv_len, "kv_set_len: %d not in [0, %d] (rollback only)", len, m ? m->kv_len : -1);
+    m->kv_len = len;
+    return SDVAR_OK;
+}
+
+int sdvar_embed_next(sdvar_model_t* m, const float* nxt, int32_t s_next, float* x, int32_t ltot, int32_t tok_off, void* stream) {
+    SDVAR_CHECK_ARG(m && m->begun && nxt && x, "embed_next: model not begun or null");
+    SDVAR_CHECK_ARG(s_next >= 1 && s_next < m->S && tok_off >= 0 && tok_off + m->lens[s_next] <= ltot, "embed_next: stage %d off %d ltot %d", s_next, tok_off, ltot);
+    ProfScope ps(7, 2.0 * m->B * m->lens[s_next] * 32.0 * m->C, 4.0 * m->lens[s_next] * m->C * (2.0 * m->B + 1.0), (hipStream_t)stream);
+    return embed_next(nxt, m->word_w, m->word_b, m->lvl_pos, x, m->B, m->lens[s_next], m->C, begin_of(m, s_next), ltot, tok_off, (hipStream_t)stream);
+}
+
+int sdvar_stage_forward(sdvar_model_t* m, float* x, int32_t s0, int32_t n, float* logits, void* stream) {
+    SDVAR_TRY(check_bound(m));
+    SDVAR_CHECK_ARG(m->begun && x && logits, "stage_forward: model not begun or null buffers");
+    SDVAR_CHECK_ARG(s0 >= 0 && n >= 1 && s0 + n <= m->S && n <= m->d.max_chunk_stages, "stage_forward: stages [%d,%d) invalid (S=%d, max chunk %d)", s0, s0 + n, m->S, m->d.max_chunk_stages);
+    if (m->kv_len != begin_of(m, s0)) { set_error("stage_forward: KV cache holds %d keys, stage %d needs %d", m->kv_len, s0, begin_of(m, s0)); return SDVAR_ERR_STATE; }
+    hipStream_t s = (hipStream_t)stream;
+    const int C = m->C, H = m->H, R = 2 * m->B, V = m->d.vocab;
+    int qbeg[SDVAR_MAX_STAGES], vis[SDVAR_MAX_STAGES], lsum = 0;
+    double lk = 0;
+    for (int j = 0; j < n; ++j) { qbeg[j] = lsum; lsum += m->lens[s0 + j]; vis[j] = m->cum[s0 + j]; lk += (double)m->lens[s0 + j] * vis[j]; }
+    const int M = R * lsum, Ktot = m->kv_len + lsum;
+    const double dM = M, dC = C;
+    for (int i = 0; i < m->d.depth; ++i) {
+        const BlockW& b = m->blk[i];
+        const float* ada = m->ada + (size_t)i * m->Rmax * 6 * C;      // (R, 6C): gamma1 gamma2 scale1 scale2 shift1 shift2
+        { ProfScope ps(2, 8 * dM * dC, 8 * dM * dC, s);
+          SDVAR_TRY(ln_modulate(x, ada + 2 * C, ada + 4 * C, m->xn, M, C, lsum, 6 * C, s)); }
+        { ProfScope ps(0, 2 * dM * 3 * dC * dC, 4 * (dM * dC + 3 * dC * dC + 3 * dM * dC), s);
+          SDVAR_TRY(gemm_f32_nt(m->xn, C, b.qkv_w, b.qkv_bias, m->qkv, 3 * C, M, 3 * C, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, s)); }
+        { ProfScope ps(3, 6 * dM * dC, 4 * 6 * dM * dC, s);
+          SDVAR_TRY(qk_norm_append(m->qkv, b.scale_mul, m->qbuf, b.kc, b.vc, R, lsum, H, m->L, m->kv_len, s)); }
+        { ProfScope ps(1, 4.0 * R * H * 64.0 * lk, 4.0 * R * H * 64.0 * (2.0 * Ktot + 2.0 * lsum), s);
+          SDVAR_TRY(attention_f32(m->qbuf, b.kc, b.vc, m->att, R, H, lsum, m->L, Ktot, n, qbeg, vis, s)); }
+        { ProfScope ps(0, 2 * dM * dC * dC, 4 * (3 * dM * dC + dC * dC), s);
+          SDVAR_TRY(gemm_f32_nt(m->att, C, b.proj_w, b.proj_b, x, C, M, C, C, EPI_GATED_RES, x, C, ada, lsum, 6 * C, s)); }
+        { ProfScope ps(2, 8 * dM * dC, 8 * dM * dC, s);
+          SDVAR_TRY(ln_modulate(x, ada + 3 * C, ada + 5 * C, m->xn, M, C, lsum, 6 * C, s)); }
+        { ProfScope ps(0, 2 * dM * 4 * dC * dC, 4 * (dM * dC + 4 * dC * dC + 4 * dM * dC), s);
+          SDVAR_TRY(gemm_f32_nt(m->xn, C, b.fc1_w, b.fc1_b, m->hid, 4 * C, M, 4 * C, C, EPI_BIAS_GELU, nullptr, 0, nullptr, 0, 0, s)); }
+        { ProfScope ps(0, 2 * dM * 4 * dC * dC, 4 * (4 * dM * dC + 4 * dC * dC + 2 * dM * dC), s);
+          SDVAR_TRY(gemm_f32_nt(m->hid, 4 * C, b.fc2_w, b.fc2_b, x, C, M, C, 4 * C, EPI_GATED_RES, x, C, ada + C, lsum, 6 * C, s)); }
+    }
+    { ProfScope ps(2, 8 * dM * dC, 8 * dM * dC, s);
+      SDVAR_TRY(ln_modulate(x, m->ada_head, m->ada_head + C, m->xn, M, C, lsum, 2 * C, s)); }
+    { ProfScope ps(0, 2 * dM * dC * V, 4 * (dM * dC + dC * V + dM * V), s);
+      SDVAR_TRY(gemm_f32_nt(m->xn, C, m->head_w, m->head_b, logits, V, M, V, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, s)); }
+    m->kv_len = Ktot;
+    return SDVAR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------- quantizer
+static void bicubic_row(int n_in, int n_out, int o, float* row) {   // one row of the (n_out x n_in) up-sampling matrix
+    const float A = -0.75f;
+    const float scale = (float)n_in / (float)n_out;
+    const float src = scale * ((float)o + 0.5f) - 0.5f;
+    const int i0 = (int)floorf(src);
+    const float t = src - (float)i0;
+    const float x2 = 1.0f - t;
+    const float xs[4] = {t + 1.0f, t, x2, x2 + 1.0f};
+    float w[4];
+    w[0] = ((A * xs[0] - 5.0f * A) * xs[0] + 8.0f * A) * xs[0] - 4.0f * A;
+    w[1] = ((A + 2.0f) * xs[1] - (A + 3.0f)) * xs[1] * xs[1] + 1.0f;
+    w[2] = ((A + 2.0f) * xs[2] - (A + 3.0f)) * xs[2] * xs[2] + 1.0f;
+    w[3] = ((A * xs[3] - 5.0f * A) * xs[3] + 8.0f * A) * xs[3] - 4.0f * A;
+    std::vector<double> acc(n_in, 0.0);
+    for (int k = 0; k < 4; ++k) {
+        int idx = i0 - 1 + k;
+        idx = idx < 0 ? 0 : (idx > n_in - 1 ? n_in - 1 : idx);
+        acc[idx] += (double)w[k];
+    }
+    for (int i = 0; i < n_in; ++i) row[i] = (float)acc[i];
+}
+
+int sdvar_quant_create(int32_t S, const int32_t* patch_nums, int32_t cvae, int32_t vocab, int32_t max_batch, int32_t n_phi, sdvar_quant_t** out) {
+    SDVAR_CHECK_ARG(out && patch_nums && S >= 1 && S <= SDVAR_MAX_STAGES && cvae >= 1 && vocab >= 1 && max_batch >= 1, "quant_create: bad argument");
+    SDVAR_CHECK_ARG(n_phi >= 1 && n_phi <= 8, "quant_create: n_phi %d", n_phi);
+    sdvar_quant* q = new sdvar_quant();
+    q->S = S; q->Cv = cvae; q->V = vocab; q->maxB = max_batch; q->n_phi = n_phi; q->bound = false; q->codebook = nullptr;
+    for (int s = 0; s < S; ++s) q->pn[s] = patch_nums[s];
+    q->HW = patch_nums[S - 1];
+    SDVAR_CHECK_ARG(q->HW <= 64, "quant_create: HW %d > 64", q->HW);
+    q->hWup.resize(S); q->hWdn.resize(S);
+    for (int s = 0; s < S; ++s) {
+        // Phi choice: argmin |ticks - s/(S-1)| (quant.py:223-226); ticks = linspace(1/3/K, 1-1/3/K, K) for K == 4 else the 1/2/K form
+        int best = 0; double bd = 1e30;
+        for (int k = 0; k < n_phi; ++k) {
+            const double lo = (n_phi == 4) ? 1.0 / 3 / n_phi : 1.0 / 2 / n_phi, hi = 1.0 - lo;
+            const double tick = (n_phi == 1) ? lo : lo + (hi - lo) * k / (n_phi - 1);
+            const double at = (S > 1) ? (double)s / (S - 1) : 0.0;
+            const double dd = fabs(tick - at);
+            if (dd < bd) { bd = dd; best = k; }
+        }
+        q->phi_of[s] = best;
+        q->Wup[s] = q->Wdn[s] = nullptr;
+        if (s < S - 1) {
+            const int pn = q->pn[s], HW = q->HW, p2 = q->pn[s + 1];
+            q->hWup[s].assign((size_t)HW * pn, 0.f);
+            for (int o = 0; o < HW; ++o) bicubic_row(pn, HW, o, &q->hWup[s][(size_t)o * pn]);
+            q->hWdn[s].assign((size_t)p2 * HW, 0.f);
+            for (int o = 0; o < p2; ++o) {
+                const int st = (o * HW) / p2, en = ((o + 1) * HW + p2 - 1) / p2;
+                for (int i = st; i < en; ++i) q->hWdn[s][(size_t)o * HW + i] = 1.0f / (float)(en - st);
+            }
+            SDVAR_TRY(dmalloc(&q->Wup[s], q->hWup[s].size()));
+            SDVAR_TRY(dmalloc(&q->Wdn[s], q->hWdn[s].size()));
+            SDVAR_HIP(hipMemcpy(q->Wup[s], q->hWup[s].data(), q->hWup[s].size() * sizeof(float), hipMemcpyHostToDevice));
+            SDVAR_HIP(hipMemcpy(q->Wdn[s], q->hWdn[s].data(), q->hWdn[s].size() * sizeof(float), hipMemcpyHostToDevice));
+        }
+    }
+    SDVAR_TRY(dmalloc(&q->up_scratch, (size_t)max_batch * cvae * q->HW * q->HW));
+    *out = q;
+    return SDVAR_OK;
+}
+
+int sdvar_quant_destroy(sdvar_quant_t* q) {
+    if (!q) return SDVAR_OK;
+    for (int s = 0; s < q->S; ++s) { if (q->Wup[s]) (void)hipFree(q->Wup[s]); if (q->Wdn[s]) (void)hipFree(q->Wdn[s]); }
+    if (q->up_scratch) (void)hipFree(q->up_scratch);
+    delete q;
+    return SDVAR_OK;
+}
+
+int sdvar_quant_bind(sdvar_quant_t* q, const float* codebook, const float* const* phi_w, const float* const* phi_b) {
+    SDVAR_CHECK_ARG(q && codebook && phi_w && phi_b, "quant_bind: null argument");
+    for (int k = 0; k < q->n_phi; ++k) { SDVAR_CHECK_ARG(phi_w[k] && phi_b[k], "quant_bind: null phi %d", k); q->phi_w[k] = phi_w[k]; q->phi_b[k] = phi_b[k]; }
+    q->codebook = codebook; q->bound = true;
+    return SDVAR_OK;
+}
+
+int sdvar_quant_next(sdvar_quant_t* q, int32_t si, const int64_t* ids, int32_t ids_stride, float* f_hat, float* nxt, int32_t B, void* stream) {
+    SDVAR_CHECK_ARG(q && q->bound, "quant_next: quantizer not bound");
+    SDVAR_CHECK_ARG(si >= 0 && si < q->S && B >= 1 && B <= q->maxB && ids && f_hat, "quant_next: stage %d B %d", si, B);
+    const int last = (si == q->S - 1), k = q->phi_of[si];
+    ProfScope ps(6, 2.0 * B * q->Cv * q->Cv * 9.0 * q->HW * q->HW, 4.0 * B * q->Cv * q->HW * q->HW * 4.0, (hipStream_t)stream);
+    return quant_next((const long long*)ids, ids_stride, q->codebook, q->Wup[si], q->phi_w[k], q->phi_b[k], last ? nullptr : q->Wdn[si], q->up_scratch, f_hat, nxt,
+                      B, q->pn[si], last ? 0 : q->pn[si + 1], q->HW, q->Cv, last, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------------- sampling
+int sdvar_cfg_sample(const float* logits, int32_t B, int32_t l, int32_t V, double t, int32_t top_k, double top_p, const float* q, uint64_t seed,
+                     uint32_t draw, uint32_t image_offset, int64_t* ids_out, int32_t ids_stride, float* dbg_masked, void* stream) {
+    // torch evaluates (1+t)*a - t*b with the python scalars rounded to float32 (var.py:199-200); `<= (1 - top_p)` likewise
+    ProfScope ps(4, 0, 4.0 * B * l * V * (q ? 3.0 : 2.0), (hipStream_t)stream);
+    return cfg_sample(logits, B, l, V, (float)(1.0 + t), (float)t, top_k, top_p > 0.0 ? 1 : 0, (float)(1.0 - top_p), q, seed, draw, image_offset,
+                      (long long*)ids_out, ids_stride, dbg_masked, (hipStream_t)stream);
+}
+
+int sdvar_verify_accept(const float* logits, int32_t B, int32_t lsum, int32_t V, int32_t n, const int32_t* stage_lens, const double* t,
+                        const int64_t* draft_ids, int32_t ids_stride, double thr, int32_t* counts, int64_t* argmax_out, void* stream) {
+    SDVAR_CHECK_ARG(stage_lens && t && n >= 1 && n <= SDVAR_MAX_STAGES, "verify_accept: bad stage table");
+    int qbeg[SDVAR_MAX_STAGES]; float opt[SDVAR_MAX_STAGES], tf[SDVAR_MAX_STAGES]; int acc = 0;
+    for (int j = 0; j < n; ++j) { qbeg[j] = acc; acc += stage_lens[j]; opt[j] = (float)(1.0 + t[j]); tf[j] = (float)t[j]; }
+    SDVAR_CHECK_ARG(acc == lsum, "verify_accept: stage lens sum %d != lsum %d", acc, lsum);
+    ProfScope ps(5, 0, 4.0 * 2.0 * B * lsum * V, (hipStream_t)stream);
+    return verify_accept(logits, B, lsum, V, n, qbeg, opt, tf, (const long long*)draft_ids, ids_stride, thr, counts, (long long*)argmax_out, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------------- single ops
+int sdvar_op_gemm(const float* X, int32_t ldx, const float* W, const float* bias, float* out, int32_t ldo, int32_t M, int32_t N, int32_t K, int32_t epi,
+                  const float* res, int32_t ldres, const float* gate, int32_t rows_per_gate, int32_t gate_stride, void* stream) {
+    ProfScope ps(0, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), (hipStream_t)stream);
+    return gemm_f32_nt(X, ldx, W, bias, out, ldo, M, N, K, epi, res, ldres, gate, rows_per_gate, gate_stride, (hipStream_t)stream);
+}
+int sdvar_op_ln_modulate(const float* x, const float* scale, const float* shift, float* out, int32_t rows, int32_t C, int32_t rows_per_img,
+                         int32_t mod_stride, void* stream) {
+    return ln_modulate(x, scale, shift, out, rows, C, rows_per_img, mod_stride, (hipStream_t)stream);
+}
+int sdvar_op_qk_norm_append(const float* qkv, const float* scale_mul, float* q_out, float* k_cache, float* v_cache, int32_t R, int32_t l, int32_t H,
+                            int32_t Lmax, int32_t pos0, void* stream) {
+    return qk_norm_append(qkv, scale_mul, q_out, k_cache, v_cache, R, l, H, Lmax, pos0, (hipStream_t)stream);
+}
+int sdvar_op_attention(const float* q, const float* kc, const float* vc, float* out, int32_t R, int32_t H, int32_t l, int32_t Lmax, int32_t Ktot,
+                       int32_t n, const int32_t* qbeg, const int32_t* vis, void* stream) {
+    SDVAR_CHECK_ARG(qbeg && vis && n >= 1 && n <= SDVAR_MAX_STAGES, "op_attention: bad stage table");
+    double lk = 0;
+    for (int j = 0; j < n; ++j) lk += (double)((j + 1 < n ? qbeg[j + 1] : l) - qbeg[j]) * vis[j];
+    ProfScope ps(1, 4.0 * R * H * 64.0 * lk, 4.0 * R * H * 64.0 * (2.0 * Ktot + 2.0 * l), (hipStream_t)stream);
+    return attention_f32(q, kc, vc, out, R, H, l, Lmax, Ktot, n, qbeg, vis, (hipStream_t)stream);
+}
+int sdvar_op_noise_fill(float* q, int32_t B, int32_t l, int32_t V, uint64_t seed, uint32_t draw, uint32_t image_offset, void* stream) {
+    return noise_fill(q, B, l, V, seed, draw, image_offset, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------------- profiling
+int sdvar_prof_enable(int32_t on) {
+    g_prof_on = on != 0;
+    if (on) { for (int i = 0; i < SDVAR_PROF_CLASSES; ++i) { g_ms[i] = g_fl[i] = g_by[i] = 0; g_n[i] = 0; } }
+    return SDVAR_OK;
+}
+
+int sdvar_prof_collect(double* ms, int64_t* launches, double* flops, double* bytes) {
+    for (auto& r : g_prof) {
+        SDVAR_HIP(hipEventSynchronize(r.e1));
+        float t = 0.f;
+        SDVAR_HIP(hipEventElapsedTime(&t, r.e0, r.e1));
+        g_ms[r.cls] += t; g_n[r.cls] += 1; g_fl[r.cls] += r.flops; g_by[r.cls] += r.bytes;
+        (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
+    }
+    g_prof.clear();
+    for (int i = 0; i < SDVAR_PROF_CLASSES; ++i) {
+        if (ms) ms[i] = g_ms[i];
+        if (launches) launches[i] = g_n[i];
+        if (flops) flops[i] = g_fl[i];
+        if (bytes) bytes[i] = g_by[i];
+    }
+    return SDVAR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,190 @@
+// Verify-attention: softmax(q k^T + block-causal mask) v over the growing KV cache, fp32, flash-style (no score matrix
+// in HBM).  Replaces F.scaled_dot_product_attention(q, cat(cached_k, k), cat(cached_v, v), scale=1, attn_mask) at
+// /root/reference/models/basic_var.py:107-117 with the mask rows of models/var.py:108-113 derived in-kernel from the
+// stage boundaries (never materialised).
+//
+// Layouts:  q (R, H, l, 64) (already L2-normalised and scaled), kc/vc (R, H, Lmax, 64) with `Ktot` valid keys
+//           (prefix + the l keys of this call), out (R, l, H*64) row-major for the projection GEMM.
+// Queries of chunk stage j (q index in [qbeg[j], qbeg[j+1])) see keys [0, vis[j]).
+//
+// Mapping (wave64):  one wave owns 32 queries; workgroup = 4 waves = 128 queries of one (row, head).
+//   S^T = K Q^T  with v_mfma_f32_32x32x2_f32: A = K tile (key on the MFMA row), B = Q (query on the lane) so every lane
+//   holds 16 scores of ONE query per 32-key sub-tile -> row max/sum are in-register plus one cross-half shuffle.
+//   O^T = V^T P^T: A = V^T read from LDS (d on the MFMA row), B = P straight from the score registers (no LDS trip).
+//   K/V tiles of 64 keys are streamed HBM -> registers -> LDS (double buffered, coalesced 16-byte loads of contiguous
+//   cache rows), K rows padded to 68 floats for conflict-free ds_read_b128.
+// Algorithmic bytes per launch: R*H*64*4 * (2*Ktot + 2*l) (K and V read once, Q read, O written).
+#include "common.h"
+
+namespace sdvar {
+
+constexpr int ATT_MAX_CHUNK = 16;
+constexpr int KT = 64;              // keys per LDS tile
+constexpr int KSTR = 68;            // padded K row (floats)
+
+struct AttnArgs {
+    const float* q; const float* kc; const float* vc; float* out;
+    int R, H, l, Lmax, Ktot;
+    int n_chunk;
+    int qbeg[ATT_MAX_CHUNK + 1];
+    int vis[ATT_MAX_CHUNK];
+};
+
+__global__ __launch_bounds__(256) void attention_f32_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int STAGE = KT * KSTR + KT * 64;              // floats per pipeline stage: K tile then V tile
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int qt = blockIdx.x, h = blockIdx.y, r = blockIdx.z;
+    const int q0 = qt * 128;
+
+    // this lane's query and how many keys it may see
+    const int qi_raw = q0 + wave * 32 + li;
+    const int qi = min(qi_raw, a.l - 1);
+    int vis_q = a.vis[0];
+#pragma unroll 1
+    for (int j = 1; j < a.n_chunk; ++j) if (qi >= a.qbeg[j]) vis_q = a.vis[j];
+    // keys needed by the workgroup: the last valid query of the block sees the most
+    const int q_last = min(q0 + 127, a.l - 1);
+    int kend = a.vis[0];
+#pragma unroll 1
+    for (int j = 1; j < a.n_chunk; ++j) if (q_last >= a.qbeg[j]) kend = a.vis[j];
+    const bool wave_active = (q0 + wave * 32) < a.l;
+
+    // Q fragment: lane (query li, half lh) holds d = 8c + 4lh + e, c = 0..7, e = 0..3
+    f32x4 qf[8];
+    {
+        const float* pq = a.q + (((size_t)r * a.H + h) * a.l + qi) * 64 + 4 * lh;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) qf[c] = *reinterpret_cast<const f32x4*>(pq + 8 * c);
+    }
+
+    const float* kbase = a.kc + ((size_t)r * a.H + h) * a.Lmax * 64;
+    const float* vbase = a.vc + ((size_t)r * a.H + h) * a.Lmax * 64;
+    // staging: 64 keys x 64 floats = 1024 float4 per operand, 4 per thread: key = tid/16 + 16*i, col4 = tid%16
+    const int skey = tid >> 4, scol = (tid & 15) * 4;
+    f32x4 rk[4], rv[4];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int key = k0 + skey + 16 * i;
+            if (key < a.Ktot) {
+                rk[i] = *reinterpret_cast<const f32x4*>(kbase + (size_t)key * 64 + scol);
+                rv[i] = *reinterpret_cast<const f32x4*>(vbase + (size_t)key * 64 + scol);
+            } else {
+                rk[i] = f32x4{0.f, 0.f, 0.f, 0.f}; rv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4*>(smem + buf * STAGE + (skey + 16 * i) * KSTR + scol) = rk[i];
+            *reinterpret_cast<f32x4*>(smem + buf * STAGE + KT * KSTR + (skey + 16 * i) * 64 + scol) = rv[i];
+        }
+    };
+
+    f32x16 o0, o1;                        // O^T accumulators: d = db*32 + (reg&3) + 8*(reg>>2) + 4*lh, column = this query
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int ntiles = (kend + KT - 1) / KT;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1, k0 = t * KT;
+        if (t + 1 < ntiles) load_tile(k0 + KT);
+        if (wave_active) {
+            // ---- scores for 2 sub-tiles of 32 keys
+            f32x16 s[2];
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s[sub][i] = 0.f;
+                const float* pk = smem + buf * STAGE + (sub * 32 + li) * KSTR + 4 * lh;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const f32x4 kf = *reinterpret_cast<const f32x4*>(pk + 8 * c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s[sub] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[c][e], s[sub], 0, 0, 0);
+                }
+            }
+            // ---- mask + online softmax (this lane: one query, keys k0 + sub*32 + (i&3) + 8*(i>>2) + 4*lh)
+            float mloc = -INFINITY;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = k0 + sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+                    if (key >= vis_q) s[sub][i] = -INFINITY;
+                    mloc = fmaxf(mloc, s[sub][i]);
+                }
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            const float m_new = fmaxf(m_run, mloc);          // finite from the first tile on (key 0 is always visible)
+            const float alpha = expf(m_run - m_new);         // exp(-inf) = 0 on the first tile
+            float lsum = 0.f;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { s[sub][i] = expf(s[sub][i] - m_new); lsum += s[sub][i]; }
+            lsum += __shfl_xor(lsum, 32, 64);
+            l_run = l_run * alpha + lsum;
+            m_run = m_new;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+            // ---- O^T += V^T P^T : step i pairs key (i&3)+8*(i>>2) (half 0) with the same +4 (half 1)
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float* pv = smem + buf * STAGE + KT * KSTR + (sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh) * 64 + li;
+                    o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(pv[0], s[sub][i], o0, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(pv[32], s[sub][i], o1, 0, 0, 0);
+                }
+            }
+        }
+        if (t + 1 < ntiles) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    if (wave_active && qi_raw < a.l) {
+        const float inv = 1.0f / l_run;
+        float* po = a.out + ((size_t)r * a.l + qi_raw) * (a.H * 64) + h * 64 + 4 * lh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v0, v1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v0[e] = o0[4 * g + e] * inv; v1[e] = o1[4 * g + e] * inv; }
+            *reinterpret_cast<f32x4*>(po + 8 * g) = v0;
+            *reinterpret_cast<f32x4*>(po + 32 + 8 * g) = v1;
+        }
+    }
+}
+
+int attention_f32(const float* q, const float* kc, const float* vc, float* out, int R, int H, int l, int Lmax, int Ktot, int n_chunk,
+                  const int* qbeg, const int* vis, hipStream_t stream) {
+    SDVAR_CHECK_ARG(q && kc && vc && out, "attention: null operand");
+    SDVAR_CHECK_ARG(n_chunk >= 1 && n_chunk <= ATT_MAX_CHUNK, "attention: chunk of %d stages unsupported (max %d)", n_chunk, ATT_MAX_CHUNK);
+    SDVAR_CHECK_ARG(R > 0 && H > 0 && l > 0 && Ktot >= l && Ktot <= Lmax, "attention: bad lengths l=%d Ktot=%d Lmax=%d", l, Ktot, Lmax);
+    AttnArgs a;
+    a.q = q; a.kc = kc; a.vc = vc; a.out = out; a.R = R; a.H = H; a.l = l; a.Lmax = Lmax; a.Ktot = Ktot; a.n_chunk = n_chunk;
+    for (int j = 0; j < n_chunk; ++j) {
+        a.qbeg[j] = qbeg[j]; a.vis[j] = vis[j];
+        SDVAR_CHECK_ARG(vis[j] >= 1 && vis[j] <= Ktot && (j == 0 ? qbeg[0] == 0 : (qbeg[j] > qbeg[j - 1] && vis[j] >= vis[j - 1])), "attention: bad stage table at %d", j);
+    }
+    a.qbeg[n_chunk] = l;
+    const size_t lds = 2 * (size_t)(KT * KSTR + KT * 64) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        SDVAR_HIP(hipFuncSetAttribute((const void*)attention_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(attention_f32_kernel, dim3((l + 127) / 128, H, R), dim3(256), lds, stream, a);
+    SDVAR_LAUNCH_CHECK();
+    return SDVAR_OK;
+}
+
+}  // namespace sdvar

@@ -1,0 +1,178 @@
+// Row-wise and gather kernels around the GEMMs (all HBM-bound; one wave64 per row, 16-byte accesses).
+//
+//   ln_modulate        LN(x; eps=1e-6, no affine) * (1 + scale[r]) + shift[r]     basic_var.py:141,157-158 ; :172-174
+//   qk_norm_append     q/k L2-normalise (F.normalize eps 1e-12), q *= exp(min(s_h, ln 100)), append k,v to the
+//                      preallocated KV cache at the length cursor                   basic_var.py:101-109
+//   silu_rows          SiLU(cond)                                                   basic_var.py:147 (ada_lin[0])
+//   prologue           cond = class_emb[label | uncond], x0 = cond + pos_start + lvl_pos[0]   var.py:162-183
+//   build_lvl_pos      lvl_embed[lvl(t)] + pos_1LC[t]                               var.py:164
+//   embed_next         word_embed(next) + lvl_pos, written to both CFG rows of a (R, ltot, C) chunk input   var.py:186-188
+#include "common.h"
+
+namespace sdvar {
+
+// ------------------------------------------------------------------------------------------------ ln_modulate
+// x (rows, C) ; scale/shift: row r of the CFG batch = row / rows_per_img, element stride `mod_stride` between r's.
+constexpr int LN_MAX_V4 = 8;   // up to C = 64 lanes * 8 * 4 = 2048
+
+__global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, float* __restrict__ out, int rows, int C,
+                                                          int rows_per_img, int mod_stride, float eps) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = C >> 2;
+    const f32x4* px = reinterpret_cast<const f32x4*>(x + (size_t)row * C);
+    f32x4 v[LN_MAX_V4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_V4; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < nv) { v[i] = px[idx]; s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_V4; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < nv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; ss += d * d; }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)C + eps);
+    const size_t mo = (size_t)(row / rows_per_img) * mod_stride;
+    const f32x4* psc = reinterpret_cast<const f32x4*>(scale + mo);
+    const f32x4* psh = reinterpret_cast<const f32x4*>(shift + mo);
+    f32x4* po = reinterpret_cast<f32x4*>(out + (size_t)row * C);
+#pragma unroll
+    for (int i = 0; i < LN_MAX_V4; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < nv) {
+            const f32x4 sc = psc[idx], sh = psh[idx];
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = ((v[i][e] - mean) * rstd) * (sc[e] + 1.0f) + sh[e];
+            po[idx] = o;
+        }
+    }
+}
+
+int ln_modulate(const float* x, const float* scale, const float* shift, float* out, int rows, int C, int rows_per_img,
+                int mod_stride, hipStream_t stream) {
+    SDVAR_CHECK_ARG(C % 4 == 0 && C <= 64 * 4 * LN_MAX_V4 && rows > 0 && rows_per_img > 0, "ln_modulate: bad shape rows=%d C=%d", rows, C);
+    SDVAR_CHECK_ARG(mod_stride % 4 == 0, "ln_modulate: mod_stride must be a multiple of 4");
+    hipLaunchKernelGGL(ln_modulate_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, scale, shift, out, rows, C, rows_per_img, mod_stride, 1e-6f);
+    SDVAR_LAUNCH_CHECK();
+    return SDVAR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ qk_norm_append
+// qkv (R*l, 3C) with the bias already added.  One wave per (row, head); lane = channel.
+// q_out (R, H, l, 64); k_cache / v_cache (R, H, Lmax, 64) written at positions pos0 .. pos0+l-1.
+__global__ __launch_bounds__(256) void qk_norm_append_kernel(const float* __restrict__ qkv, const float* __restrict__ scale_mul,
+                                                             float* __restrict__ q_out, float* __restrict__ k_cache,
+                                                             float* __restrict__ v_cache, int R, int l, int H, int Lmax, int pos0) {
+    const int lane = threadIdx.x & 63;
+    const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= (long long)R * l * H) return;
+    const int h = (int)(item % H);
+    const long long row = item / H;            // r * l + t
+    const int t = (int)(row % l), r = (int)(row / l);
+    const int C = H * 64;
+    const float* p = qkv + (size_t)row * 3 * C + h * 64 + lane;
+    const float q = p[0], k = p[C], v = p[2 * C];
+    const float qn = fmaxf(sqrtf(wave_sum(q * q)), 1e-12f);
+    const float kn = fmaxf(sqrtf(wave_sum(k * k)), 1e-12f);
+    const float sm = expf(fminf(scale_mul[h], 4.605170249938965f));    // log(100) as the reference's float32 clamp
+    q_out[(((size_t)r * H + h) * l + t) * 64 + lane] = (q / qn) * sm;
+    const size_t c = (((size_t)r * H + h) * Lmax + pos0 + t) * 64 + lane;
+    k_cache[c] = k / kn;
+    v_cache[c] = v;
+}
+
+int qk_norm_append(const float* qkv, const float* scale_mul, float* q_out, float* k_cache, float* v_cache, int R, int l, int H,
+                   int Lmax, int pos0, hipStream_t stream) {
+    SDVAR_CHECK_ARG(R > 0 && l > 0 && H > 0 && pos0 >= 0 && pos0 + l <= Lmax, "qk_norm_append: cache overflow pos0=%d l=%d Lmax=%d", pos0, l, Lmax);
+    const long long items = (long long)R * l * H;
+    hipLaunchKernelGGL(qk_norm_append_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, qkv, scale_mul, q_out, k_cache, v_cache, R, l, H, Lmax, pos0);
+    SDVAR_LAUNCH_CHECK();
+    return SDVAR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ small helpers
+__global__ void silu_kernel(const float* __restrict__ x, float* __restrict__ y, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const float v = x[i]; y[i] = v / (1.0f + expf(-v)); }
+}
+
+int silu_rows(const float* x, float* y, int n, hipStream_t stream) {
+    hipLaunchKernelGGL(silu_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, x, y, n);
+    SDVAR_LAUNCH_CHECK();
+    return SDVAR_OK;
+}
+
+// cond (2B, C) = class_emb[label_b] for rows < B, class_emb[num_classes] for rows >= B;  x0 (2B,1,C) = cond + pos_start + lvl_pos[0]
+__global__ void prologue_kernel(const long long* __restrict__ labels, const float* __restrict__ class_emb, const float* __restrict__ pos_start,
+                                const float* __restrict__ lvl_pos, float* __restrict__ cond, float* __restrict__ x0, int B, int C, int num_classes) {
+    const int r = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    long long lab = (r < B) ? labels[r] : (long long)num_classes;
+    if (lab < 0 || lab > num_classes) lab = num_classes;
+    const float e = class_emb[(size_t)lab * C + c];
+    cond[(size_t)r * C + c] = e;
+    x0[(size_t)r * C + c] = (e + pos_start[c]) + lvl_pos[c];
+}
+
+int prologue(const long long* labels, const float* class_emb, const float* pos_start, const float* lvl_pos, float* cond, float* x0,
+             int B, int C, int num_classes, hipStream_t stream) {
+    hipLaunchKernelGGL(prologue_kernel, dim3((C + 255) / 256, 2 * B), dim3(256), 0, stream, labels, class_emb, pos_start, lvl_pos, cond, x0, B, C, num_classes);
+    SDVAR_LAUNCH_CHECK();
+    return SDVAR_OK;
+}
+
+// lvl_pos[t][c] = lvl_embed[stage(t)][c] + pos_1LC[t][c]
+__global__ void build_lvl_pos_kernel(const float* __restrict__ lvl_embed, const float* __restrict__ pos, const int* __restrict__ stage_of_tok,
+                                     float* __restrict__ out, int L, int C) {
+    const int t = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) out[(size_t)t * C + c] = lvl_embed[(size_t)stage_of_tok[t] * C + c] + pos[(size_t)t * C + c];
+}
+
+int build_lvl_pos(const float* lvl_embed, const float* pos, const int* stage_of_tok, float* out, int L, int C, hipStream_t stream) {
+    hipLaunchKernelGGL(build_lvl_pos_kernel, dim3((C + 255) / 256, L), dim3(256), 0, stream, lvl_embed, pos, stage_of_tok, out, L, C);
+    SDVAR_LAUNCH_CHECK();
+    return SDVAR_OK;
+}
+
+// x[b][t][:] = x[B+b][t][:] = nxt[b][t][0:32] . Ww[:, 0:32]^T + bw + lvl_pos[t0 + t]       (Cvae = 32)
+// one workgroup per (token, image): the 32 inputs are broadcast from LDS, each thread owns output channels.
+__global__ __launch_bounds__(256) void embed_next_kernel(const float* __restrict__ nxt, const float* __restrict__ Ww, const float* __restrict__ bw,
+                                                         const float* __restrict__ lvl_pos, float* __restrict__ x, int B, int l, int C, int t0,
+                                                         int ltot, int tok_off) {
+    __shared__ float in[32];
+    const int t = blockIdx.x, b = blockIdx.y;
+    if (threadIdx.x < 32) in[threadIdx.x] = nxt[((size_t)b * l + t) * 32 + threadIdx.x];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const f32x4* w = reinterpret_cast<const f32x4*>(Ww + (size_t)c * 32);
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const f32x4 wv = w[k];
+            acc = fmaf(in[4 * k + 0], wv[0], acc); acc = fmaf(in[4 * k + 1], wv[1], acc);
+            acc = fmaf(in[4 * k + 2], wv[2], acc); acc = fmaf(in[4 * k + 3], wv[3], acc);
+        }
+        const float v = (acc + bw[c]) + lvl_pos[(size_t)(t0 + t) * C + c];
+        x[((size_t)b * ltot + tok_off + t) * C + c] = v;
+        x[((size_t)(B + b) * ltot + tok_off + t) * C + c] = v;
+    }
+}
+
+int embed_next(const float* nxt, const float* Ww, const float* bw, const float* lvl_pos, float* x, int B, int l, int C, int t0, int ltot, int tok_off,
+               hipStream_t stream) {
+    SDVAR_CHECK_ARG(B > 0 && l > 0 && tok_off >= 0 && tok_off + l <= ltot, "embed_next: bad placement");
+    hipLaunchKernelGGL(embed_next_kernel, dim3(l, B), dim3(256), 0, stream, nxt, Ww, bw, lvl_pos, x, B, l, C, t0, ltot, tok_off);
+    SDVAR_LAUNCH_CHECK();
+    return SDVAR_OK;
+}
+
+}  // namespace sdvar

@@ -1,0 +1,181 @@
+// fp32 "NT" GEMM on the gfx950 matrix cores:  out[M,N] = epilogue( X[M,K] . W[N,K]^T + bias[N] ).
+//
+// Replaces the reference's F.linear calls on the sampling path (/root/reference/models/basic_var.py:93 QKV, :119 proj,
+// :52 fc1/fc2, :156 ada_lin; models/var.py:125 head, :187 word_embed).  The reference computes them in fp32, and the
+// parity bar is bit-exact token ids, so the MFMA form used is v_mfma_f32_32x32x2_f32: fp32 in / fp32 accumulate,
+// bitwise a k-ordered fmaf chain (MI355X_MICROARCH.md "Matrix cores"), 157 TFLOP/s peak.
+//
+// Tiling (wave64, 4 waves / 256 threads per workgroup):
+//   block tile BM x BN (128x128, 64x128 or 32x128), K-step 32, both operands K-contiguous in HBM;
+//   X and W tiles are staged global -> registers -> LDS (double buffered, one barrier per K-step) with rows padded to
+//   36 floats so that the per-lane ds_read_b128 of 4 consecutive k is bank-conflict free;
+//   the 4 k of one ds_read_b128 feed 4 MFMAs: lane (i, h) supplies k = 8c + 4h + e for MFMA e of chunk c on BOTH
+//   operands, i.e. the K order inside a tile is permuted identically for X and W (sum unchanged, order fixed).
+//   Output: lane holds column n = lane & 31 of 16 rows -> 128-byte row segments per store instruction.
+// Epilogues (fused, the reference's elementwise ops around each linear):
+//   EPI_BIAS        out = acc + bias
+//   EPI_BIAS_GELU   out = gelu_tanh(acc + bias)                         (basic_var.py:40,52)
+//   EPI_GATED_RES   out = res + (acc + bias) * gate[row / rows_per_gate] (basic_var.py:157-158: x + f(.)*gamma)
+#include "common.h"
+
+namespace sdvar {
+
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_GATED_RES = 2 };
+
+constexpr int BK = 32;
+constexpr int LDS_STRIDE = BK + 4;   // floats
+
+__device__ __forceinline__ float gelu_tanh(float x) {
+    // 0.5 x (1 + tanh( sqrt(2/pi) (x + 0.044715 x^3) ))   (nn.GELU(approximate='tanh'))
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    const float inner = k0 * (x + k1 * x * x * x);
+    return 0.5f * x * (1.0f + tanhf(inner));
+}
+
+struct GemmArgs {
+    const float* X; const float* W; const float* bias; float* out;
+    const float* res; const float* gate;
+    int M, N, K, ldx, ldo, ldres;
+    int rows_per_gate, gate_stride;
+};
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_nt_kernel(GemmArgs a) {
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;     // wave tile
+    constexpr int TM = WM / 32, TN = WN / 32;               // 32x32 MFMA tiles per wave
+    static_assert(TM >= 1 && TN >= 1, "wave tile too small");
+    constexpr int XV = BM / 32, WV = BN / 32;                // float4 loads per thread per K-step
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int STAGE = (BM + BN) * LDS_STRIDE;           // floats per pipeline stage: X tile then W tile
+
+    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
+    const int lid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tm = lid % tiles_m, tn = lid / tiles_m;       // m fastest: neighbours share the W panel
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int li = lane & 31, lh = lane >> 5;
+
+    // staging assignment: thread -> (row = tid/8 + 32*i, 4 floats at col 4*(tid%8))
+    const int srow = tid >> 3, scol = (tid & 7) * 4;
+    f32x4 rx[XV], rw[WV];
+
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            const int m = m0 + srow + 32 * i;
+            rx[i] = (m < a.M) ? *reinterpret_cast<const f32x4*>(a.X + (size_t)m * a.ldx + k0 + scol) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < WV; ++i) {
+            const int n = n0 + srow + 32 * i;
+            rw[i] = (n < a.N) ? *reinterpret_cast<const f32x4*>(a.W + (size_t)n * a.K + k0 + scol) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < XV; ++i) *reinterpret_cast<f32x4*>(smem + buf * STAGE + (srow + 32 * i) * LDS_STRIDE + scol) = rx[i];
+#pragma unroll
+        for (int i = 0; i < WV; ++i) *reinterpret_cast<f32x4*>(smem + buf * STAGE + (BM + srow + 32 * i) * LDS_STRIDE + scol) = rw[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = a.K / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile((kt + 1) * BK);
+        const float* px = smem + buf * STAGE + (wm * WM + li) * LDS_STRIDE + 4 * lh;
+        const float* pw = smem + buf * STAGE + (BM + wn * WN + li) * LDS_STRIDE + 4 * lh;
+#pragma unroll
+        for (int c = 0; c < BK / 8; ++c) {
+            f32x4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(px + i * 32 * LDS_STRIDE + 8 * c);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(pw + j * 32 * LDS_STRIDE + 8 * c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: lane owns column n, rows (r&3) + 8*(r>>2) + 4*lh of each 32x32 tile
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WN + j * 32 + li;
+        if (n >= a.N) continue;
+        const float bv = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= a.M) continue;
+                float v = acc[i][j][r] + bv;
+                if (EPI == EPI_BIAS_GELU) v = gelu_tanh(v);
+                if (EPI == EPI_GATED_RES) {
+                    const float g = a.gate[(size_t)(m / a.rows_per_gate) * a.gate_stride + n];
+                    v = a.res[(size_t)m * a.ldres + n] + v * g;
+                }
+                a.out[(size_t)m * a.ldo + n] = v;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+static int launch_cfg(const GemmArgs& a, int epi, hipStream_t stream) {
+    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    const size_t lds = 2 * (size_t)(BM + BN) * LDS_STRIDE * sizeof(float);
+    dim3 grid(tiles), block(256);
+    static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in once per kernel
+    if (!attr_set) {
+        SDVAR_HIP(hipFuncSetAttribute((const void*)gemm_f32_nt_kernel<BM, BN, WAVES_M, WAVES_N, EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SDVAR_HIP(hipFuncSetAttribute((const void*)gemm_f32_nt_kernel<BM, BN, WAVES_M, WAVES_N, EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SDVAR_HIP(hipFuncSetAttribute((const void*)gemm_f32_nt_kernel<BM, BN, WAVES_M, WAVES_N, EPI_GATED_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    switch (epi) {
+        case EPI_BIAS: hipLaunchKernelGGL((gemm_f32_nt_kernel<BM, BN, WAVES_M, WAVES_N, EPI_BIAS>), grid, block, lds, stream, a); break;
+        case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_f32_nt_kernel<BM, BN, WAVES_M, WAVES_N, EPI_BIAS_GELU>), grid, block, lds, stream, a); break;
+        case EPI_GATED_RES: hipLaunchKernelGGL((gemm_f32_nt_kernel<BM, BN, WAVES_M, WAVES_N, EPI_GATED_RES>), grid, block, lds, stream, a); break;
+        default: set_error("gemm: unknown epilogue %d", epi); return SDVAR_ERR_ARG;
+    }
+    SDVAR_LAUNCH_CHECK();
+    return SDVAR_OK;
+}
+
+// Host entry used by the model code and by the op-level C-ABI.
+int gemm_f32_nt(const float* X, int ldx, const float* W, const float* bias, float* out, int ldo, int M, int N, int K, int epi,
+                const float* res, int ldres, const float* gate, int rows_per_gate, int gate_stride, hipStream_t stream) {
+    SDVAR_CHECK_ARG(X && W && out, "gemm: null operand");
+    SDVAR_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % BK == 0, "gemm: need K %% 32 == 0 (M=%d N=%d K=%d)", M, N, K);
+    SDVAR_CHECK_ARG(ldx >= K && ldx % 4 == 0 && ldo >= N, "gemm: bad leading dims ldx=%d ldo=%d", ldx, ldo);
+    SDVAR_CHECK_ARG(((uintptr_t)X % 16) == 0 && ((uintptr_t)W % 16) == 0, "gemm: operands must be 16-byte aligned");
+    if (epi == EPI_GATED_RES) SDVAR_CHECK_ARG(res && gate && rows_per_gate > 0 && ldres >= N, "gemm: gated-residual epilogue needs res/gate");
+    GemmArgs a{X, W, bias, out, res, gate, M, N, K, ldx, ldo, ldres, rows_per_gate > 0 ? rows_per_gate : 1, gate_stride};
+    if (M <= 32) return launch_cfg<32, 128, 1, 4>(a, epi, stream);
+    if (M <= 64 || (size_t)((M + 127) / 128) * ((N + 127) / 128) < 192) return launch_cfg<64, 128, 2, 2>(a, epi, stream);
+    return launch_cfg<128, 128, 2, 2>(a, epi, stream);
+}
+
+}  // namespace sdvar

@@ -1,0 +1,65 @@
+"""One-process-per-GPU sharding of independent image samples.
+
+The sampling path has no data-path exchange: images are independent, every rank holds full weight replicas and private
+KV caches, and the acceptance decision is taken per shard (`accept_scope="shard"`).  The only collective is ONE
+all-gather of per-rank counters (accepted tokens, target calls, ...) after the run - RCCL over xGMI on the GPU box
+(`backend="nccl"`), gloo in the CPU tests.  Noise is keyed by the GLOBAL image index (sdvar_amd/noise.py), so a shard
+produces exactly the tokens the same images would get in a single-process run of the whole batch with shard scope.
+The reference has no counterpart (its inference is single-device; dist.py there only serves training).
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Sequence, Tuple
+
+import torch
+import torch.distributed as tdist
+
+COUNTER_KEYS = ("images", "accepted_tokens", "target_calls", "draft_stage_calls", "forced_accepts")
+
+
+def init_from_env(device_type: str = "cuda") -> Tuple[int, int, int]:
+    """(rank, world, local_rank) from the torchrun environment; initialises the process group when world > 1."""
+    rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    if world > 1 and not tdist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = "nccl" if device_type == "cuda" else "gloo"
+        if device_type == "cuda":
+            torch.cuda.set_device(local)
+        tdist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous batch split: images [lo, hi) of the global batch belong to `rank` (remainder to the low ranks)."""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_counters(stats: Dict[str, int], device) -> Dict[str, object]:
+    """All-gather the per-rank counters; returns totals plus the per-rank table (identical on every rank)."""
+    vec = torch.tensor([int(stats.get(k, 0)) for k in COUNTER_KEYS], dtype=torch.int64, device=device)
+    if tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1:
+        out = [torch.zeros_like(vec) for _ in range(tdist.get_world_size())]
+        tdist.all_gather(out, vec)
+        table = torch.stack(out).cpu()
+    else:
+        table = vec.cpu().view(1, -1)
+    tot = table.sum(0).tolist()
+    res = {k: int(v) for k, v in zip(COUNTER_KEYS, tot)}
+    res["per_rank"] = table.tolist()
+    res["mean_accepted_tokens_per_step"] = (res["accepted_tokens"] / res["target_calls"]) if res["target_calls"] else 0.0
+    return res
+
+
+def max_over_ranks(value: float, device) -> float:
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    if tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1:
+        tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    if tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1:
+        tdist.barrier()

@@ -1,0 +1,401 @@
+"""ctypes binding of libsdvar_hip.so (include/sdvar_hip.h) and the host-side sampling loops built on it.
+
+PyTorch is plumbing here: it owns the weight tensors and a few staging buffers (device memory + streams); every
+operation of the draft -> verify loop is a call into the C ABI.  There is NO fallback: if the shared library is missing
+or a call fails this module raises - the product path never routes through torch ops or the CPU oracle.
+
+Reference loops restated on top of the ABI:
+  * `Sampler.plain_ar`  - VAR.autoregressive_infer_cfg         (/root/reference/models/var.py:127-215)
+  * `Sampler.spec_decode` - SDVAR.sdvar_autoregressive_infer_cfg_parallel_v1 with the resolved semantics of
+    SURVEY.md App. C.1 (models/var.py:949-1070 draft/verify, 1160-1227 acceptance, 1318-1372 loop policy).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .ladder import Ladder, as_ladder
+from .noise import exponential_noise
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsdvar_hip.so")
+MAX_STAGES = 16
+PROF_CLASSES = ("gemm", "attention", "ln_modulate", "qk_norm_append", "sampler", "verify", "quant", "embed_misc")
+
+
+class SdvarError(RuntimeError):
+    pass
+
+
+class _ModelDesc(C.Structure):
+    _fields_ = [("depth", C.c_int32), ("n_stages", C.c_int32), ("patch_nums", C.c_int32 * MAX_STAGES), ("vocab", C.c_int32),
+                ("cvae", C.c_int32), ("num_classes", C.c_int32), ("max_batch", C.c_int32), ("max_chunk_stages", C.c_int32)]
+
+
+_P, _I, _D, _U64, _U32 = C.c_void_p, C.c_int32, C.c_double, C.c_uint64, C.c_uint32
+# name -> (restype, argtypes); must list every symbol declared in include/sdvar_hip.h (tests/test_abi.py checks it)
+_SIGNATURES = {
+    "sdvar_abi_version": (_I, []),
+    "sdvar_last_error": (C.c_char_p, []),
+    "sdvar_model_create": (_I, [C.POINTER(_ModelDesc), C.POINTER(_P)]),
+    "sdvar_model_destroy": (_I, [_P]),
+    "sdvar_model_bind_embed": (_I, [_P] * 8),
+    "sdvar_model_bind_block": (_I, [_P, _I] + [_P] * 13),
+    "sdvar_model_bind_head": (_I, [_P] * 5),
+    "sdvar_model_begin": (_I, [_P, _I, _P, _P]),
+    "sdvar_model_place_first": (_I, [_P, _P, _I, _P]),
+    "sdvar_kv_len": (_I, [_P]),
+    "sdvar_kv_set_len": (_I, [_P, _I]),
+    "sdvar_embed_next": (_I, [_P, _P, _I, _P, _I, _I, _P]),
+    "sdvar_stage_forward": (_I, [_P, _P, _I, _I, _P, _P]),
+    "sdvar_quant_create": (_I, [_I, C.POINTER(_I), _I, _I, _I, _I, C.POINTER(_P)]),
+    "sdvar_quant_destroy": (_I, [_P]),
+    "sdvar_quant_bind": (_I, [_P, _P, C.POINTER(_P), C.POINTER(_P)]),
+    "sdvar_quant_next": (_I, [_P, _I, _P, _I, _P, _P, _I, _P]),
+    "sdvar_cfg_sample": (_I, [_P, _I, _I, _I, _D, _I, _D, _P, _U64, _U32, _U32, _P, _I, _P, _P]),
+    "sdvar_verify_accept": (_I, [_P, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_D), _P, _I, _D, _P, _P, _P]),
+    "sdvar_op_gemm": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P]),
+    "sdvar_op_ln_modulate": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "sdvar_op_qk_norm_append": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "sdvar_op_attention": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), _P]),
+    "sdvar_op_noise_fill": (_I, [_P, _I, _I, _I, _U64, _U32, _U32, _P]),
+    "sdvar_prof_enable": (_I, [_I]),
+    "sdvar_prof_collect": (_I, [C.POINTER(_D), C.POINTER(C.c_int64), C.POINTER(_D), C.POINTER(_D)]),
+}
+
+_lib = None
+
+
+def load_library(path: str = LIB_PATH):
+    """dlopen the HIP library and attach prototypes.  Raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise SdvarError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                         f"(make -C sdvar_amd/csrc); there is no CPU fallback for the sampler")
+    lib = C.CDLL(path)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    if lib.sdvar_abi_version() != 1:
+        raise SdvarError("libsdvar_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise SdvarError(f"libsdvar_hip error {rc}: {_lib.sdvar_last_error().decode()}")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device tensors must be contiguous CUDA(HIP) tensors"
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(t: torch.Tensor, dev) -> torch.Tensor:
+    return t.detach().to(device=dev, dtype=torch.float32).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------------- objects
+class ModelCtx:
+    """sdvar_model_t for one VAR transformer given its state_dict (reference key names)."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], depth: int, patch_nums: Sequence[int], max_batch: int, max_chunk: int,
+                 device, num_classes: int = 1000):
+        self.lib = load_library()
+        self.lad = as_ladder(patch_nums)
+        self.depth, self.Cw, self.H = depth, 64 * depth, depth
+        self.V = sd["head.weight"].shape[0]
+        self.device = torch.device(device)
+        self.max_batch, self.max_chunk = max_batch, max_chunk
+        d = _ModelDesc()
+        d.depth, d.n_stages, d.vocab, d.cvae, d.num_classes = depth, self.lad.S, self.V, sd["word_embed.weight"].shape[1], num_classes
+        d.max_batch, d.max_chunk_stages = max_batch, max_chunk
+        for i, p in enumerate(self.lad.patch_nums):
+            d.patch_nums[i] = p
+        self.h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _check(self.lib.sdvar_model_create(C.byref(d), C.byref(self.h)))
+            self._keep: List[torch.Tensor] = []
+            self.bind(sd)
+
+    def bind(self, sd: Dict[str, torch.Tensor]):
+        dev, k = self.device, self._keep
+        k.clear()
+        def w(name):
+            t = _f32(sd[name], dev); k.append(t); return _ptr(t)
+        st = _stream()
+        _check(self.lib.sdvar_model_bind_embed(self.h, w("class_emb.weight"), w("pos_start"), w("pos_1LC"), w("lvl_embed.weight"),
+                                               w("word_embed.weight"), w("word_embed.bias"), st))
+        for i in range(self.depth):
+            p = f"blocks.{i}."
+            _check(self.lib.sdvar_model_bind_block(
+                self.h, i, w(p + "ada_lin.1.weight"), w(p + "ada_lin.1.bias"), w(p + "attn.mat_qkv.weight"), w(p + "attn.q_bias"),
+                w(p + "attn.v_bias"), w(p + "attn.scale_mul_1H11"), w(p + "attn.proj.weight"), w(p + "attn.proj.bias"),
+                w(p + "ffn.fc1.weight"), w(p + "ffn.fc1.bias"), w(p + "ffn.fc2.weight"), w(p + "ffn.fc2.bias"), st))
+        _check(self.lib.sdvar_model_bind_head(self.h, w("head_nm.ada_lin.1.weight"), w("head_nm.ada_lin.1.bias"), w("head.weight"), w("head.bias")))
+
+    # thin wrappers ----------------------------------------------------------------------------------------------
+    def begin(self, labels: torch.Tensor):
+        assert labels.dtype == torch.int64 and labels.is_cuda
+        self.B = labels.shape[0]
+        _check(self.lib.sdvar_model_begin(self.h, self.B, _ptr(labels), _stream()))
+
+    def place_first(self, x: torch.Tensor, ltot: int):
+        _check(self.lib.sdvar_model_place_first(self.h, _ptr(x), ltot, _stream()))
+
+    def embed_next(self, nxt: torch.Tensor, s_next: int, x: torch.Tensor, ltot: int, tok_off: int):
+        _check(self.lib.sdvar_embed_next(self.h, _ptr(nxt), s_next, _ptr(x), ltot, tok_off, _stream()))
+
+    def forward(self, x: torch.Tensor, s0: int, n: int, logits: torch.Tensor):
+        _check(self.lib.sdvar_stage_forward(self.h, _ptr(x), s0, n, _ptr(logits), _stream()))
+
+    def kv_len(self) -> int:
+        return self.lib.sdvar_kv_len(self.h)
+
+    def kv_set_len(self, n: int):
+        _check(self.lib.sdvar_kv_set_len(self.h, n))
+
+    def close(self):
+        if self.h:
+            self.lib.sdvar_model_destroy(self.h); self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class QuantCtx:
+    """sdvar_quant_t from the VQVAE state_dict (quantize.embedding / quantize.quant_resi.qresi_ls.*)."""
+
+    def __init__(self, vae_sd: Dict[str, torch.Tensor], patch_nums: Sequence[int], max_batch: int, device, prefix: str = "quantize."):
+        self.lib = load_library()
+        self.lad = as_ladder(patch_nums)
+        self.device = torch.device(device)
+        self.codebook = _f32(vae_sd[prefix + "embedding.weight"], self.device)
+        self.V, self.Cv = self.codebook.shape
+        n_phi = 0
+        while f"{prefix}quant_resi.qresi_ls.{n_phi}.weight" in vae_sd:
+            n_phi += 1
+        if n_phi == 0:
+            raise SdvarError("only the partially-shared Phi layout (share_quant_resi=4) is supported")
+        self.pw = [_f32(vae_sd[f"{prefix}quant_resi.qresi_ls.{k}.weight"], self.device) for k in range(n_phi)]
+        self.pb = [_f32(vae_sd[f"{prefix}quant_resi.qresi_ls.{k}.bias"], self.device) for k in range(n_phi)]
+        pn = (_I * self.lad.S)(*self.lad.patch_nums)
+        self.h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _check(self.lib.sdvar_quant_create(self.lad.S, pn, self.Cv, self.V, max_batch, n_phi, C.byref(self.h)))
+        aw = (_P * n_phi)(*[t.data_ptr() for t in self.pw]); ab = (_P * n_phi)(*[t.data_ptr() for t in self.pb])
+        _check(self.lib.sdvar_quant_bind(self.h, _ptr(self.codebook), aw, ab))
+
+    def next(self, si: int, ids: torch.Tensor, ids_stride: int, f_hat: torch.Tensor, nxt: Optional[torch.Tensor], B: int):
+        _check(self.lib.sdvar_quant_next(self.h, si, C.c_void_p(ids.data_ptr()), ids_stride, _ptr(f_hat), _ptr(nxt) if nxt is not None else None, B, _stream()))
+
+    def close(self):
+        if self.h:
+            self.lib.sdvar_quant_destroy(self.h); self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------------------------------------------- noise
+class Noise:
+    """Where the Exp(1) draw noise q comes from (sdvar_amd/noise.py explains why it is explicit).
+    kind = 'device': Philox generated inside the sampler kernel (fast path, no host traffic);
+           'host'  : the same Philox stream computed on the host in float64 and uploaded (portable parity mode);
+           'torch' : torch.empty(B*l, V).exponential_(generator=cpu_gen), the reference's own CPU stream on this host;
+           callable: fn(draw, B, l, V) -> float32 array/tensor (B*l, V) or (B, l, V)."""
+
+    def __init__(self, kind="device", seed: int = 0, image_offset: int = 0, fn: Optional[Callable] = None, generator: Optional[torch.Generator] = None):
+        self.kind, self.seed, self.image_offset, self.fn, self.gen = kind, int(seed), int(image_offset), fn, generator
+        if kind == "torch" and generator is None:
+            self.gen = torch.Generator(device="cpu"); self.gen.manual_seed(self.seed)
+
+    def tensor(self, draw: int, B: int, l: int, V: int, device) -> Optional[torch.Tensor]:
+        if self.kind == "device":
+            return None
+        if self.kind == "host":
+            q = torch.from_numpy(exponential_noise(self.seed, draw, B, l, V, self.image_offset))
+        elif self.kind == "torch":
+            q = torch.empty(B * l, V).exponential_(1, generator=self.gen)
+        else:
+            q = self.fn(draw, B, l, V)
+            q = torch.from_numpy(np.ascontiguousarray(q)) if isinstance(q, np.ndarray) else q
+        return q.reshape(B * l, V).to(device=device, dtype=torch.float32, non_blocking=False).contiguous()
+
+
+def cfg_sample(logits: torch.Tensor, B: int, l: int, V: int, t: float, top_k: int, top_p: float, q: Optional[torch.Tensor], seed: int, draw: int,
+               image_offset: int, ids_out: torch.Tensor, ids_off: int, ids_stride: int, dbg_masked: Optional[torch.Tensor] = None):
+    lib = load_library()
+    _check(lib.sdvar_cfg_sample(_ptr(logits), B, l, V, float(t), int(top_k), float(top_p), _ptr(q) if q is not None else None, seed & (2**64 - 1),
+                                draw, image_offset, C.c_void_p(ids_out.data_ptr() + 8 * ids_off), ids_stride,
+                                _ptr(dbg_masked) if dbg_masked is not None else None, _stream()))
+
+
+def verify_accept(logits: torch.Tensor, B: int, lens: Sequence[int], V: int, ts: Sequence[float], ids: torch.Tensor, ids_off: int, ids_stride: int,
+                  thr: float, counts: torch.Tensor, argmax_out: Optional[torch.Tensor] = None):
+    lib = load_library()
+    n = len(lens)
+    _check(lib.sdvar_verify_accept(_ptr(logits), B, int(sum(lens)), V, n, (_I * n)(*lens), (_D * n)(*[float(t) for t in ts]),
+                                   C.c_void_p(ids.data_ptr() + 8 * ids_off), ids_stride, float(thr), _ptr(counts),
+                                   _ptr(argmax_out) if argmax_out is not None else None, _stream()))
+
+
+def prof_enable(on: bool):
+    _check(load_library().sdvar_prof_enable(1 if on else 0))
+
+
+def prof_collect() -> Dict[str, Dict[str, float]]:
+    ms, n, fl, by = (_D * 8)(), (C.c_int64 * 8)(), (_D * 8)(), (_D * 8)()
+    _check(load_library().sdvar_prof_collect(ms, n, fl, by))
+    return {PROF_CLASSES[i]: dict(ms=ms[i], launches=int(n[i]), flops=fl[i], bytes=by[i]) for i in range(8)}
+
+
+# ------------------------------------------------------------------------------------------------------- sampling loops
+@dataclass
+class SampleResult:
+    ids: torch.Tensor                      # (B, L) int64 accepted token ids, stage s at columns [begin(s), begin(s)+l_s)
+    f_hat: torch.Tensor                    # (B, Cvae, HW, HW)
+    stats: Dict[str, object] = field(default_factory=dict)
+    trace: Dict[str, list] = field(default_factory=dict)
+
+
+class Sampler:
+    """Buffers + loops for one (draft, target) pair (or a single model for plain AR) on one GPU."""
+
+    def __init__(self, target: ModelCtx, quant: QuantCtx, draft: Optional[ModelCtx] = None):
+        self.t, self.d, self.q = target, draft, quant
+        self.lad: Ladder = target.lad
+        self.dev = target.device
+        B, V, lad = target.max_batch, target.V, self.lad
+        lens = lad.lens
+        self.lmax_t = max(sum(lens[s:s + target.max_chunk]) for s in range(lad.S))
+        f = dict(device=self.dev, dtype=torch.float32)
+        self.x_t = torch.empty(2 * B * self.lmax_t * target.Cw, **f)
+        self.logits_t = torch.empty(2 * B * self.lmax_t * V, **f)
+        if draft is not None:
+            assert draft.lad.patch_nums == lad.patch_nums and draft.V == V
+            self.x_d = torch.empty(2 * B * lens[-1] * draft.Cw, **f)
+            self.logits_d = torch.empty(2 * B * lens[-1] * V, **f)
+        g = target.max_chunk
+        self.ids = torch.zeros(B, lad.L, device=self.dev, dtype=torch.int64)
+        self.f_work = torch.zeros(B, quant.Cv, lad.HW, lad.HW, **f)
+        self.f_acc = torch.zeros_like(self.f_work)
+        self.f_snap = [torch.zeros_like(self.f_work) for _ in range(g)]
+        self.nxt = [torch.empty(B * lens[-1] * quant.Cv, **f) for _ in range(g)]
+        self.nxt_cur = torch.empty(B * lens[-1] * quant.Cv, **f)
+        self.counts = torch.zeros(40, device=self.dev, dtype=torch.int32)
+        self.counts_host = torch.zeros(40, dtype=torch.int32).pin_memory()
+
+    # ---- VAR.autoregressive_infer_cfg (var.py:127-215) up to the decode
+    def plain_ar(self, labels: torch.Tensor, cfg: float, top_k: int, top_p: float, noise: Noise, trace: bool = False) -> SampleResult:
+        m, qz, lad = self.t, self.q, self.lad
+        B, V, S, L = labels.shape[0], m.V, lad.S, lad.L
+        res = SampleResult(ids=self.ids[:B], f_hat=self.f_work[:B])
+        with torch.cuda.device(self.dev):
+            m.begin(labels)
+            f_hat = self.f_work[:B]; f_hat.zero_()
+            m.place_first(self.x_t, lad.lens[0])
+            for si in range(S):
+                l = lad.lens[si]
+                m.forward(self.x_t, si, 1, self.logits_t)
+                if trace:
+                    res.trace.setdefault("logits", []).append(self.logits_t[:2 * B * l * V].view(2 * B, l, V).clone())
+                q = noise.tensor(si, B, l, V, self.dev)
+                cfg_sample(self.logits_t, B, l, V, lad.cfg_t(cfg, si), top_k, top_p, q, noise.seed, si, noise.image_offset, self.ids, lad.begin(si), L)
+                last = si == S - 1
+                qz.next(si, self.ids[:, lad.begin(si):], L, f_hat, None if last else self.nxt[0], B)
+                if not last:
+                    m.embed_next(self.nxt[0], si + 1, self.x_t, lad.lens[si + 1], 0)
+            m.kv_set_len(0)
+        res.stats = dict(target_calls=S, draft_stage_calls=0, forced_accepts=0, accepted_tokens=0)
+        return res
+
+    # ---- speculative draft -> verify loop
+    def spec_decode(self, labels: torch.Tensor, cfg: float, gamma: int, top_k: int, top_p: float, noise: Noise, thr: float = 0.5,
+                    trace: bool = False) -> SampleResult:
+        assert self.d is not None, "spec_decode needs a draft model"
+        d, t, qz, lad = self.d, self.t, self.q, self.lad
+        assert 1 <= gamma <= t.max_chunk, f"gamma {gamma} exceeds the engine's max_chunk {t.max_chunk}"
+        B, V, S, L, lens = labels.shape[0], t.V, lad.S, lad.L, lad.lens
+        st = dict(target_calls=0, draft_stage_calls=0, forced_accepts=0, accepted_tokens=0, rounds=[], gamma_final=gamma)
+        res = SampleResult(ids=self.ids[:B], f_hat=self.f_acc[:B], stats=st)
+        with torch.cuda.device(self.dev):
+            d.begin(labels); t.begin(labels)
+            f_acc, f_work = self.f_acc[:B], self.f_work[:B]
+            f_acc.zero_()
+            cur, draw = 0, 0
+            while cur < S:
+                g = min(gamma, S - cur)
+                glen = lens[cur:cur + g]
+                lsum = sum(glen)
+                offs = [sum(glen[:j]) for j in range(g)]
+                # inputs of stage `cur` for both models
+                if cur == 0:
+                    d.place_first(self.x_d, lens[0]); t.place_first(self.x_t, lsum)
+                else:
+                    d.embed_next(self.nxt_cur, cur, self.x_d, lens[cur], 0); t.embed_next(self.nxt_cur, cur, self.x_t, lsum, 0)
+                f_work.copy_(f_acc)
+                # ---- draft g stages (var.py:949-1024)
+                for j in range(g):
+                    s = cur + j
+                    d.forward(self.x_d, s, 1, self.logits_d)
+                    st["draft_stage_calls"] += 1
+                    q = noise.tensor(draw, B, lens[s], V, self.dev)
+                    cfg_sample(self.logits_d, B, lens[s], V, lad.cfg_t(cfg, s), top_k, top_p, q, noise.seed, draw, noise.image_offset, self.ids, lad.begin(s), L)
+                    draw += 1
+                    last = s == S - 1
+                    qz.next(s, self.ids[:, lad.begin(s):], L, f_work, None if last else self.nxt[j], B)
+                    self.f_snap[j][:B].copy_(f_work)
+                    if j + 1 < g:
+                        d.embed_next(self.nxt[j], s + 1, self.x_d, lens[s + 1], 0)
+                        t.embed_next(self.nxt[j], s + 1, self.x_t, lsum, offs[j + 1])
+                # ---- ONE target forward over the g stages + acceptance scan (var.py:1026-1070, 1160-1227)
+                t.forward(self.x_t, cur, g, self.logits_t)
+                st["target_calls"] += 1
+                if trace:
+                    res.trace.setdefault("target_logits", []).append((cur, g, self.logits_t[:2 * B * lsum * V].view(2 * B, lsum, V).clone()))
+                # draft ids of the chunk, stage j at ids[:, begin(cur+j)...]: contiguous columns begin(cur) .. begin(cur)+lsum
+                verify_accept(self.logits_t, B, glen, V, [lad.cfg_t(cfg, cur + j) for j in range(g)], self.ids, lad.begin(cur), L, thr, self.counts)
+                self.counts_host.copy_(self.counts, non_blocking=False)        # the one host sync of the round
+                c = self.counts_host.tolist()
+                n_acc, matched = c[16], c[:g]
+                forced = False
+                if n_acc == 0:                                                  # var.py:1353-1364
+                    if gamma > 1:
+                        gamma -= 1
+                    else:
+                        n_acc, forced = 1, True
+                        st["forced_accepts"] += 1
+                st["rounds"].append(dict(stage=cur, g=g, matched=matched, total=[B * n for n in glen], n_accept=n_acc, forced=forced))
+                if n_acc > 0:                                                   # commit (var.py:1245-1282, 1349-1350)
+                    f_acc.copy_(self.f_snap[n_acc - 1][:B])
+                    if not forced:
+                        st["accepted_tokens"] += sum(glen[:n_acc])
+                    if cur + n_acc < S:
+                        self.nxt_cur.copy_(self.nxt[n_acc - 1])
+                    cur += n_acc
+                keep = lad.begin(cur) if cur < S else L
+                d.kv_set_len(keep); t.kv_set_len(keep)                          # rollback of the rejected suffix
+            st["gamma_final"] = gamma
+            d.kv_set_len(0); t.kv_set_len(0)
+        return res

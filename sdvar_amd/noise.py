@@ -7,7 +7,7 @@ token ids can only be compared across machines when q is an explicit, portable i
 
     counter = (v >> 2, token, image_global, draw)   key = (seed_lo, seed_hi ^ 0x5D5A17AB)
     x       = Philox4x32-10(counter, key)[v & 3]
-    u       = ((x >> 8) + 0.5) * 2^-24          in (0, 1)
+    u       = ((x >> 9) + 0.5) * 2^-23          in (0, 1), exactly representable in float32
     q       = -log(u)                           (host: float64 log rounded to float32)
 
 `draw` is the index of the sampler call in the run (one per drafted stage), `image_global` the index of the image in
@@ -48,5 +48,5 @@ def exponential_noise(seed: int, draw: int, B: int, l: int, V: int, image_offset
     img = (np.arange(B, dtype=np.uint32) + np.uint32(image_offset))[:, None, None]
     x = philox4x32_10(v4, tok, img, np.uint32(draw), k0, k1)
     x = np.stack(x, axis=-1).reshape(B, l, V)
-    u = ((x >> np.uint32(8)).astype(np.float64) + 0.5) * (2.0 ** -24)
+    u = ((x >> np.uint32(9)).astype(np.float64) + 0.5) * (2.0 ** -23)
     return (-np.log(u)).astype(np.float32)

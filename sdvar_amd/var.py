@@ -1,0 +1,275 @@
+"""Host-side mirror of the reference's `models.var` API for the sampling path: VAR and SDVAR.
+
+Same constructor arguments, attribute names, sampler signatures and state_dict keys as
+/root/reference/models/var.py:22-215 (VAR) and :535-1383 (SDVAR), so existing callers and upstream checkpoints work
+unchanged - but the modules here only HOLD parameters; every sampler call runs on the gfx950 kernels through
+sdvar_amd.engine (C ABI).  Training-side methods (VAR.forward with teacher forcing, progressive training) are outside
+the scope table and raise NotImplementedError.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Sequence, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from . import engine as E
+from .ladder import as_ladder
+from .vqvae import VQVAE
+
+
+class _SelfAttention(nn.Module):                   # parameter names of basic_var.py:58-87
+    def __init__(self, C, H):
+        super().__init__()
+        self.num_heads, self.head_dim = H, C // H
+        self.scale_mul_1H11 = nn.Parameter(torch.full((1, H, 1, 1), 4.0).log())
+        self.mat_qkv = nn.Linear(C, 3 * C, bias=False)
+        self.q_bias, self.v_bias = nn.Parameter(torch.zeros(C)), nn.Parameter(torch.zeros(C))
+        self.register_buffer("zero_k_bias", torch.zeros(C))
+        self.proj = nn.Linear(C, C)
+        self.caching = False
+        self._owner = None
+
+    def kv_caching(self, enable: bool):             # basic_var.py:87: toggling resets the cache
+        self.caching = enable
+        if self._owner is not None:
+            self._owner()._kv_reset()
+
+
+class _FFN(nn.Module):
+    def __init__(self, C):
+        super().__init__()
+        self.fc1, self.fc2 = nn.Linear(C, 4 * C), nn.Linear(4 * C, C)
+
+
+class _Block(nn.Module):
+    def __init__(self, C, H):
+        super().__init__()
+        self.attn, self.ffn = _SelfAttention(C, H), _FFN(C)
+        self.ada_lin = nn.Sequential(nn.SiLU(inplace=False), nn.Linear(C, 6 * C))
+
+
+class _HeadNorm(nn.Module):
+    def __init__(self, C):
+        super().__init__()
+        self.ada_lin = nn.Sequential(nn.SiLU(inplace=False), nn.Linear(C, 2 * C))
+
+
+class VAR(nn.Module):
+    def __init__(self, vae_local: VQVAE, num_classes=1000, depth=16, embed_dim=1024, num_heads=16, mlp_ratio=4., drop_rate=0.,
+                 attn_drop_rate=0., drop_path_rate=0., norm_eps=1e-6, shared_aln=False, cond_drop_rate=0.1, attn_l2_norm=False,
+                 patch_nums=(1, 2, 3, 4, 5, 6, 8, 10, 13, 16), flash_if_available=True, fused_if_available=True):
+        super().__init__()
+        assert embed_dim % num_heads == 0
+        if shared_aln:
+            raise NotImplementedError("shared_aln=True (SharedAdaLin, var.py:16-19) is not built; no BASELINE config uses it")
+        if not attn_l2_norm:
+            raise NotImplementedError("attn_l2_norm=False is not built: the factories default to True (models/__init__.py:22)")
+        if embed_dim != 64 * num_heads or num_heads != depth or mlp_ratio != 4.:
+            raise NotImplementedError("the HIP path assumes head_dim 64, heads == depth, mlp_ratio 4 (models/__init__.py:26-27)")
+        self.Cvae, self.V = vae_local.Cvae, vae_local.vocab_size
+        self.depth, self.C, self.D, self.num_heads = depth, embed_dim, embed_dim, num_heads
+        self.patch_nums: Tuple[int] = tuple(patch_nums)
+        lad = as_ladder(patch_nums)
+        self.L, self.first_l = lad.L, lad.lens[0]
+        self.begin_ends = [(lad.begin(s), lad.cum[s]) for s in range(lad.S)]
+        self.num_stages_minus_1 = lad.S - 1
+        self.num_classes = num_classes
+        self.vae_proxy, self.vae_quant_proxy = (vae_local,), (vae_local.quantize,)
+        C = embed_dim
+        self.word_embed = nn.Linear(self.Cvae, C)
+        self.class_emb = nn.Embedding(num_classes + 1, C)
+        self.pos_start = nn.Parameter(torch.zeros(1, self.first_l, C))
+        self.pos_1LC = nn.Parameter(torch.zeros(1, self.L, C))
+        self.lvl_embed = nn.Embedding(lad.S, C)
+        self.shared_ada_lin = nn.Identity()
+        self.blocks = nn.ModuleList([_Block(C, num_heads) for _ in range(depth)])
+        lvl = torch.cat([torch.full((n,), i, dtype=torch.int64) for i, n in enumerate(lad.lens)]).view(1, self.L)
+        self.register_buffer("lvl_1L", lvl)
+        d = lvl.view(1, self.L, 1)
+        self.register_buffer("attn_bias_for_masking", torch.where(d >= d.transpose(1, 2), 0., -torch.inf).reshape(1, 1, self.L, self.L).contiguous())
+        self.head_nm = _HeadNorm(C)
+        self.head = nn.Linear(C, self.V)
+        self.rng = torch.Generator(device="cpu")
+        import weakref
+        for b in self.blocks:
+            b.attn._owner = weakref.ref(self)
+        self._ctx: Optional[E.ModelCtx] = None
+        self._sampler: Optional[E.Sampler] = None
+        self._quant: Optional[E.QuantCtx] = None
+        self.noise_kind = "device"                  # 'device' | 'host' | 'torch' (sdvar_amd.engine.Noise)
+        self.last_result: Optional[E.SampleResult] = None
+
+    # ---- engine plumbing ---------------------------------------------------------------------------------------
+    def _device(self):
+        return self.lvl_1L.device
+
+    def _kv_reset(self):
+        if self._ctx is not None and self._ctx.kv_len() > 0:
+            self._ctx.kv_set_len(0)
+
+    def invalidate_engine(self):
+        """Call after changing parameters in place (load_state_dict does it automatically)."""
+        self._ctx = self._sampler = self._quant = None
+
+    def load_state_dict(self, *a, **kw):
+        out = super().load_state_dict(*a, **kw)
+        self.invalidate_engine()
+        return out
+
+    def _apply(self, fn, *a, **kw):                 # .to()/.cuda() move the tensors the engine points at
+        self.invalidate_engine()
+        return super()._apply(fn, *a, **kw)
+
+    def engine_ctx(self, max_batch: int, max_chunk: int = 1) -> E.ModelCtx:
+        dev = self._device()
+        if dev.type != "cuda":
+            raise E.SdvarError("the sampler runs on an MI355X: move the model to a cuda (HIP) device; there is no CPU path")
+        c = self._ctx
+        if c is None or c.max_batch < max_batch or c.max_chunk < max_chunk or c.device != dev:
+            if c is not None:
+                c.close()
+            self._ctx = E.ModelCtx(self.state_dict(), self.depth, self.patch_nums, max_batch, max_chunk, dev, self.num_classes)
+            self._sampler = None
+        return self._ctx
+
+    def quant_ctx(self, max_batch: int) -> E.QuantCtx:
+        if self._quant is None or self._quant.lad.patch_nums != self.patch_nums or self._quant.device != self._device():
+            sd = {"quantize." + k: v for k, v in self.vae_quant_proxy[0].state_dict().items()}
+            self._quant = E.QuantCtx(sd, self.patch_nums, max(max_batch, 1), self._device())
+        return self._quant
+
+    def _labels(self, B, label_B, rng):             # var.py:147-150
+        dev = self._device()
+        if label_B is None:
+            p = torch.full((1, self.num_classes), 1.0 / self.num_classes)
+            label_B = torch.multinomial(p, num_samples=B, replacement=True, generator=rng).reshape(B)
+        elif isinstance(label_B, int):
+            label_B = torch.full((B,), fill_value=self.num_classes if label_B < 0 else label_B)
+        label_B = label_B.to(device=dev, dtype=torch.int64).contiguous()
+        assert label_B.shape == (B,)
+        return label_B
+
+    def _noise(self, g_seed, image_offset=0) -> E.Noise:
+        seed = int(torch.seed() & 0x7FFFFFFFFFFFFFFF) if g_seed is None else int(g_seed)
+        if self.noise_kind == "torch":
+            return E.Noise("torch", seed, generator=self.rng if g_seed is not None else None)
+        return E.Noise(self.noise_kind, seed, image_offset)
+
+    # ---- the sampler (var.py:127-215) ----------------------------------------------------------------------------
+    @torch.no_grad()
+    def autoregressive_infer_cfg(self, B: int, label_B: Optional[Union[int, torch.LongTensor]], g_seed: Optional[int] = None, cfg=1.5,
+                                 top_k=0, top_p=0.0, more_smooth=False) -> torch.Tensor:
+        if more_smooth:
+            raise NotImplementedError("more_smooth=True (gumbel visualisation path, helpers.py:22-36) is not built")
+        if g_seed is None:
+            rng = None
+        else:
+            self.rng.manual_seed(g_seed); rng = self.rng
+        labels = self._labels(B, label_B, rng)
+        ctx = self.engine_ctx(B, 1)
+        if self._sampler is None or self._sampler.t is not ctx:
+            self._sampler = E.Sampler(ctx, self.quant_ctx(ctx.max_batch))
+        res = self._sampler.plain_ar(labels, cfg, top_k, top_p, self._noise(g_seed))
+        self.last_result = res
+        return self.vae_proxy[0].fhat_to_img(res.f_hat.clone()).add_(1).mul_(0.5)
+
+    def forward(self, *a, **kw):
+        raise NotImplementedError("teacher-forced training forward (var.py:217-259) is outside the sampling hot path")
+
+    def init_weights(self, init_adaln=0.5, init_adaln_gamma=1e-5, init_head=0.02, init_std=0.02, conv_std_or_gain=0.02, seed: int = 1234):
+        """Distributions of var.py:261-311 drawn from a seeded generator (sdvar_amd.weights 'perf' init)."""
+        from .weights import var_state_dict
+        sd = var_state_dict(self.depth, self.patch_nums, "perf", seed, V=self.V, Cvae=self.Cvae, num_classes=self.num_classes)
+        self.load_state_dict({k: v.to(self._device()) for k, v in sd.items()})
+
+
+class SDVAR(nn.Module):
+    """Speculative draft -> verify sampler over a (draft, target) VAR pair (models/var.py:535-1383)."""
+
+    def __init__(self, draft_model: VAR, target_model: VAR, similarity_thresh: float = 0.8):
+        super().__init__()
+        self.draft_model, self.target_model = draft_model, target_model
+        self.similarity_thresh = similarity_thresh     # stored and never read, as in the reference (var.py:546)
+        self.match_threshold = 0.5                      # the constant of var.py:1215
+        self.noise_kind = "device"
+        self.accept_scope = "shard"
+        self._sampler: Optional[E.Sampler] = None
+        self.last_result: Optional[E.SampleResult] = None
+
+    def init_param(self, model: VAR, B: int, label_B):
+        raise NotImplementedError("init_param (var.py:580-601) is fused into sdvar_model_begin; use the sampler entry points")
+
+    def _get_sampler(self, B: int, gamma: int) -> E.Sampler:
+        d, t = self.draft_model, self.target_model
+        assert d.patch_nums == t.patch_nums                                   # var.py:877
+        dc, tc = d.engine_ctx(B, 1), t.engine_ctx(B, max(gamma, 1))
+        s = self._sampler
+        if s is None or s.t is not tc or s.d is not dc:
+            self._sampler = E.Sampler(tc, t.quant_ctx(tc.max_batch), dc)
+        return self._sampler
+
+    @torch.no_grad()
+    def sdvar_autoregressive_infer_cfg_parallel_v1(self, B: int, label_B: Optional[Union[int, torch.LongTensor]] = None, g_seed: Optional[int] = None,
+                                                   cfg: float = 1.5, gamma: int = 2, top_k: int = 0, top_p: float = 0.0, more_smooth: bool = False) -> torch.Tensor:
+        if more_smooth:
+            raise NotImplementedError("more_smooth=True is not built")
+        t = self.target_model
+        rng = None
+        if g_seed is not None:
+            rng = torch.Generator(device="cpu"); rng.manual_seed(g_seed)      # var.py:882-887
+        labels = t._labels(B, label_B, rng)
+        smp = self._get_sampler(B, gamma)
+        seed = int(torch.seed() & 0x7FFFFFFFFFFFFFFF) if g_seed is None else int(g_seed)
+        noise = E.Noise("torch", seed, generator=rng) if self.noise_kind == "torch" else E.Noise(self.noise_kind, seed)
+        res = smp.spec_decode(labels, cfg, gamma, top_k, top_p, noise, thr=self.match_threshold)
+        self.last_result = res
+        return t.vae_proxy[0].fhat_to_img(res.f_hat.clone()).add_(1).mul_(0.5)
+
+
+def _factory_checks(patch_nums: Sequence[int]):
+    if len(patch_nums) > E.MAX_STAGES:
+        raise NotImplementedError(f"ladders longer than {E.MAX_STAGES} stages are not supported")
+
+
+def build_vae_var(device, patch_nums=(1, 2, 3, 4, 5, 6, 8, 10, 13, 16), V=4096, Cvae=32, ch=160, share_quant_resi=4, num_classes=1000, depth=16,
+                  shared_aln=False, attn_l2_norm=True, flash_if_available=True, fused_if_available=True, init_adaln=0.5, init_adaln_gamma=1e-5,
+                  init_head=0.02, init_std=-1):
+    """models/__init__.py:16-46 (same arguments and return value)."""
+    _factory_checks(patch_nums)
+    vae = VQVAE(vocab_size=V, z_channels=Cvae, ch=ch, test_mode=True, share_quant_resi=share_quant_resi, v_patch_nums=patch_nums).to(device)
+    var = VAR(vae_local=vae, num_classes=num_classes, depth=depth, embed_dim=depth * 64, num_heads=depth, drop_rate=0., attn_drop_rate=0.,
+              drop_path_rate=0.1 * depth / 24, norm_eps=1e-6, shared_aln=shared_aln, cond_drop_rate=0.1, attn_l2_norm=attn_l2_norm,
+              patch_nums=patch_nums, flash_if_available=flash_if_available, fused_if_available=fused_if_available).to(device)
+    var.init_weights(init_adaln=init_adaln, init_adaln_gamma=init_adaln_gamma, init_head=init_head, init_std=init_std)
+    _init_vae(vae)
+    return vae, var
+
+
+def build_vae_var_speculative_decoding(device, patch_nums=(1, 2, 3, 4, 5, 6, 8, 10, 13, 16), V=4096, Cvae=32, ch=160, share_quant_resi=4,
+                                       num_classes=1000, depth_draft=16, depth_target=30, shared_aln=False, attn_l2_norm=True,
+                                       flash_if_available=True, fused_if_available=True, init_adaln=0.5, init_adaln_gamma=1e-5, init_head=0.02,
+                                       init_std=-1, similarity_thresh=0.8):
+    """models/__init__.py:51-97 (same arguments; returns (vae, draft, target, sd_var); one VQVAE shared by both models)."""
+    _factory_checks(patch_nums)
+    vae = VQVAE(vocab_size=V, z_channels=Cvae, ch=ch, test_mode=True, share_quant_resi=share_quant_resi, v_patch_nums=patch_nums).to(device)
+    models = []
+    for depth in (depth_draft, depth_target):
+        m = VAR(vae_local=vae, num_classes=num_classes, depth=depth, embed_dim=depth * 64, num_heads=depth, drop_path_rate=0.1 * depth / 24,
+                shared_aln=shared_aln, attn_l2_norm=attn_l2_norm, patch_nums=patch_nums, flash_if_available=flash_if_available,
+                fused_if_available=fused_if_available).to(device)
+        m.init_weights(init_adaln=init_adaln, init_adaln_gamma=init_adaln_gamma, init_head=init_head, init_std=init_std)
+        models.append(m)
+    _init_vae(vae)
+    return vae, models[0], models[1], SDVAR(models[0], models[1], similarity_thresh)
+
+
+def _init_vae(vae: VQVAE, seed: int = 1234):
+    """The reference leaves the VQVAE uninitialised when no checkpoint is loaded; give it the seeded
+    'perf' init so random-weight runs are finite and reproducible."""
+    from .weights import vae_state_dict
+    dev = next(vae.parameters()).device
+    sd = vae_state_dict(vae.quantize.v_patch_nums, "perf", seed, V=vae.vocab_size, Cvae=vae.Cvae, ch=vae.decoder.conv_out.in_channels,
+                        with_encoder=hasattr(vae, "encoder"))
+    vae.load_state_dict({k: v.to(dev) for k, v in sd.items()})

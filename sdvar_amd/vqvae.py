@@ -1,0 +1,168 @@
+"""VQVAE parameter container + image decoder with the reference's state_dict layout.
+
+Only the quantizer tensors (codebook, shared Phi convs) are on the HIP hot path (sdvar_amd/csrc/quant.hip).  The conv
+decoder `fhat_to_img` (/root/reference/models/vqvae.py:62-63, models/basic_vae.py:163-226) is the "next" row of the scope
+table: it runs on PyTorch-ROCm (MIOpen) here.  Module/parameter names follow the upstream
+checkpoint `vae_ch160v4096z32.pth` so it loads unchanged; the encoder is kept as parameters only (it is never run in
+sampling).
+"""
+from __future__ import annotations
+
+from typing import Sequence
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _gn(c): return nn.GroupNorm(32, c, eps=1e-6, affine=True)
+
+
+class _Res(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.norm1, self.conv1 = _gn(cin), nn.Conv2d(cin, cout, 3, 1, 1)
+        self.norm2, self.conv2 = _gn(cout), nn.Conv2d(cout, cout, 3, 1, 1)
+        self.nin_shortcut = nn.Conv2d(cin, cout, 1) if cin != cout else nn.Identity()
+
+    def forward(self, x):
+        h = self.conv1(F.silu(self.norm1(x)))
+        h = self.conv2(F.silu(self.norm2(h)))
+        return self.nin_shortcut(x) + h
+
+
+class _Attn(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.C = c
+        self.norm, self.qkv, self.proj_out = _gn(c), nn.Conv2d(c, 3 * c, 1), nn.Conv2d(c, c, 1)
+
+    def forward(self, x):
+        B, C, H, W = x.shape
+        q, k, v = self.qkv(self.norm(x)).reshape(B, 3, C, H * W).unbind(1)
+        w = torch.bmm(q.transpose(1, 2), k).mul_(C ** -0.5).softmax(dim=2)
+        h = torch.bmm(v, w.transpose(1, 2)).view(B, C, H, W)
+        return x + self.proj_out(h)
+
+
+class _Up(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.conv = nn.Conv2d(c, c, 3, 1, 1)
+
+    def forward(self, x):
+        return self.conv(F.interpolate(x, scale_factor=2, mode="nearest"))
+
+
+class _Down(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.conv = nn.Conv2d(c, c, 3, 2, 0)
+
+
+class Decoder(nn.Module):
+    def __init__(self, ch, ch_mult, nrb, z):
+        super().__init__()
+        nres = len(ch_mult)
+        bi = ch * ch_mult[-1]
+        self.conv_in = nn.Conv2d(z, bi, 3, 1, 1)
+        self.mid = nn.Module()
+        self.mid.block_1, self.mid.attn_1, self.mid.block_2 = _Res(bi, bi), _Attn(bi), _Res(bi, bi)
+        self.up = nn.ModuleList()
+        for lv in reversed(range(nres)):
+            bo = ch * ch_mult[lv]
+            up = nn.Module()
+            up.block, up.attn = nn.ModuleList(), nn.ModuleList()
+            for _ in range(nrb + 1):
+                up.block.append(_Res(bi, bo)); bi = bo
+                if lv == nres - 1:
+                    up.attn.append(_Attn(bi))
+            if lv != 0:
+                up.upsample = _Up(bi)
+            self.up.insert(0, up)
+        self.norm_out, self.conv_out = _gn(bi), nn.Conv2d(bi, 3, 3, 1, 1)
+
+    def forward(self, z):
+        h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(self.conv_in(z))))
+        for lv in reversed(range(len(self.up))):
+            up = self.up[lv]
+            for ib, blk in enumerate(up.block):
+                h = blk(h)
+                if len(up.attn):
+                    h = up.attn[ib](h)
+            if lv != 0:
+                h = up.upsample(h)
+        return self.conv_out(F.silu(self.norm_out(h)))
+
+
+class Encoder(nn.Module):
+    """Parameters only (state_dict compatibility); sampling never encodes."""
+    def __init__(self, ch, ch_mult, nrb, z):
+        super().__init__()
+        nres = len(ch_mult)
+        self.conv_in = nn.Conv2d(3, ch, 3, 1, 1)
+        in_mult = (1,) + tuple(ch_mult)
+        self.down = nn.ModuleList()
+        bi = ch
+        for lv in range(nres):
+            bi, bo = ch * in_mult[lv], ch * ch_mult[lv]
+            dn = nn.Module()
+            dn.block, dn.attn = nn.ModuleList(), nn.ModuleList()
+            for _ in range(nrb):
+                dn.block.append(_Res(bi, bo)); bi = bo
+                if lv == nres - 1:
+                    dn.attn.append(_Attn(bi))
+            if lv != nres - 1:
+                dn.downsample = _Down(bi)
+            self.down.append(dn)
+        self.mid = nn.Module()
+        self.mid.block_1, self.mid.attn_1, self.mid.block_2 = _Res(bi, bi), _Attn(bi), _Res(bi, bi)
+        self.norm_out, self.conv_out = _gn(bi), nn.Conv2d(bi, z, 3, 1, 1)
+
+
+class _PhiList(nn.Module):
+    def __init__(self, n, c):
+        super().__init__()
+        self.qresi_ls = nn.ModuleList([nn.Conv2d(c, c, 3, 1, 1) for _ in range(n)])
+
+
+class Quantizer(nn.Module):
+    """quantize.* tensors of the checkpoint (models/quant.py:15-43); the arithmetic lives in csrc/quant.hip."""
+    def __init__(self, vocab_size, Cvae, v_patch_nums, share_quant_resi=4):
+        super().__init__()
+        if share_quant_resi < 2:
+            raise NotImplementedError("only the partially-shared Phi layout (share_quant_resi >= 2, reference default 4) is built")
+        self.vocab_size, self.Cvae, self.v_patch_nums = vocab_size, Cvae, tuple(v_patch_nums)
+        self.quant_resi = _PhiList(share_quant_resi, Cvae)
+        self.register_buffer("ema_vocab_hit_SV", torch.zeros(len(v_patch_nums), vocab_size))
+        self.embedding = nn.Embedding(vocab_size, Cvae)
+
+
+class VQVAE(nn.Module):
+    def __init__(self, vocab_size=4096, z_channels=32, ch=128, share_quant_resi=4, v_patch_nums: Sequence[int] = (1, 2, 3, 4, 5, 6, 8, 10, 13, 16),
+                 test_mode=True, with_encoder=True, **_unused):
+        super().__init__()
+        self.V = self.vocab_size = vocab_size
+        self.Cvae = z_channels
+        ch_mult, nrb = (1, 1, 2, 2, 4), 2
+        if with_encoder:
+            self.encoder = Encoder(ch, ch_mult, nrb, z_channels)
+        self.decoder = Decoder(ch, ch_mult, nrb, z_channels)
+        self.downsample = 2 ** (len(ch_mult) - 1)
+        self.quantize = Quantizer(vocab_size, z_channels, v_patch_nums, share_quant_resi)
+        self.quant_conv = nn.Conv2d(z_channels, z_channels, 3, 1, 1)
+        self.post_quant_conv = nn.Conv2d(z_channels, z_channels, 3, 1, 1)
+        if test_mode:
+            self.eval()
+            for p in self.parameters():
+                p.requires_grad_(False)
+
+    @torch.no_grad()
+    def fhat_to_img(self, f_hat: torch.Tensor) -> torch.Tensor:      # vqvae.py:62-63
+        return self.decoder(self.post_quant_conv(f_hat)).clamp_(-1, 1)
+
+    def load_state_dict(self, state_dict, strict=True, assign=False):  # vqvae.py:92-95
+        key = "quantize.ema_vocab_hit_SV"
+        if key in state_dict and state_dict[key].shape[0] != self.quantize.ema_vocab_hit_SV.shape[0]:
+            state_dict[key] = self.quantize.ema_vocab_hit_SV
+        return super().load_state_dict(state_dict, strict=strict, assign=assign)

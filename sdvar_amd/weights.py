@@ -161,3 +161,35 @@ def vae_state_dict(patch_nums: Sequence[int], mode: str = "perf", seed: int = 12
         elif kind == "emb": sd[name] = _n(g, shape, 1.0)
         elif kind == "buf": sd[name] = torch.zeros(shape)
     return sd
+
+
+def var_state_dict_device(depth: int, patch_nums: Sequence[int], device, seed: int = 1234, V: int = 4096, Cvae: int = 32,
+                          num_classes: int = 1000) -> "OrderedDict[str, torch.Tensor]":
+    """'perf' init generated directly on the GPU (torch's device generator): same shapes/scales as var_state_dict(mode=
+    'perf'), different values.  For benchmarks only - parity tests use the portable host streams above."""
+    lad = as_ladder(patch_nums)
+    C, H, L, S = 64 * depth, depth, lad.L, lad.S
+    g = torch.Generator(device=device); g.manual_seed(seed * 31 + depth)
+    std0 = math.sqrt(1.0 / C / 3.0)
+    sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+
+    def tn(shape, scale=1.0):
+        return torch.randn(shape, generator=g, device=device, dtype=torch.float32).clamp_(-2.0, 2.0).mul_(std0 * scale)
+
+    def z(shape): return torch.zeros(shape, device=device, dtype=torch.float32)
+    sd["pos_start"], sd["pos_1LC"] = tn((1, 1, C)), tn((1, L, C))
+    sd["word_embed.weight"], sd["word_embed.bias"] = tn((C, Cvae)), z((C,))
+    sd["class_emb.weight"], sd["lvl_embed.weight"] = tn((num_classes + 1, C)), tn((S, C))
+    for i in range(depth):
+        p = f"blocks.{i}."
+        sd[p + "attn.scale_mul_1H11"] = torch.full((1, H, 1, 1), math.log(4.0), device=device)
+        sd[p + "attn.q_bias"], sd[p + "attn.v_bias"], sd[p + "attn.zero_k_bias"] = z((C,)), z((C,)), z((C,))
+        sd[p + "attn.mat_qkv.weight"] = tn((3 * C, C))
+        sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"] = tn((C, C), 1 / math.sqrt(2 * depth)), z((C,))
+        sd[p + "ffn.fc1.weight"], sd[p + "ffn.fc1.bias"] = tn((4 * C, C)), z((4 * C,))
+        sd[p + "ffn.fc2.weight"], sd[p + "ffn.fc2.bias"] = tn((C, 4 * C), 1 / math.sqrt(2 * depth)), z((C,))
+        aw = tn((6 * C, C)); aw[2 * C:] *= 0.5; aw[: 2 * C] *= 1e-5
+        sd[p + "ada_lin.1.weight"], sd[p + "ada_lin.1.bias"] = aw, z((6 * C,))
+    sd["head_nm.ada_lin.1.weight"], sd["head_nm.ada_lin.1.bias"] = tn((2 * C, C), 0.5), z((2 * C,))
+    sd["head.weight"], sd["head.bias"] = tn((V, C), 0.02), z((V,))
+    return sd

@@ -1,0 +1,185 @@
+"""GPU: the whole sampling path through the C ABI against (1) fixtures produced by the REFERENCE, (2) the CPU oracle.
+Token ids are compared bit-exactly, logits within 1e-3 (BASELINE.json north_star); f_hat within 1e-4."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, state_dicts
+from oracle import var_oracle as orc
+from sdvar_amd import engine as E
+from sdvar_amd.ladder import LADDER_256, as_ladder
+from sdvar_amd.noise import exponential_noise
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+LOGIT_TOL = 1e-3
+
+
+def _noise_o(seed):
+    return orc.array_noise(lambda d, B, l, V: exponential_noise(seed, d, B, l, V))
+
+
+def _flip_report(ids_hip, ids_ref, lad):
+    bad = np.argwhere(ids_hip != ids_ref)
+    if len(bad) == 0:
+        return ""
+    b, t = bad[0]
+    s = next(i for i in range(lad.S) if t < lad.cum[i])
+    return f"{len(bad)} ids differ; first at image {b}, token {t} (stage {s})"
+
+
+@pytest.mark.parametrize("name", ["ar_d4_256_stress", "ar_d6_256_stress", "ar_d4_512_stress", "ar_d4_256_notopkp"])
+def test_plain_ar_vs_reference_fixture(dev, name):
+    g = golden(name)
+    depth, pns = int(g["depth"]), tuple(int(p) for p in g["patch_nums"])
+    lad = as_ladder(pns)
+    sd_var, sd_vae = state_dicts(depth, pns, str(g["mode"]), int(g["wseed"]))
+    B = int(g["B"])
+    ctx = E.ModelCtx(sd_var, depth, pns, B, 1, dev); qc = E.QuantCtx(sd_vae, pns, B, dev)
+    smp = E.Sampler(ctx, qc)
+    labels = torch.from_numpy(g["labels"]).long().to(dev)
+    res = smp.plain_ar(labels, float(g["cfg"]), int(g["top_k"]), float(g["top_p"]), E.Noise("host", int(g["g_seed"])), trace=True)
+    ids = res.ids.cpu().numpy()
+    assert np.array_equal(ids, g["ids"].astype(np.int64)), _flip_report(ids, g["ids"].astype(np.int64), lad) + f" (fixture min margin {g['min_rel_margin'].min():.1e})"
+    # logits of token 0 / image 0 at every stage, after CFG, vs the reference's
+    for s in range(lad.S):
+        lg = res.trace["logits"][s].cpu()
+        cl = orc.cfg_combine(lg, B, lad.cfg_t(float(g["cfg"]), s))
+        assert (cl[0, 0].numpy() - g["cfg_logits_rows"][s][0]).__abs__().max() <= LOGIT_TOL, s
+    np.testing.assert_allclose(res.f_hat.cpu().numpy(), g["f_hat"], atol=1e-4)
+    ctx.close(); qc.close()
+
+
+def test_d16_b1_vs_reference_fixture(dev):
+    g = golden("ar_d16_256_stress_B1")
+    pns = tuple(int(p) for p in g["patch_nums"])
+    sd_var, sd_vae = state_dicts(16, pns, "stress", int(g["wseed"]))
+    ctx = E.ModelCtx(sd_var, 16, pns, 1, 1, dev); qc = E.QuantCtx(sd_vae, pns, 1, dev)
+    res = E.Sampler(ctx, qc).plain_ar(torch.from_numpy(g["labels"]).long().to(dev), 1.5, 900, 0.96, E.Noise("host", int(g["g_seed"])), trace=True)
+    ids = res.ids.cpu().numpy()
+    assert np.array_equal(ids, g["ids"].astype(np.int64)), _flip_report(ids, g["ids"].astype(np.int64), as_ladder(pns))
+    lg = res.trace["logits"][-1].cpu()
+    cl = orc.cfg_combine(lg, 1, 1.5)
+    assert np.abs(cl[:, :2].numpy() - g["cfg_logits_last_rows"]).max() <= LOGIT_TOL
+    np.testing.assert_allclose(res.f_hat.cpu().numpy(), g["f_hat"], atol=1e-4)
+    ctx.close(); qc.close()
+
+
+@pytest.fixture(scope="module")
+def pair(dev):
+    pns = LADDER_256
+    sd_d, sd_v = state_dicts(4, pns); sd_t, _ = state_dicts(6, pns)
+    B = 2
+    dc, tc, qc = E.ModelCtx(sd_d, 4, pns, B, 1, dev), E.ModelCtx(sd_t, 6, pns, B, 3, dev), E.QuantCtx(sd_v, pns, B, dev)
+    od, ot, oq = orc.OracleVAR(sd_d, 4, pns), orc.OracleVAR(sd_t, 6, pns), orc.OracleQuant(sd_v, pns)
+    yield E.Sampler(tc, qc, dc), (od, ot, oq)
+    dc.close(); tc.close(); qc.close()
+
+
+def test_chunk_verify_logits_vs_reference_fixture(dev, pair):
+    """One target forward over a gamma-chunk under the block-causal rows == the reference modules' own chunk forward
+    (fixture rows from make_golden.sd_fixture, I2)."""
+    smp, (od, ot, oq) = pair
+    g = golden("sd_components")
+    labels = torch.from_numpy(g["labels"]).long()
+    tr = orc.plain_ar(ot, oq, labels, 1.5, 900, 0.96, _noise_o(0), keep=True)
+    t, lad, B, V = smp.t, smp.lad, 2, 4096
+    for (s0, n) in ((3, 2), (5, 3), (0, 2), (8, 2)):
+        t.begin(labels.to(dev))
+        for s in range(s0):
+            x = tr.x_in[s].to(dev).contiguous()
+            t.forward(x, s, 1, smp.logits_t)
+        x = torch.cat(tr.x_in[s0:s0 + n], 1).to(dev).contiguous()
+        lsum = x.shape[1]
+        t.forward(x, s0, n, smp.logits_t)
+        lg = smp.logits_t[:2 * B * lsum * V].view(2 * B, lsum, V).cpu()
+        assert np.abs(lg[0, -1].numpy() - g[f"chunk_{s0}_{n}_row"]).max() <= LOGIT_TOL
+        want = torch.cat(tr.logits[s0:s0 + n], 1)
+        assert (lg - want).abs().max().item() <= LOGIT_TOL
+        t.kv_set_len(0)
+
+
+@pytest.mark.parametrize("mode,thr", [("natural", 0.5), ("accept_all", 0.0), ("reject_all", 2.0)])
+@pytest.mark.parametrize("gamma", [1, 2, 3])
+def test_spec_decode_vs_oracle(dev, pair, mode, thr, gamma):
+    smp, (od, ot, oq) = pair
+    g = golden("sd_components")
+    labels = torch.from_numpy(g["labels"]).long()
+    res = smp.spec_decode(labels.to(dev), 1.5, gamma, 900, 0.96, E.Noise("host", 0), thr=thr)
+    want_ids = g[f"spec_{mode}_g{gamma}_ids"].astype(np.int64)
+    ids = res.ids.cpu().numpy()
+    assert np.array_equal(ids, want_ids), _flip_report(ids, want_ids, smp.lad)
+    st = res.stats
+    assert [st["target_calls"], st["draft_stage_calls"], st["forced_accepts"], st["accepted_tokens"]] == list(g[f"spec_{mode}_g{gamma}_stats"])
+    tr = orc.spec_decode(od, ot, oq, labels, 1.5, gamma, 900, 0.96, _noise_o(0), thr=thr)
+    assert (res.f_hat.cpu() - tr.f_hat).abs().max().item() <= 1e-4
+    assert [r["n_accept"] for r in st["rounds"]] == [r["n_accept"] for r in tr.stats["rounds"]]
+    assert [r["matched"] for r in st["rounds"]] == [r["matched"] for r in tr.stats["rounds"]]
+
+
+def test_spec_invariants_identical_models_and_rollback(dev):
+    """I1: draft == target weights, top_k = 1 -> every stage accepted, ids == plain AR, ceil(S/gamma) target calls.
+    I4: a rejected round leaves no trace: reject_all ids == plain draft AR with the same draw sequence (I3)."""
+    pns = LADDER_256
+    sd, sd_v = state_dicts(4, pns)
+    B = 2
+    a, b, qc = E.ModelCtx(sd, 4, pns, B, 1, dev), E.ModelCtx(sd, 4, pns, B, 3, dev), E.QuantCtx(sd_v, pns, B, dev)
+    smp = E.Sampler(b, qc, a)
+    labels = torch.tensor([1, 2], device=dev)
+    ref = smp.plain_ar(labels, 1.5, 1, 0.0, E.Noise("host", 5)).ids.clone()
+    for gamma in (1, 2, 3):
+        res = smp.spec_decode(labels, 1.5, gamma, 1, 0.0, E.Noise("host", 5))
+        assert torch.equal(res.ids, ref)
+        assert res.stats["target_calls"] == -(-10 // gamma) and res.stats["forced_accepts"] == 0 and res.stats["accepted_tokens"] == 680
+    # reject_all with sampling noise: forced accepts only; the draws consumed are 0..n in order
+    res = smp.spec_decode(labels, 1.5, 2, 900, 0.96, E.Noise("host", 5), thr=2.0)
+    st = res.stats
+    assert st["forced_accepts"] == 10 and st["accepted_tokens"] == 0 and st["gamma_final"] == 1
+    draws = []                                                                  # draw index used by each committed stage
+    d = 0
+    for r in st["rounds"]:
+        if r["n_accept"]:
+            draws.append(d)
+        d += r["g"]
+    od, oq = orc.OracleVAR(sd, 4, pns), orc.OracleQuant(sd_v, pns)
+    seq = iter(draws)
+    tr = orc.plain_ar(od, oq, labels.cpu(), 1.5, 900, 0.96, orc.array_noise(lambda dd, B_, l, V: exponential_noise(5, draws[dd], B_, l, V)), keep=False)
+    assert np.array_equal(res.ids.cpu().numpy(), torch.cat(tr.ids, 1).numpy())
+    a.close(); b.close(); qc.close()
+
+
+def test_device_noise_run_is_reproduced_by_oracle_with_dumped_noise(dev, pair):
+    """Fast path: Philox generated inside the sampler kernel.  The oracle is fed the same stream dumped by
+    sdvar_op_noise_fill, so the in-kernel generator is tied to the portable stream definition."""
+    import ctypes as C
+    smp, (od, ot, oq) = pair
+    lib = E.load_library()
+    labels = torch.tensor([7, 500])
+    res = smp.spec_decode(labels.to(dev), 1.5, 2, 900, 0.96, E.Noise("device", 1234), thr=0.0)
+    def dumped(draw, B, l, V):
+        q = torch.empty(B * l, V, device=dev)
+        E._check(lib.sdvar_op_noise_fill(C.c_void_p(q.data_ptr()), B, l, V, 1234, draw, 0, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return q.cpu()
+    tr = orc.spec_decode(od, ot, oq, labels, 1.5, 2, 900, 0.96, dumped, thr=0.0)
+    assert np.array_equal(res.ids.cpu().numpy(), torch.cat(tr.ids, 1).numpy())
+
+
+def test_api_surface_drop_in(dev):
+    """models.build_vae_var_speculative_decoding / VAR.autoregressive_infer_cfg / SDVAR...parallel_v1 signatures."""
+    import sdvar_amd
+    vae, draft, target, sd = sdvar_amd.build_vae_var_speculative_decoding(device=dev, depth_draft=2, depth_target=4)
+    assert sd.draft_model is draft and sd.target_model is target and target.vae_proxy[0] is vae
+    assert target.patch_nums == LADDER_256 and target.L == 680 and target.num_stages_minus_1 == 9 and target.begin_ends[1] == (1, 5)
+    img = target.autoregressive_infer_cfg(B=2, label_B=torch.tensor([1, 2], device=dev), g_seed=0, cfg=1.5, top_k=900, top_p=0.96)
+    assert img.shape == (2, 3, 256, 256) and img.min().item() >= 0 and img.max().item() <= 1 and torch.isfinite(img).all()
+    ids1 = target.last_result.ids.clone()
+    img2 = target.autoregressive_infer_cfg(B=2, label_B=torch.tensor([1, 2], device=dev), g_seed=0, cfg=1.5, top_k=900, top_p=0.96)
+    assert torch.equal(ids1, target.last_result.ids) and torch.equal(img, img2)                      # same seed -> same image
+    img3 = sd.sdvar_autoregressive_infer_cfg_parallel_v1(B=2, label_B=3, g_seed=1, cfg=1.5, gamma=2, top_k=900, top_p=0.96)
+    assert img3.shape == (2, 3, 256, 256) and torch.isfinite(img3).all()
+    assert sd.last_result.stats["target_calls"] >= 5
+    for blk in target.blocks: blk.attn.kv_caching(False)
+    img4 = draft.autoregressive_infer_cfg(B=1, label_B=None, g_seed=3)
+    assert img4.shape == (1, 3, 256, 256)
+    with pytest.raises(NotImplementedError):
+        target.autoregressive_infer_cfg(B=1, label_B=0, more_smooth=True)

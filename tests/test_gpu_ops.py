@@ -1,0 +1,265 @@
+"""GPU: every HIP kernel, called through the C ABI, against the oracle / torch fp32 on the same seeded inputs."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import golden, rnd, state_dicts
+from oracle import var_oracle as orc
+from sdvar_amd import engine as E
+from sdvar_amd.ladder import LADDER_256, LADDER_512, as_ladder, bicubic_up_matrix, area_down_matrix
+from sdvar_amd.noise import exponential_noise
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+def _st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+@pytest.mark.parametrize("M,N,K", [(16, 768, 256), (1, 128, 32), (33, 384, 1024), (64, 3072, 1024), (100, 1024, 4096), (400, 1152, 384),
+                                   (576, 4096, 1024), (1600, 1024, 1024), (4096, 256, 1024), (130, 192, 64)])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_gemm_epilogues(dev, M, N, K, epi):
+    lib = E.load_library()
+    X, W, b = rnd(1, (M, K)).to(dev), rnd(2, (N, K), 1 / math.sqrt(K)).to(dev), rnd(3, (N,)).to(dev)
+    rows_per_gate = 7 if M > 7 else 1
+    R = (M + rows_per_gate - 1) // rows_per_gate
+    res, gate = rnd(4, (M, N)).to(dev), rnd(5, (R, 2 * N)).to(dev)
+    out = res.clone() if epi == 2 else torch.empty(M, N, device=dev)
+    E._check(lib.sdvar_op_gemm(_p(X), K, _p(W), _p(b), _p(out), N, M, N, K, epi, _p(out) if epi == 2 else None, N, _p(gate) if epi == 2 else None,
+                               rows_per_gate, 2 * N, _st()))
+    ref = X.double() @ W.double().t() + b.double()
+    if epi == 1:
+        ref = F.gelu(ref, approximate="tanh")
+    if epi == 2:
+        g = gate[:, :N].double().repeat_interleave(rows_per_gate, 0)[:M]
+        ref = res.double() + ref * g
+    err = (out.double() - ref).abs().max().item()
+    assert err <= 2e-5 * max(1.0, ref.abs().max().item()), err
+    # against torch fp32 on the same device as a second opinion on scale
+    assert torch.isfinite(out).all()
+
+
+def test_gemm_is_deterministic(dev):
+    lib = E.load_library()
+    X, W = rnd(1, (576, 1024)).to(dev), rnd(2, (3072, 1024), 0.03).to(dev)
+    outs = []
+    for _ in range(2):
+        o = torch.empty(576, 3072, device=dev)
+        E._check(lib.sdvar_op_gemm(_p(X), 1024, _p(W), None, _p(o), 3072, 576, 3072, 1024, 0, None, 0, None, 1, 0, _st()))
+        outs.append(o)
+    assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("rows,Cw,rpi", [(5, 256, 5), (64, 1024, 16), (41, 384, 41), (18, 1920, 9), (7, 768, 1)])
+def test_ln_modulate(dev, rows, Cw, rpi):
+    lib = E.load_library()
+    x = rnd(1, (rows, Cw), 2.0).to(dev) + 0.3
+    R = (rows + rpi - 1) // rpi
+    mod = rnd(2, (R, 6 * Cw)).to(dev)
+    out = torch.empty_like(x)
+    E._check(lib.sdvar_op_ln_modulate(_p(x), C_void(mod, 2 * Cw), C_void(mod, 4 * Cw), _p(out), rows, Cw, rpi, 6 * Cw, _st()))
+    sc = mod[:, 2 * Cw:3 * Cw].repeat_interleave(rpi, 0)[:rows]; sh = mod[:, 4 * Cw:5 * Cw].repeat_interleave(rpi, 0)[:rows]
+    ref = F.layer_norm(x.cpu(), (Cw,), eps=1e-6).mul(sc.cpu().add(1)).add_(sh.cpu())
+    assert (out.cpu() - ref).abs().max().item() <= 2e-5
+
+
+def C_void(t, off_elems):
+    return C.c_void_p(t.data_ptr() + 4 * off_elems)
+
+
+@pytest.mark.parametrize("R,l,H,pos0", [(2, 1, 4, 0), (4, 9, 6, 5), (2, 36, 16, 55), (16, 4, 12, 1)])
+def test_qk_norm_append(dev, R, l, H, pos0):
+    lib = E.load_library()
+    Cw, Lmax = 64 * H, pos0 + l + 3
+    qkv = rnd(1, (R * l, 3 * Cw)).to(dev)
+    sm = (rnd(2, (H,), 0.5) + math.log(4.0)); sm[0] = 6.0                       # one head above the ln(100) clamp
+    sm = sm.to(dev)
+    qo = torch.zeros(R, H, l, 64, device=dev); kc = torch.zeros(R, H, Lmax, 64, device=dev); vc = torch.zeros_like(kc)
+    E._check(lib.sdvar_op_qk_norm_append(_p(qkv), _p(sm), _p(qo), _p(kc), _p(vc), R, l, H, Lmax, pos0, _st()))
+    q, k, v = qkv.cpu().view(R, l, 3, H, 64).permute(2, 0, 3, 1, 4).unbind(0)
+    scale = sm.cpu().view(1, H, 1, 1).clamp_max(math.log(100.0)).exp()
+    assert (qo.cpu() - F.normalize(q, dim=-1).mul(scale)).abs().max().item() <= 2e-5
+    assert (kc.cpu()[:, :, pos0:pos0 + l] - F.normalize(k, dim=-1)).abs().max().item() <= 1e-6
+    assert torch.equal(vc.cpu()[:, :, pos0:pos0 + l], v)
+    assert kc[:, :, :pos0].abs().max().item() == 0 if pos0 else True           # nothing outside the appended window
+    assert kc[:, :, pos0 + l:].abs().max().item() == 0
+
+
+def _attn_ref(q, k, v, qbeg, vis):
+    l, K = q.shape[2], k.shape[2]
+    mask = torch.zeros(l, K)
+    for j in range(len(qbeg)):
+        e = qbeg[j + 1] if j + 1 < len(qbeg) else l
+        mask[qbeg[j]:e, vis[j]:] = -torch.inf
+    return F.scaled_dot_product_attention(q.double(), k.double(), v.double(), attn_mask=mask.double().view(1, 1, l, K), scale=1.0)
+
+
+@pytest.mark.parametrize("R,H,lens,prefix", [(2, 4, [1], 0), (2, 2, [4], 1), (4, 3, [25], 30), (2, 4, [100], 155), (2, 16, [256], 424),
+                                             (2, 4, [9, 16], 5), (2, 3, [64, 100, 169], 91), (2, 2, [1, 4], 0), (1, 2, [169, 256], 255), (2, 2, [324], 640)])
+def test_attention_matches_sdpa_with_block_causal_rows(dev, R, H, lens, prefix):
+    lib = E.load_library()
+    l = sum(lens); Ktot = prefix + l; Lmax = Ktot + 5
+    q = (F.normalize(rnd(1, (R, H, l, 64)), dim=-1) * 4.0).to(dev)
+    kc = torch.full((R, H, Lmax, 64), float("nan"), device=dev); vc = torch.full_like(kc, float("nan"))   # unread tail must not leak
+    kc[:, :, :Ktot] = F.normalize(rnd(2, (R, H, Ktot, 64)), dim=-1).to(dev); vc[:, :, :Ktot] = rnd(3, (R, H, Ktot, 64)).to(dev)
+    qbeg = [int(sum(lens[:j])) for j in range(len(lens))]
+    vis = [prefix + int(sum(lens[:j + 1])) for j in range(len(lens))]
+    out = torch.empty(R, l, H * 64, device=dev)
+    n = len(lens)
+    E._check(lib.sdvar_op_attention(_p(q), _p(kc), _p(vc), _p(out), R, H, l, Lmax, Ktot, n, (C.c_int32 * n)(*qbeg), (C.c_int32 * n)(*vis), _st()))
+    ref = _attn_ref(q.cpu(), kc.cpu()[:, :, :Ktot], vc.cpu()[:, :, :Ktot], qbeg, vis).transpose(1, 2).reshape(R, l, H * 64)
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err <= 2e-5, err
+
+
+def test_attention_forced_online_rescale(dev):
+    """A key far above the rest late in the cache forces the running max to jump (rule 26 of the CDNA guide)."""
+    lib = E.load_library()
+    R, H, l, Ktot = 1, 1, 40, 300
+    q = F.normalize(rnd(1, (R, H, l, 64)), dim=-1) * 50.0
+    k = F.normalize(rnd(2, (R, H, Ktot, 64)), dim=-1)
+    k[0, 0, 200] = q[0, 0, 3] / 50.0
+    k[0, 0, 299] = q[0, 0, 17] / 50.0
+    v = rnd(3, (R, H, Ktot, 64))
+    out = torch.empty(R, l, 64, device=dev)
+    E._check(lib.sdvar_op_attention(_p(q.to(dev)), _p(k.to(dev).contiguous()), _p(v.to(dev)), _p(out), R, H, l, Ktot, Ktot, 1, (C.c_int32 * 1)(0), (C.c_int32 * 1)(Ktot), _st()))
+    ref = _attn_ref(q, k, v, [0], [Ktot]).transpose(1, 2).reshape(R, l, 64)
+    assert (out.cpu().double() - ref).abs().max().item() <= 2e-5
+
+
+def test_noise_fill_matches_host_stream(dev):
+    lib = E.load_library()
+    B, l, V = 3, 7, 4096
+    q = torch.empty(B * l, V, device=dev)
+    E._check(lib.sdvar_op_noise_fill(_p(q), B, l, V, 0x1234567890ABCDEF, 5, 11, _st()))
+    host = torch.from_numpy(exponential_noise(0x1234567890ABCDEF, 5, B, l, V, image_offset=11)).view(B * l, V)
+    rel = ((q.cpu() - host).abs() / host).max().item()
+    assert rel <= 5e-6, rel                                                    # same uniforms; logf vs float64 log
+
+
+def _sampler_inputs(ci, scale):
+    rng = np.random.Generator(np.random.Philox(key=[11, 22]))
+    lg = None
+    for c in range(ci + 1):                                                    # same draw sequence as make_golden.sampler_fixture
+        lg = torch.from_numpy(rng.standard_normal(size=(2, 5, 4096), dtype=np.float32) * np.float32(golden("sampler_cases")["scale"][c]))
+    if ci == 2:
+        srt = lg.sort(-1, descending=True)[0]
+        lg[lg == srt[..., 899:900]] = 0.0
+        lg[..., :7] = srt[..., 899:900]
+    return lg
+
+
+def test_cfg_sample_reference_known_answers(dev):
+    """helpers.py:6-19 fixtures (ties at the k-th value, top-k/top-p on and off): ids and the surviving set are exact."""
+    g = golden("sampler_cases")
+    B, l, V = 2, 5, 4096
+    for ci in range(len(g["top_k"])):
+        lg = _sampler_inputs(ci, g["scale"][ci])
+        q = torch.from_numpy(exponential_noise(77, ci, B, l, V)).view(-1, V).to(dev)
+        logits2 = torch.cat([lg, torch.zeros_like(lg)], 0).to(dev).contiguous()         # t = 0 -> CFG is the identity on the cond rows
+        ids = torch.zeros(B, l, dtype=torch.int64, device=dev); dbg = torch.empty(B, l, V, device=dev)
+        E.cfg_sample(logits2, B, l, V, 0.0, int(g["top_k"][ci]), float(g["top_p"][ci]), q, 0, 0, 0, ids, 0, l, dbg)
+        assert np.array_equal(ids.cpu().numpy(), g["ids"][ci]), f"case {ci}"
+        assert np.array_equal((~torch.isinf(dbg)).sum(-1).cpu().numpy(), g["n_keep"][ci]), f"case {ci} surviving set"
+
+
+@pytest.mark.parametrize("B,l,t,tk,tp", [(2, 16, 0.75, 900, 0.96), (8, 64, 1.5, 0, 0.9), (3, 5, 0.0, 40, 0.0), (1, 256, 1.3333, 900, 0.96), (2, 9, 0.5, 0, 0.0)])
+def test_cfg_sample_vs_oracle(dev, B, l, t, tk, tp):
+    V = 4096
+    lg = rnd(7, (2 * B, l, V), 2.5)
+    q = torch.from_numpy(exponential_noise(3, 1, B, l, V)).view(-1, V)
+    ids_o, masked_o = orc.sample_topk_topp(orc.cfg_combine(lg, B, t), tk, tp, q)
+    ids = torch.zeros(B, 1000, dtype=torch.int64, device=dev); dbg = torch.empty(B, l, V, device=dev)
+    E.cfg_sample(lg.to(dev), B, l, V, t, tk, tp, q.to(dev), 0, 0, 0, ids, 100, 1000, dbg)
+    assert torch.equal(dbg.cpu(), masked_o), "masked CFG logits must be bit-identical (same roundings as torch)"
+    assert torch.equal(ids.cpu()[:, 100:100 + l], ids_o)
+    assert ids[:, :100].abs().sum().item() == 0 and ids[:, 100 + l:].abs().sum().item() == 0
+
+
+def test_cfg_sample_device_noise_equals_explicit_noise(dev):
+    lib = E.load_library()
+    B, l, V = 4, 25, 4096
+    lg = rnd(9, (2 * B, l, V), 2.0).to(dev)
+    q = torch.empty(B * l, V, device=dev)
+    E._check(lib.sdvar_op_noise_fill(_p(q), B, l, V, 99, 3, 8, _st()))
+    a = torch.zeros(B, l, dtype=torch.int64, device=dev); b = torch.zeros_like(a)
+    E.cfg_sample(lg, B, l, V, 0.9, 900, 0.96, None, 99, 3, 8, a, 0, l)
+    E.cfg_sample(lg, B, l, V, 0.9, 900, 0.96, q, 0, 0, 0, b, 0, l)
+    assert torch.equal(a, b)
+
+
+def test_verify_accept_known_answers(dev):
+    """basic_token_matching fixtures (var.py:1160-1227): accepted stages and match counts are exact."""
+    g = golden("sd_components")
+    kat = g["accept_kat"]
+    pns = LADDER_256
+    rng = np.random.Generator(np.random.Philox(key=[9, 9]))
+    B, V = 2, 4096
+    fr = [[1.0, 1.0, 1.0], [1.0, 0.52, 0.2], [0.5, 0.5, 0.49], [0.49, 1.0, 1.0], [1.0, 1.0, 0.0], [0.75, 0.5, 0.5]]
+    for case in range(6):
+        toks, lgs = [], []
+        for j in range(3):
+            n = pns[4 + j] ** 2
+            lg = torch.from_numpy(rng.standard_normal(size=(B, n, V), dtype=np.float32))
+            flat = lg.argmax(-1).reshape(-1).clone()
+            k = int(round(fr[case][j] * B * n))
+            wrong = (flat + 1) % V
+            flat[k:] = wrong[k:]
+            toks.append(flat.view(B, n)); lgs.append(lg)
+        lens = [t.shape[1] for t in toks]
+        cond = torch.cat(lgs, 1)
+        logits2 = torch.cat([cond, torch.zeros_like(cond)], 0).to(dev).contiguous()
+        ids = torch.cat(toks, 1).to(dev).contiguous()
+        counts = torch.zeros(40, dtype=torch.int32, device=dev)
+        E.verify_accept(logits2, B, lens, V, [0.0, 0.0, 0.0], ids, 0, ids.shape[1], 0.5, counts)
+        c = counts.cpu().tolist()
+        assert [c[16]] + c[:3] + c[17:20] == list(kat[case]), case
+
+
+def test_verify_accept_cfg_per_stage_vs_oracle(dev):
+    B, V, lens, ts = 3, 4096, [4, 9, 16], [0.3, 0.45, 0.6]
+    lg = rnd(21, (2 * B, sum(lens), V), 2.0)
+    cls, off = [], 0
+    for n, t in zip(lens, ts):
+        cls.append(orc.cfg_combine(lg[:, off:off + n], B, t)); off += n
+    am = torch.cat([c.argmax(-1) for c in cls], 1)
+    ids = am.clone(); ids[0, 5:] = (ids[0, 5:] + 3) % V
+    n_o, matched, total = orc.accept_scan([ids[:, :4], ids[:, 4:13], ids[:, 13:]], cls, 0.5)
+    counts = torch.zeros(40, dtype=torch.int32, device=dev); amx = torch.zeros(B, sum(lens), dtype=torch.int64, device=dev)
+    E.verify_accept(lg.to(dev), B, lens, V, ts, ids.to(dev), 0, ids.shape[1], 0.5, counts, amx)
+    c = counts.cpu().tolist()
+    assert torch.equal(amx.cpu(), am)
+    assert c[16] == n_o and c[:3] == matched and c[17:20] == total
+
+
+@pytest.mark.parametrize("lname,pns", [("256", LADDER_256), ("512", LADDER_512)])
+def test_quant_next_vs_reference_fixture_and_oracle(dev, lname, pns):
+    g = golden("quant_" + lname)
+    _, sd_vae = state_dicts(2, pns, "stress", 1234)
+    oq = orc.OracleQuant(sd_vae, pns)
+    qc = E.QuantCtx(sd_vae, pns, 2, dev)
+    B, L = 2, sum(p * p for p in pns)
+    ids_all = torch.from_numpy(g["ids"].astype(np.int64)).to(dev).contiguous()
+    f = torch.zeros(B, 32, pns[-1], pns[-1], device=dev); f_o = torch.zeros(B, 32, pns[-1], pns[-1])
+    off = 0
+    for si, pn in enumerate(pns):
+        last = si == len(pns) - 1
+        nxt = None if last else torch.empty(B, pns[si + 1] ** 2, 32, device=dev)
+        qc.next(si, ids_all[:, off:], L, f, nxt, B)
+        f_o, nxt_o = oq.next_input(si, f_o, oq.embed_ids(ids_all[:, off:off + pn * pn].cpu(), pn))
+        off += pn * pn
+        assert (f.cpu() - f_o).abs().max().item() <= 2e-5, si
+        if not last:
+            want = nxt_o.view(B, 32, -1).transpose(1, 2)
+            assert (nxt.cpu() - want).abs().max().item() <= 2e-5, si
+    np.testing.assert_allclose(f.cpu().numpy(), g["f_hat"], atol=3e-5)         # the reference's own f_hat
