@@ -341,11 +341,14 @@ int sdvar_quant_create(int32_t S, const int32_t* patch_nums, int32_t cvae, int32
     q->hWup.resize(S); q->hWdn.resize(S);
     for (int s = 0; s < S; ++s) {
         // Phi choice: argmin |ticks - s/(S-1)| (quant.py:223-226); ticks = linspace(1/3/K, 1-1/3/K, K) for K == 4 else the 1/2/K form
+        // evaluated exactly like numpy.linspace (k*step + start, last tick = stop) so that the tie at s/(S-1) = 7/9
+        // between ticks 2 and 3 resolves as in the reference
         int best = 0; double bd = 1e30;
+        const double lo = (n_phi == 4) ? 1.0 / 3 / n_phi : 1.0 / 2 / n_phi, hi = 1.0 - lo;
+        const double step = (n_phi > 1) ? (hi - lo) / (n_phi - 1) : 0.0;
+        const double at = (S > 1) ? (double)s / (S - 1) : 0.0;
         for (int k = 0; k < n_phi; ++k) {
-            const double lo = (n_phi == 4) ? 1.0 / 3 / n_phi : 1.0 / 2 / n_phi, hi = 1.0 - lo;
-            const double tick = (n_phi == 1) ? lo : lo + (hi - lo) * k / (n_phi - 1);
-            const double at = (S > 1) ? (double)s / (S - 1) : 0.0;
+            const double tick = (k == n_phi - 1 && n_phi > 1) ? hi : (double)k * step + lo;
             const double dd = fabs(tick - at);
             if (dd < bd) { bd = dd; best = k; }
         }

@@ -40,7 +40,13 @@ def test_plain_ar_vs_reference_fixture(dev, name):
     labels = torch.from_numpy(g["labels"]).long().to(dev)
     res = smp.plain_ar(labels, float(g["cfg"]), int(g["top_k"]), float(g["top_p"]), E.Noise("host", int(g["g_seed"])), trace=True)
     ids = res.ids.cpu().numpy()
-    assert np.array_equal(ids, g["ids"].astype(np.int64)), _flip_report(ids, g["ids"].astype(np.int64), lad) + f" (fixture min margin {g['min_rel_margin'].min():.1e})"
+    # diagnostic: per-stage logits error of the HIP path against the oracle fed with the HIP path's own inputs
+    tr = orc.plain_ar(orc.OracleVAR(sd_var, depth, pns), orc.OracleQuant(sd_vae, pns), labels.cpu(), float(g["cfg"]), int(g["top_k"]), float(g["top_p"]),
+                      _noise_o(int(g["g_seed"])), keep=True)
+    errs = [float((res.trace["logits"][s].cpu() - tr.logits[s]).abs().max()) for s in range(lad.S)]
+    msg = _flip_report(ids, g["ids"].astype(np.int64), lad) + f" (fixture min margin {g['min_rel_margin'].min():.1e}); per-stage max|dlogit| vs oracle {['%.1e' % e for e in errs]}"
+    assert np.array_equal(ids, g["ids"].astype(np.int64)), msg
+    assert max(errs) <= LOGIT_TOL, msg
     # logits of token 0 / image 0 at every stage, after CFG, vs the reference's
     for s in range(lad.S):
         lg = res.trace["logits"][s].cpu()
@@ -174,7 +180,8 @@ def test_api_surface_drop_in(dev):
     assert img.shape == (2, 3, 256, 256) and img.min().item() >= 0 and img.max().item() <= 1 and torch.isfinite(img).all()
     ids1 = target.last_result.ids.clone()
     img2 = target.autoregressive_infer_cfg(B=2, label_B=torch.tensor([1, 2], device=dev), g_seed=0, cfg=1.5, top_k=900, top_p=0.96)
-    assert torch.equal(ids1, target.last_result.ids) and torch.equal(img, img2)                      # same seed -> same image
+    assert torch.equal(ids1, target.last_result.ids)                                                 # same seed -> same tokens
+    assert (img - img2).abs().max().item() <= 1e-4                                                   # MIOpen conv algorithms are not bitwise repeatable
     img3 = sd.sdvar_autoregressive_infer_cfg_parallel_v1(B=2, label_B=3, g_seed=1, cfg=1.5, gamma=2, top_k=900, top_p=0.96)
     assert img3.shape == (2, 3, 256, 256) and torch.isfinite(img3).all()
     assert sd.last_result.stats["target_calls"] >= 5

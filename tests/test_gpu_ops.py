@@ -132,7 +132,8 @@ def test_attention_forced_online_rescale(dev):
     k[0, 0, 299] = q[0, 0, 17] / 50.0
     v = rnd(3, (R, H, Ktot, 64))
     out = torch.empty(R, l, 64, device=dev)
-    E._check(lib.sdvar_op_attention(_p(q.to(dev)), _p(k.to(dev).contiguous()), _p(v.to(dev)), _p(out), R, H, l, Ktot, Ktot, 1, (C.c_int32 * 1)(0), (C.c_int32 * 1)(Ktot), _st()))
+    qd, kd, vd = q.to(dev), k.to(dev).contiguous(), v.to(dev)                  # keep the device copies alive across the call
+    E._check(lib.sdvar_op_attention(_p(qd), _p(kd), _p(vd), _p(out), R, H, l, Ktot, Ktot, 1, (C.c_int32 * 1)(0), (C.c_int32 * 1)(Ktot), _st()))
     ref = _attn_ref(q, k, v, [0], [Ktot]).transpose(1, 2).reshape(R, l, 64)
     assert (out.cpu().double() - ref).abs().max().item() <= 2e-5
 
