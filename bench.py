@@ -22,6 +22,26 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+T_START = time.perf_counter()
+
+
+def log(msg):
+    print(f"[bench +{time.perf_counter() - T_START:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def host_cores():
+    """Usable host threads: the affinity mask, capped by the cgroup CPU quota when there is one (a 1-GPU box gets a
+    16-CPU share of a much larger host; sizing OpenMP to os.cpu_count() there oversubscribes by an order of magnitude)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("SDVAR_CPU_THREADS", 16))))
+
+
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0             # same guide, HBM3E spec
 
@@ -38,6 +58,7 @@ def main():
     ap.add_argument("--mode", default="natural", choices=["natural", "accept_all", "reject_all"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-modes", action="store_true")
+    ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark for the VQVAE decoder convs")
     args = ap.parse_args()
 
     from sdvar_amd import dist as D
@@ -51,9 +72,11 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     torch.set_grad_enabled(False)
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)
     pns, B, lad = LADDER_256, args.batch, as_ladder(LADDER_256)
     thr = {"natural": 0.5, "accept_all": 0.0, "reject_all": 2.0}
 
+    log(f"rank {rank}/{world} on {torch.cuda.get_device_name(dev)}; host cpu_count={os.cpu_count()} affinity={len(os.sched_getaffinity(0))} usable={host_cores()}")
     sd_d = var_state_dict_device(args.depth_draft, pns, dev, seed=1234)
     sd_t = var_state_dict_device(args.depth_target, pns, dev, seed=1234)
     sd_v = vae_state_dict(pns, "perf", 1234, with_encoder=False)
@@ -63,6 +86,7 @@ def main():
     tc = E.ModelCtx(sd_t, args.depth_target, pns, B, max(args.gamma, 1), dev)
     qc = E.QuantCtx(sd_v, pns, B, dev)
     smp = E.Sampler(tc, qc, dc)
+    log("models bound, buffers allocated")
     lo, _ = D.shard_range(B * world, rank, world)
     labels = ((torch.arange(B) + lo) % 1000).to(dev)
 
@@ -88,6 +112,7 @@ def main():
 
     dt, agg = timed(args.mode, args.steps, args.warmup)
     value = agg["images"] / dt
+    log(f"timed region: {dt:.3f}s for {args.steps} steps -> {value:.2f} images/s")
 
     # no-decode rate (sampler only), same mode, shorter
     def timed_nodecode(steps):
@@ -98,6 +123,7 @@ def main():
         return D.max_over_ranks(time.perf_counter() - t0, dev)
     nd_steps = max(2, args.steps // 2)
     dt_nd = timed_nodecode(nd_steps)
+    log(f"no-decode: {B * world * nd_steps / dt_nd:.2f} images/s")
 
     extra = {}
     if not args.no_extra_modes:
@@ -105,6 +131,7 @@ def main():
             if m == args.mode:
                 continue
             d2, a2 = timed(m, max(2, args.steps // 3), 1)
+            log(f"mode {m}: {a2['images'] / d2:.2f} images/s")
             extra[m] = dict(images_per_s=a2["images"] / d2, mean_accepted_tokens_per_step=a2["mean_accepted_tokens_per_step"],
                             target_calls_per_image_batch=a2["target_calls"] / max(1, a2["images"] // B))
 
@@ -128,6 +155,7 @@ def main():
     roofline = roof(dom)
     roofline_attn = roof("attention") if "attention" in classes else None
     class_ms = {k: round(v["ms"], 3) for k, v in classes.items()}
+    log(f"profiled step: {class_ms}")
 
     out = {
         "metric": "images/s (+ mean accepted tokens/step), VAR-d16 256^2 B=8 per GPU, d12 draft + d16 verify",
@@ -145,14 +173,16 @@ def main():
     # ---- CPU baseline (rank 0, N=1): the oracle's plain AR of the TARGET model on the host cores
     if world == 1 and not args.no_cpu_baseline:
         from oracle import var_oracle as orc
-        cores = os.cpu_count() or 1
+        cores = host_cores()
         torch.set_num_threads(cores)
+        log(f"cpu baseline on {cores} threads ...")
         sd_cpu = {k: v.cpu() for k, v in sd_t.items()}
         model, quant = orc.OracleVAR(sd_cpu, args.depth_target, pns), orc.OracleQuant(sd_v, pns)
         g = torch.Generator(); g.manual_seed(0)
         t0 = time.perf_counter()
         tr = orc.plain_ar(model, quant, labels.cpu(), 1.5, 900, 0.96, orc.torch_noise(g), keep=False)
         t_ar = time.perf_counter() - t0
+        log(f"cpu baseline AR done in {t_ar:.1f}s")
         orc.decode_image(sd_v, tr.f_hat)
         t_all = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": B / t_all, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",

@@ -12,6 +12,11 @@
 //   the 4 k of one ds_read_b128 feed 4 MFMAs: lane (i, h) supplies k = 8c + 4h + e for MFMA e of chunk c on BOTH
 //   operands, i.e. the K order inside a tile is permuted identically for X and W (sum unchanged, order fixed).
 //   Output: lane holds column n = lane & 31 of 16 rows -> 128-byte row segments per store instruction.
+// Split-K: the sampler's GEMMs have M = 2B * (tokens of the stage) = 16 .. 4096 rows and N as small as C, so most
+//   launches have far fewer output tiles than the 256 CUs and a single workgroup walking all of K is latency-bound
+//   (measured: 116 us for any grid of 8..200 workgroups at K = 4096).  When tiles < ~256 the K range is cut into
+//   `split` slices (grid = tiles x split), each slice stores its raw fp32 partial tile into a workspace slab, and
+//   splitk_reduce_kernel sums the slabs in slice order (deterministic, no atomics) and applies the epilogue.
 // Epilogues (fused, the reference's elementwise ops around each linear):
 //   EPI_BIAS        out = acc + bias
 //   EPI_BIAS_GELU   out = gelu_tanh(acc + bias)                         (basic_var.py:40,52)
@@ -20,7 +25,7 @@
 
 namespace sdvar {
 
-enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_GATED_RES = 2 };
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_GATED_RES = 2, EPI_PARTIAL = 3 };
 
 constexpr int BK = 32;
 constexpr int LDS_STRIDE = BK + 4;   // floats
@@ -37,6 +42,7 @@ struct GemmArgs {
     const float* res; const float* gate;
     int M, N, K, ldx, ldo, ldres;
     int rows_per_gate, gate_stride;
+    int split, k_per_split;     // split-K: slice ks covers K-tiles [ks*k_per_split, ...) and writes slab ks of `out`
 };
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
@@ -51,7 +57,9 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(GemmArgs a) {
     constexpr int STAGE = (BM + BN) * LDS_STRIDE;           // floats per pipeline stage: X tile then W tile
 
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
-    const int lid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int ntile = tiles_m * tiles_n;
+    const int ks = blockIdx.x / ntile;                      // K slice (0 when not split)
+    const int lid = xcd_remap(blockIdx.x - ks * ntile, ntile);
     const int tm = lid % tiles_m, tn = lid / tiles_m;       // m fastest: neighbours share the W panel
     const int m0 = tm * BM, n0 = tn * BN;
 
@@ -90,13 +98,14 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(GemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = a.K / BK;
-    load_tile(0);
+    const int kt0 = ks * a.k_per_split;
+    const int nk = min(a.K / BK - kt0, a.k_per_split);
+    load_tile(kt0 * BK);
     store_tile(0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile((kt + 1) * BK);
+        if (kt + 1 < nk) load_tile((kt0 + kt + 1) * BK);
         const float* px = smem + buf * STAGE + (wm * WM + li) * LDS_STRIDE + 4 * lh;
         const float* pw = smem + buf * STAGE + (BM + wn * WN + li) * LDS_STRIDE + 4 * lh;
 #pragma unroll
@@ -123,7 +132,8 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(GemmArgs a) {
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * WN + j * 32 + li;
         if (n >= a.N) continue;
-        const float bv = a.bias ? a.bias[n] : 0.f;
+        const float bv = (EPI != EPI_PARTIAL && a.bias) ? a.bias[n] : 0.f;
+        float* outp = (EPI == EPI_PARTIAL) ? a.out + (size_t)ks * a.M * a.ldo : a.out;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -136,24 +146,71 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(GemmArgs a) {
                     const float g = a.gate[(size_t)(m / a.rows_per_gate) * a.gate_stride + n];
                     v = a.res[(size_t)m * a.ldres + n] + v * g;
                 }
-                a.out[(size_t)m * a.ldo + n] = v;
+                outp[(size_t)m * a.ldo + n] = v;
             }
         }
     }
 }
 
+// out = epi( sum_s ws[s] + bias ), 4 columns per thread, slabs summed in slice order
+template <int EPI>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int split, const float* __restrict__ bias, float* out,
+                                                            const float* res, const float* __restrict__ gate, int M, int N, int ldo, int ldres,
+                                                            int rows_per_gate, int gate_stride) {
+    const int nv = N >> 2;
+    const size_t total = (size_t)M * nv, slab = (size_t)M * N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / nv), n = (int)(i % nv) * 4;
+        f32x4 acc = *reinterpret_cast<const f32x4*>(ws + (size_t)m * N + n);
+        for (int s = 1; s < split; ++s) {
+            const f32x4 p = *reinterpret_cast<const f32x4*>(ws + s * slab + (size_t)m * N + n);
+            acc[0] += p[0]; acc[1] += p[1]; acc[2] += p[2]; acc[3] += p[3];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = acc[e] + (bias ? bias[n + e] : 0.f);
+            if (EPI == EPI_BIAS_GELU) v = gelu_tanh(v);
+            if (EPI == EPI_GATED_RES) v = res[(size_t)m * ldres + n + e] + v * gate[(size_t)(m / rows_per_gate) * gate_stride + n + e];
+            out[(size_t)m * ldo + n + e] = v;
+        }
+    }
+}
+
+static float* g_ws = nullptr;                      // split-K slabs; one stream at a time per process (see sdvar_hip.h)
+constexpr size_t WS_FLOATS = (size_t)24 << 20;     // 96 MiB
+
 template <int BM, int BN, int WAVES_M, int WAVES_N>
-static int launch_cfg(const GemmArgs& a, int epi, hipStream_t stream) {
+static int launch_cfg(GemmArgs a, int epi, int split, hipStream_t stream) {
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     const size_t lds = 2 * (size_t)(BM + BN) * LDS_STRIDE * sizeof(float);
-    dim3 grid(tiles), block(256);
+    dim3 block(256);
     static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in once per kernel
     if (!attr_set) {
         SDVAR_HIP(hipFuncSetAttribute((const void*)gemm_f32_nt_kernel<BM, BN, WAVES_M, WAVES_N, EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         SDVAR_HIP(hipFuncSetAttribute((const void*)gemm_f32_nt_kernel<BM, BN, WAVES_M, WAVES_N, EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         SDVAR_HIP(hipFuncSetAttribute((const void*)gemm_f32_nt_kernel<BM, BN, WAVES_M, WAVES_N, EPI_GATED_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SDVAR_HIP(hipFuncSetAttribute((const void*)gemm_f32_nt_kernel<BM, BN, WAVES_M, WAVES_N, EPI_PARTIAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
+    const int nkt = a.K / BK;
+    if (split > 1) {
+        if (!g_ws) SDVAR_HIP(hipMalloc((void**)&g_ws, WS_FLOATS * sizeof(float)));
+        GemmArgs p = a;
+        p.out = g_ws; p.ldo = a.N; p.split = split; p.k_per_split = (nkt + split - 1) / split;
+        hipLaunchKernelGGL((gemm_f32_nt_kernel<BM, BN, WAVES_M, WAVES_N, EPI_PARTIAL>), dim3(tiles * split), block, lds, stream, p);
+        SDVAR_LAUNCH_CHECK();
+        const size_t total = (size_t)a.M * (a.N / 4);
+        const int rgrid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+        switch (epi) {
+            case EPI_BIAS: hipLaunchKernelGGL(splitk_reduce_kernel<EPI_BIAS>, dim3(rgrid), block, 0, stream, g_ws, split, a.bias, a.out, a.res, a.gate, a.M, a.N, a.ldo, a.ldres, a.rows_per_gate, a.gate_stride); break;
+            case EPI_BIAS_GELU: hipLaunchKernelGGL(splitk_reduce_kernel<EPI_BIAS_GELU>, dim3(rgrid), block, 0, stream, g_ws, split, a.bias, a.out, a.res, a.gate, a.M, a.N, a.ldo, a.ldres, a.rows_per_gate, a.gate_stride); break;
+            default: hipLaunchKernelGGL(splitk_reduce_kernel<EPI_GATED_RES>, dim3(rgrid), block, 0, stream, g_ws, split, a.bias, a.out, a.res, a.gate, a.M, a.N, a.ldo, a.ldres, a.rows_per_gate, a.gate_stride); break;
+        }
+        SDVAR_LAUNCH_CHECK();
+        return SDVAR_OK;
+    }
+    a.split = 1; a.k_per_split = nkt;
+    dim3 grid(tiles);
     switch (epi) {
         case EPI_BIAS: hipLaunchKernelGGL((gemm_f32_nt_kernel<BM, BN, WAVES_M, WAVES_N, EPI_BIAS>), grid, block, lds, stream, a); break;
         case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_f32_nt_kernel<BM, BN, WAVES_M, WAVES_N, EPI_BIAS_GELU>), grid, block, lds, stream, a); break;
@@ -171,11 +228,31 @@ int gemm_f32_nt(const float* X, int ldx, const float* W, const float* bias, floa
     SDVAR_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % BK == 0, "gemm: need K %% 32 == 0 (M=%d N=%d K=%d)", M, N, K);
     SDVAR_CHECK_ARG(ldx >= K && ldx % 4 == 0 && ldo >= N, "gemm: bad leading dims ldx=%d ldo=%d", ldx, ldo);
     SDVAR_CHECK_ARG(((uintptr_t)X % 16) == 0 && ((uintptr_t)W % 16) == 0, "gemm: operands must be 16-byte aligned");
+    SDVAR_CHECK_ARG(epi >= EPI_BIAS && epi <= EPI_GATED_RES, "gemm: unknown epilogue %d", epi);
     if (epi == EPI_GATED_RES) SDVAR_CHECK_ARG(res && gate && rows_per_gate > 0 && ldres >= N, "gemm: gated-residual epilogue needs res/gate");
-    GemmArgs a{X, W, bias, out, res, gate, M, N, K, ldx, ldo, ldres, rows_per_gate > 0 ? rows_per_gate : 1, gate_stride};
-    if (M <= 32) return launch_cfg<32, 128, 1, 4>(a, epi, stream);
-    if (M <= 64 || (size_t)((M + 127) / 128) * ((N + 127) / 128) < 192) return launch_cfg<64, 128, 2, 2>(a, epi, stream);
-    return launch_cfg<128, 128, 2, 2>(a, epi, stream);
+    GemmArgs a{X, W, bias, out, res, gate, M, N, K, ldx, ldo, ldres, rows_per_gate > 0 ? rows_per_gate : 1, gate_stride, 1, K / BK};
+    // row tile: the one wasting the fewest padded rows (ties -> larger tile: more reuse per LDS byte)
+    int bm = 128;
+    {
+        const int pad128 = (M + 127) / 128 * 128, pad64 = (M + 63) / 64 * 64, pad32 = (M + 31) / 32 * 32;
+        if (pad64 < pad128) bm = 64;
+        if (pad32 < (bm == 64 ? pad64 : pad128)) bm = 32;
+    }
+    const int tiles = ((M + bm - 1) / bm) * ((N + 127) / 128);
+    // K slices: aim at >= 2 workgroups per CU, keep >= 4 K-steps per slice, stay inside the slab workspace
+    int split = 1;
+    const int nkt = K / BK;
+    if (tiles < 384 && nkt >= 8 && N % 4 == 0) {
+        split = (512 + tiles - 1) / tiles;
+        if (split > nkt / 4) split = nkt / 4;
+        while (split > 1 && (size_t)split * M * N > WS_FLOATS) --split;
+        if (split < 1) split = 1;
+        const int kps = (nkt + split - 1) / split;      // drop empty trailing slices
+        split = (nkt + kps - 1) / kps;
+    }
+    if (bm == 32) return launch_cfg<32, 128, 1, 4>(a, epi, split, stream);
+    if (bm == 64) return launch_cfg<64, 128, 2, 2>(a, epi, split, stream);
+    return launch_cfg<128, 128, 2, 2>(a, epi, split, stream);
 }
 
 }  // namespace sdvar

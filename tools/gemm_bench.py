@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the fp32 MFMA GEMM over the exact (M, N, K, epilogue) set one sampling step launches.
+Usage (GPU box):  python tools/gemm_bench.py [--depth 16] [--batch 8] [--iters 20]"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sdvar_amd import engine as E  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--depth", type=int, default=16)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--chunk", type=int, default=1)
+    a = ap.parse_args()
+    lib = E.load_library()
+    dev = torch.device("cuda:0")
+    Cw, R = 64 * a.depth, 2 * a.batch
+    lens = [p * p for p in (1, 2, 3, 4, 5, 6, 8, 10, 13, 16)]
+    if a.chunk > 1:
+        lens = [sum(lens[i:i + a.chunk]) for i in range(0, len(lens), a.chunk)]
+    shapes = [("qkv", 3 * Cw, Cw, 0), ("proj", Cw, Cw, 2), ("fc1", 4 * Cw, Cw, 1), ("fc2", Cw, 4 * Cw, 2)]
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    tot_t, tot_f = 0.0, 0.0
+    print(f"{'op':5s} {'M':>6s} {'N':>5s} {'K':>5s} {'us':>9s} {'TFLOP/s':>8s}")
+    for l in lens:
+        M = R * l
+        for name, N, K, epi in shapes:
+            X = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev) * 0.02; b = torch.randn(N, device=dev)
+            out = torch.randn(M, N, device=dev); gate = torch.randn(R, 6 * Cw, device=dev)
+            def run():
+                E._check(lib.sdvar_op_gemm(C.c_void_p(X.data_ptr()), K, C.c_void_p(W.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(out.data_ptr()), N, M, N, K, epi,
+                                           C.c_void_p(out.data_ptr()) if epi == 2 else None, N, C.c_void_p(gate.data_ptr()) if epi == 2 else None, l, 6 * Cw, st))
+            for _ in range(3): run()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.iters): run()
+            e1.record(); torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / a.iters
+            fl = 2.0 * M * N * K
+            tot_t += us * a.depth; tot_f += fl * a.depth
+            print(f"{name:5s} {M:6d} {N:5d} {K:5d} {us:9.1f} {fl / us / 1e6:8.1f}")
+    print(f"one pass over all stages, {a.depth} layers: {tot_t / 1e3:.2f} ms, {tot_f / tot_t / 1e6:.1f} TFLOP/s average")
+
+
+if __name__ == "__main__":
+    main()
