@@ -110,6 +110,9 @@ int sdvar_op_attention(const float* q, const float* k_cache, const float* v_cach
                        int32_t Ktot, int32_t n_stages, const int32_t* qbeg /*host*/, const int32_t* vis /*host*/, void* stream);
 int sdvar_op_noise_fill(float* q, int32_t B, int32_t l, int32_t V, uint64_t seed, uint32_t draw, uint32_t image_offset, void* stream);
 
+/* tuning aid (tools/gemm_bench.py --sweep): force the GEMM row tile (32/64/128) and K-slice count; 0 = automatic */
+int sdvar_debug_set_gemm_cfg(int32_t bm, int32_t split);
+
 /* ---- per-kernel-class timing with HIP events on the launch stream (bench.py roofline leg) ----------------------------- */
 #define SDVAR_PROF_CLASSES 8   /* 0 gemm, 1 attention, 2 ln_modulate, 3 qk_norm_append, 4 sampler, 5 verify, 6 quant, 7 embed/misc */
 int sdvar_prof_enable(int32_t on);

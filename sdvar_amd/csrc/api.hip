@@ -26,6 +26,7 @@ int cfg_sample(const float* logits, int B, int l, int V, float one_plus_t, float
 int noise_fill(float* q, int B, int l, int V, uint64_t seed, uint32_t draw, uint32_t image_offset, hipStream_t stream);
 int verify_accept(const float* logits, int B, int lsum, int V, int n_chunk, const int* qbeg, const float* one_plus_t, const float* t, const long long* draft_ids,
                   int ids_stride, double thr, int* counts, long long* argmax_out, hipStream_t stream);
+void debug_set_gemm_cfg(int bm, int split);
 int quant_next(const long long* ids, int ids_stride, const float* codebook, const float* Wup, const float* phi_w, const float* phi_b, const float* Wdn,
                float* up_scratch, float* f_hat, float* nxt, int B, int pn, int pn_next, int HW, int Cv, int last, hipStream_t stream);
 
@@ -441,6 +442,13 @@ int sdvar_op_attention(const float* q, const float* kc, const float* vc, float* 
 }
 int sdvar_op_noise_fill(float* q, int32_t B, int32_t l, int32_t V, uint64_t seed, uint32_t draw, uint32_t image_offset, void* stream) {
     return noise_fill(q, B, l, V, seed, draw, image_offset, (hipStream_t)stream);
+}
+
+int sdvar_debug_set_gemm_cfg(int32_t bm, int32_t split) {
+    SDVAR_CHECK_ARG(bm == 0 || bm == 32 || bm == 64 || bm == 128, "debug_set_gemm_cfg: bm %d", bm);
+    SDVAR_CHECK_ARG(split >= 0 && split <= 64, "debug_set_gemm_cfg: split %d", split);
+    debug_set_gemm_cfg(bm, split);
+    return SDVAR_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------- profiling

@@ -124,12 +124,15 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(AttnArgs a) {
                 }
             mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
             const float m_new = fmaxf(m_run, mloc);          // finite from the first tile on (key 0 is always visible)
-            const float alpha = expf(m_run - m_new);         // exp(-inf) = 0 on the first tile
+            // exp(x) = 2^(x log2 e) on v_exp_f32: the exponent argument is (s - m) <= 0, its rounding error |s - m| 2^-24
+            // only matters for weights far below the row maximum
+            const float L2E = 1.4426950408889634f;
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * L2E);   // 2^-inf = 0 on the first tile
             float lsum = 0.f;
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) { s[sub][i] = expf(s[sub][i] - m_new); lsum += s[sub][i]; }
+                for (int i = 0; i < 16; ++i) { s[sub][i] = __builtin_amdgcn_exp2f((s[sub][i] - m_new) * L2E); lsum += s[sub][i]; }
             lsum += __shfl_xor(lsum, 32, 64);
             l_run = l_run * alpha + lsum;
             m_run = m_new;

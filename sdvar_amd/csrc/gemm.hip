@@ -221,6 +221,41 @@ static int launch_cfg(GemmArgs a, int epi, int split, hipStream_t stream) {
     return SDVAR_OK;
 }
 
+static int g_force_bm = 0, g_force_split = 0;     // tools/gemm_bench.py --sweep (sdvar_debug_set_gemm_cfg); 0 = automatic
+void debug_set_gemm_cfg(int bm, int split) { g_force_bm = bm; g_force_split = split; }
+
+// (row tile, K slices) as a pure function of the shape - the summation order, hence every output bit, depends only on
+// (M, N, K).  Cost model in MFMA cycles per CU, calibrated with tools/gemm_bench.py --sweep on MI355X:
+//   a workgroup spends 64 cycles x 16 x (bm/32 x 4 / 4 waves) per K-step on each SIMD; workgroups are dealt evenly over
+//   the 256 CUs, co-resident ones share the matrix pipes (so time ~ per-CU sum), a lone workgroup per CU cannot hide
+//   its LDS/barrier latency, every workgroup pays a fixed prologue/epilogue, and split > 1 pays the slab round trip.
+static void choose_cfg(int M, int N, int K, int* bm_out, int* split_out) {
+    const int nkt = K / BK, tiles_n = (N + 127) / 128;
+    double best = 1e30; int bbm = 128, bs = 1;
+    const int bms[3] = {128, 64, 32};
+    const int resident[3] = {2, 2, 3};                                   // workgroups per CU the LDS footprint admits
+    const double lat[4] = {0.0, 1.35, 1.08, 1.0};                        // slowdown of n co-resident workgroups' K-step (latency exposed when alone)
+    for (int bi = 0; bi < 3; ++bi) {
+        const int bm = bms[bi], res = resident[bi];
+        const int tiles = ((M + bm - 1) / bm) * tiles_n;
+        // MFMA cycles per K-step per workgroup; narrower tiles re-read more LDS/L2 per MFMA (measured +3 % / +12 %)
+        const double ktile = 64.0 * 16.0 * (bm / 32) * (bm == 32 ? 1.12 : (bm == 64 ? 1.03 : 1.0));
+        for (int split = 1; split <= 32 && split <= nkt / 2; ++split) {
+            if (split > 1 && ((size_t)split * M * N > WS_FLOATS || N % 4)) break;
+            const int kps = (nkt + split - 1) / split;
+            if ((nkt + kps - 1) / kps != split) continue;               // would leave empty trailing slices
+            const long blocks = (long)tiles * split;
+            const long per_cu = (blocks + 255) / 256;                    // workgroups the busiest CU executes
+            const double T = kps * ktile + 2500.0 + 40.0 * bm;           // one workgroup alone on the matrix pipes (+ prologue/epilogue)
+            const long full = per_cu / res, rem = per_cu % res;
+            double cyc = full * res * T * lat[res] + (rem ? rem * T * lat[rem] : 0.0);
+            if (split > 1) cyc += 6000.0 + (double)(split + 1) * M * N * 4.0 / 1800.0;   // reduce launch + slab traffic (~3.8 TB/s at 2.1 GHz)
+            if (cyc < best) { best = cyc; bbm = bm; bs = split; }
+        }
+    }
+    *bm_out = bbm; *split_out = bs;
+}
+
 // Host entry used by the model code and by the op-level C-ABI.
 int gemm_f32_nt(const float* X, int ldx, const float* W, const float* bias, float* out, int ldo, int M, int N, int K, int epi,
                 const float* res, int ldres, const float* gate, int rows_per_gate, int gate_stride, hipStream_t stream) {
@@ -231,23 +266,15 @@ int gemm_f32_nt(const float* X, int ldx, const float* W, const float* bias, floa
     SDVAR_CHECK_ARG(epi >= EPI_BIAS && epi <= EPI_GATED_RES, "gemm: unknown epilogue %d", epi);
     if (epi == EPI_GATED_RES) SDVAR_CHECK_ARG(res && gate && rows_per_gate > 0 && ldres >= N, "gemm: gated-residual epilogue needs res/gate");
     GemmArgs a{X, W, bias, out, res, gate, M, N, K, ldx, ldo, ldres, rows_per_gate > 0 ? rows_per_gate : 1, gate_stride, 1, K / BK};
-    // row tile: the one wasting the fewest padded rows (ties -> larger tile: more reuse per LDS byte)
-    int bm = 128;
-    {
-        const int pad128 = (M + 127) / 128 * 128, pad64 = (M + 63) / 64 * 64, pad32 = (M + 31) / 32 * 32;
-        if (pad64 < pad128) bm = 64;
-        if (pad32 < (bm == 64 ? pad64 : pad128)) bm = 32;
-    }
-    const int tiles = ((M + bm - 1) / bm) * ((N + 127) / 128);
-    // K slices: aim at >= 2 workgroups per CU, keep >= 4 K-steps per slice, stay inside the slab workspace
-    int split = 1;
-    const int nkt = K / BK;
-    if (tiles < 384 && nkt >= 8 && N % 4 == 0) {
-        split = (512 + tiles - 1) / tiles;
-        if (split > nkt / 4) split = nkt / 4;
+    int bm, split;
+    choose_cfg(M, N, K, &bm, &split);
+    if (g_force_bm) bm = g_force_bm;
+    if (g_force_split) {
+        split = g_force_split;
+        const int nkt = K / BK;
+        if (split > nkt) split = nkt;
         while (split > 1 && (size_t)split * M * N > WS_FLOATS) --split;
-        if (split < 1) split = 1;
-        const int kps = (nkt + split - 1) / split;      // drop empty trailing slices
+        const int kps = (nkt + split - 1) / split;
         split = (nkt + kps - 1) / kps;
     }
     if (bm == 32) return launch_cfg<32, 128, 1, 4>(a, epi, split, stream);

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--chunk", type=int, default=1)
+    ap.add_argument("--sweep", action="store_true", help="time every (row tile, K slices) candidate per shape")
     a = ap.parse_args()
     lib = E.load_library()
     dev = torch.device("cuda:0")
@@ -37,12 +38,24 @@ def main():
             def run():
                 E._check(lib.sdvar_op_gemm(C.c_void_p(X.data_ptr()), K, C.c_void_p(W.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(out.data_ptr()), N, M, N, K, epi,
                                            C.c_void_p(out.data_ptr()) if epi == 2 else None, N, C.c_void_p(gate.data_ptr()) if epi == 2 else None, l, 6 * Cw, st))
-            for _ in range(3): run()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(a.iters): run()
-            e1.record(); torch.cuda.synchronize()
-            us = e0.elapsed_time(e1) * 1e3 / a.iters
+            def timeit():
+                for _ in range(3): run()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(a.iters): run()
+                e1.record(); torch.cuda.synchronize()
+                return e0.elapsed_time(e1) * 1e3 / a.iters
+            us = timeit()
+            if a.sweep:
+                res = []
+                for bm in (32, 64, 128):
+                    for split in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 24, 32):
+                        if split > K // 64: continue
+                        E._check(lib.sdvar_debug_set_gemm_cfg(bm, split))
+                        res.append((timeit(), bm, split))
+                E._check(lib.sdvar_debug_set_gemm_cfg(0, 0))
+                res.sort()
+                print(f"   sweep {name} M={M}: auto {us:.1f}us; best " + ", ".join(f"{t:.1f}us(bm{bm},s{sp})" for t, bm, sp in res[:4]))
             fl = 2.0 * M * N * K
             tot_t += us * a.depth; tot_f += fl * a.depth
             print(f"{name:5s} {M:6d} {N:5d} {K:5d} {us:9.1f} {fl / us / 1e6:8.1f}")
