@@ -142,15 +142,23 @@ def main():
     E.prof_enable(False)
     classes = {k: v for k, v in prof.items() if v["launches"]}
     dom = max(classes, key=lambda k: classes[k]["ms"])
+    pmc = {}
+    try:   # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (profiles/)
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    except Exception:
+        pass
+
     def roof(name):
         c = classes[name]
         sec = c["ms"] * 1e-3
         if name == "gemm":
             ach = c["flops"] / sec / 1e12
             return dict(kernel="gemm_f32_nt_kernel", bound="mfma", achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_F32_MFMA_TFLOPS,
-                        traffic=None, launches=c["launches"], avg_us=c["ms"] * 1e3 / c["launches"])
+                        traffic=pmc.get("gemm_f32_nt_kernel", {}).get("hbm_bytes_per_launch"), algorithmic_bytes=c["bytes"] / c["launches"],
+                        launches=c["launches"], avg_us=c["ms"] * 1e3 / c["launches"])
         ach = c["bytes"] / sec / 1e9
-        return dict(kernel=name, bound="hbm", achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS, traffic=None,
+        return dict(kernel=name, bound="hbm", achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS,
+                    traffic=pmc.get(name + "_f32_kernel", {}).get("hbm_bytes_per_launch"), algorithmic_bytes=c["bytes"] / c["launches"],
                     launches=c["launches"], avg_us=c["ms"] * 1e3 / c["launches"], tflops=c["flops"] / sec / 1e12)
     roofline = roof(dom)
     roofline_attn = roof("attention") if "attention" in classes else None
