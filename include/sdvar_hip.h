@@ -33,6 +33,7 @@ typedef struct {
     int32_t num_classes;                    /* 1000; class_emb has num_classes + 1 rows (var.py:62) */
     int32_t max_batch;                      /* B; the CFG batch is R = 2B rows (var.py:162,188) */
     int32_t max_chunk_stages;               /* largest number of stages one forward may cover (gamma) */
+    int32_t kv_dtype;                       /* KV-cache storage: 0 = fp32 (reference CPU path), 1 = fp16 (BASELINE config P4) */
 } sdvar_model_desc;
 
 int sdvar_abi_version(void);
@@ -103,11 +104,11 @@ int sdvar_op_gemm(const float* X, int32_t ldx, const float* W, const float* bias
                   int32_t epilogue, const float* res, int32_t ldres, const float* gate, int32_t rows_per_gate, int32_t gate_stride, void* stream);
 int sdvar_op_ln_modulate(const float* x, const float* scale, const float* shift, float* out, int32_t rows, int32_t C,
                          int32_t rows_per_img, int32_t mod_stride, void* stream);
-int sdvar_op_qk_norm_append(const float* qkv, const float* scale_mul, float* q_out, float* k_cache, float* v_cache, int32_t R, int32_t l,
-                            int32_t H, int32_t Lmax, int32_t pos0, void* stream);
-/* q (R,H,l,64), caches (R,H,Lmax,64) with Ktot valid keys, out (R,l,H*64); queries >= qbeg[j] see keys < vis[j] */
-int sdvar_op_attention(const float* q, const float* k_cache, const float* v_cache, float* out, int32_t R, int32_t H, int32_t l, int32_t Lmax,
-                       int32_t Ktot, int32_t n_stages, const int32_t* qbeg /*host*/, const int32_t* vis /*host*/, void* stream);
+int sdvar_op_qk_norm_append(const float* qkv, const float* scale_mul, float* q_out, void* k_cache, void* v_cache, int32_t kv_f16, int32_t R,
+                            int32_t l, int32_t H, int32_t Lmax, int32_t pos0, void* stream);
+/* q (R,H,l,64), caches (R,H,Lmax,64) fp32 or fp16 (kv_f16) with Ktot valid keys, out (R,l,H*64); queries >= qbeg[j] see keys < vis[j] */
+int sdvar_op_attention(const float* q, const void* k_cache, const void* v_cache, int32_t kv_f16, float* out, int32_t R, int32_t H, int32_t l,
+                       int32_t Lmax, int32_t Ktot, int32_t n_stages, const int32_t* qbeg /*host*/, const int32_t* vis /*host*/, void* stream);
 int sdvar_op_noise_fill(float* q, int32_t B, int32_t l, int32_t V, uint64_t seed, uint32_t draw, uint32_t image_offset, void* stream);
 
 /* tuning aid (tools/gemm_bench.py --sweep): force the GEMM row tile (32/64/128) and K-slice count; 0 = automatic */

@@ -36,7 +36,8 @@ NoiseFn = Callable[[int, int, int, int], Tensor]      # (draw, B, l, V) -> q (B*
 class OracleVAR:
     """Weights (reference state_dict names) + dims of one VAR transformer, with an explicit KV cache."""
 
-    def __init__(self, sd: Dict[str, Tensor], depth: int, patch_nums: Sequence[int], num_classes: int = 1000):
+    def __init__(self, sd: Dict[str, Tensor], depth: int, patch_nums: Sequence[int], num_classes: int = 1000, kv_fp16: bool = False):
+        self.kv_fp16 = kv_fp16        # BASELINE config P4: cache entries rounded to fp16 (all arithmetic stays fp32)
         self.sd = {k: v.detach().to(torch.float32) if v.is_floating_point() else v for k, v in sd.items()}
         self.depth, self.C, self.H = depth, 64 * depth, depth
         self.patch_nums = tuple(patch_nums)
@@ -86,6 +87,8 @@ class OracleVAR:
         scale_mul = sd[p + "attn.scale_mul_1H11"].clamp_max(math.log(100.0)).exp()
         q = F.normalize(q, dim=-1).mul(scale_mul)
         k = F.normalize(k, dim=-1)
+        if self.kv_fp16:
+            k, v = k.half().float(), v.half().float()
         if self.kv[i] is not None:
             k = torch.cat((self.kv[i][0], k), dim=2); v = torch.cat((self.kv[i][1], v), dim=2)
         self.kv[i] = (k, v)

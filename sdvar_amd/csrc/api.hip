@@ -15,12 +15,12 @@ namespace sdvar {
 int gemm_f32_nt(const float* X, int ldx, const float* W, const float* bias, float* out, int ldo, int M, int N, int K, int epi,
                 const float* res, int ldres, const float* gate, int rows_per_gate, int gate_stride, hipStream_t stream);
 int ln_modulate(const float* x, const float* scale, const float* shift, float* out, int rows, int C, int rows_per_img, int mod_stride, hipStream_t stream);
-int qk_norm_append(const float* qkv, const float* scale_mul, float* q_out, float* k_cache, float* v_cache, int R, int l, int H, int Lmax, int pos0, hipStream_t stream);
+int qk_norm_append(const float* qkv, const float* scale_mul, float* q_out, void* k_cache, void* v_cache, int kv_f16, int R, int l, int H, int Lmax, int pos0, hipStream_t stream);
 int silu_rows(const float* x, float* y, int n, hipStream_t stream);
 int prologue(const long long* labels, const float* class_emb, const float* pos_start, const float* lvl_pos, float* cond, float* x0, int B, int C, int num_classes, hipStream_t stream);
 int build_lvl_pos(const float* lvl_embed, const float* pos, const int* stage_of_tok, float* out, int L, int C, hipStream_t stream);
 int embed_next(const float* nxt, const float* Ww, const float* bw, const float* lvl_pos, float* x, int B, int l, int C, int t0, int ltot, int tok_off, hipStream_t stream);
-int attention_f32(const float* q, const float* kc, const float* vc, float* out, int R, int H, int l, int Lmax, int Ktot, int n_chunk, const int* qbeg, const int* vis, hipStream_t stream);
+int attention_f32(const float* q, const void* kc, const void* vc, int kv_f16, float* out, int R, int H, int l, int Lmax, int Ktot, int n_chunk, const int* qbeg, const int* vis, hipStream_t stream);
 int cfg_sample(const float* logits, int B, int l, int V, float one_plus_t, float t, int top_k, int use_top_p, float top_p_thr, const float* q, uint64_t seed,
                uint32_t draw, uint32_t image_offset, long long* ids, int ids_stride, float* dbg_masked, hipStream_t stream);
 int noise_fill(float* q, int B, int l, int V, uint64_t seed, uint32_t draw, uint32_t image_offset, hipStream_t stream);
@@ -73,7 +73,7 @@ static int dmalloc(T** p, size_t n) {
 struct BlockW {
     const float *ada_w, *ada_b, *qkv_w, *scale_mul, *proj_w, *proj_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
     float* qkv_bias;     // owned: [q_bias, 0, v_bias]  (basic_var.py:93)
-    float *kc, *vc;      // owned KV cache (Rmax, H, L, 64)
+    void *kc, *vc;       // owned KV cache (Rmax, H, L, 64), fp32 or fp16 (desc.kv_dtype)
     bool bound;
 };
 
@@ -126,6 +126,7 @@ int sdvar_model_create(const sdvar_model_desc* desc, sdvar_model_t** out) {
     SDVAR_CHECK_ARG(desc->vocab > 0 && desc->vocab <= 4096 && desc->vocab % 4 == 0, "model_create: vocab %d", desc->vocab);
     SDVAR_CHECK_ARG(desc->cvae == 32, "model_create: cvae must be 32 (got %d)", desc->cvae);
     SDVAR_CHECK_ARG(desc->max_batch >= 1 && desc->num_classes >= 1, "model_create: batch/classes");
+    SDVAR_CHECK_ARG(desc->kv_dtype == 0 || desc->kv_dtype == 1, "model_create: kv_dtype %d (0 = fp32, 1 = fp16)", desc->kv_dtype);
     SDVAR_CHECK_ARG(desc->max_chunk_stages >= 1 && desc->max_chunk_stages <= SDVAR_MAX_STAGES, "model_create: max_chunk_stages %d", desc->max_chunk_stages);
     sdvar_model* m = new sdvar_model();
     m->d = *desc;
@@ -165,8 +166,9 @@ int sdvar_model_create(const sdvar_model_desc* desc, sdvar_model_t** out) {
     SDVAR_TRY(dmalloc(&m->hid, M * 4 * C));
     for (auto& b : m->blk) {
         SDVAR_TRY(dmalloc(&b.qkv_bias, 3 * C));
-        SDVAR_TRY(dmalloc(&b.kc, R * (size_t)m->H * m->L * 64));
-        SDVAR_TRY(dmalloc(&b.vc, R * (size_t)m->H * m->L * 64));
+        const size_t kvb = R * (size_t)m->H * m->L * 64 * (desc->kv_dtype ? 2 : 4);
+        SDVAR_HIP(hipMalloc(&b.kc, kvb));
+        SDVAR_HIP(hipMalloc(&b.vc, kvb));
     }
     *out = m;
     return SDVAR_OK;
@@ -288,9 +290,9 @@ int sdvar_stage_forward(sdvar_model_t* m, float* x, int32_t s0, int32_t n, float
         { ProfScope ps(0, 2 * dM * 3 * dC * dC, 4 * (dM * dC + 3 * dC * dC + 3 * dM * dC), s);
           SDVAR_TRY(gemm_f32_nt(m->xn, C, b.qkv_w, b.qkv_bias, m->qkv, 3 * C, M, 3 * C, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, s)); }
         { ProfScope ps(3, 6 * dM * dC, 4 * 6 * dM * dC, s);
-          SDVAR_TRY(qk_norm_append(m->qkv, b.scale_mul, m->qbuf, b.kc, b.vc, R, lsum, H, m->L, m->kv_len, s)); }
-        { ProfScope ps(1, 4.0 * R * H * 64.0 * lk, 4.0 * R * H * 64.0 * (2.0 * Ktot + 2.0 * lsum), s);
-          SDVAR_TRY(attention_f32(m->qbuf, b.kc, b.vc, m->att, R, H, lsum, m->L, Ktot, n, qbeg, vis, s)); }
+          SDVAR_TRY(qk_norm_append(m->qkv, b.scale_mul, m->qbuf, b.kc, b.vc, m->d.kv_dtype, R, lsum, H, m->L, m->kv_len, s)); }
+        { ProfScope ps(1, 4.0 * R * H * 64.0 * lk, R * H * 64.0 * ((m->d.kv_dtype ? 4.0 : 8.0) * Ktot + 8.0 * lsum), s);
+          SDVAR_TRY(attention_f32(m->qbuf, b.kc, b.vc, m->d.kv_dtype, m->att, R, H, lsum, m->L, Ktot, n, qbeg, vis, s)); }
         { ProfScope ps(0, 2 * dM * dC * dC, 4 * (3 * dM * dC + dC * dC), s);
           SDVAR_TRY(gemm_f32_nt(m->att, C, b.proj_w, b.proj_b, x, C, M, C, C, EPI_GATED_RES, x, C, ada, lsum, 6 * C, s)); }
         { ProfScope ps(2, 8 * dM * dC, 8 * dM * dC, s);
@@ -428,17 +430,17 @@ int sdvar_op_ln_modulate(const float* x, const float* scale, const float* shift,
                          int32_t mod_stride, void* stream) {
     return ln_modulate(x, scale, shift, out, rows, C, rows_per_img, mod_stride, (hipStream_t)stream);
 }
-int sdvar_op_qk_norm_append(const float* qkv, const float* scale_mul, float* q_out, float* k_cache, float* v_cache, int32_t R, int32_t l, int32_t H,
-                            int32_t Lmax, int32_t pos0, void* stream) {
-    return qk_norm_append(qkv, scale_mul, q_out, k_cache, v_cache, R, l, H, Lmax, pos0, (hipStream_t)stream);
+int sdvar_op_qk_norm_append(const float* qkv, const float* scale_mul, float* q_out, void* k_cache, void* v_cache, int32_t kv_f16, int32_t R, int32_t l,
+                            int32_t H, int32_t Lmax, int32_t pos0, void* stream) {
+    return qk_norm_append(qkv, scale_mul, q_out, k_cache, v_cache, kv_f16, R, l, H, Lmax, pos0, (hipStream_t)stream);
 }
-int sdvar_op_attention(const float* q, const float* kc, const float* vc, float* out, int32_t R, int32_t H, int32_t l, int32_t Lmax, int32_t Ktot,
-                       int32_t n, const int32_t* qbeg, const int32_t* vis, void* stream) {
+int sdvar_op_attention(const float* q, const void* kc, const void* vc, int32_t kv_f16, float* out, int32_t R, int32_t H, int32_t l, int32_t Lmax,
+                       int32_t Ktot, int32_t n, const int32_t* qbeg, const int32_t* vis, void* stream) {
     SDVAR_CHECK_ARG(qbeg && vis && n >= 1 && n <= SDVAR_MAX_STAGES, "op_attention: bad stage table");
     double lk = 0;
     for (int j = 0; j < n; ++j) lk += (double)((j + 1 < n ? qbeg[j + 1] : l) - qbeg[j]) * vis[j];
-    ProfScope ps(1, 4.0 * R * H * 64.0 * lk, 4.0 * R * H * 64.0 * (2.0 * Ktot + 2.0 * l), (hipStream_t)stream);
-    return attention_f32(q, kc, vc, out, R, H, l, Lmax, Ktot, n, qbeg, vis, (hipStream_t)stream);
+    ProfScope ps(1, 4.0 * R * H * 64.0 * lk, R * H * 64.0 * ((kv_f16 ? 4.0 : 8.0) * Ktot + 8.0 * l), (hipStream_t)stream);
+    return attention_f32(q, kc, vc, kv_f16, out, R, H, l, Lmax, Ktot, n, qbeg, vis, (hipStream_t)stream);
 }
 int sdvar_op_noise_fill(float* q, int32_t B, int32_t l, int32_t V, uint64_t seed, uint32_t draw, uint32_t image_offset, void* stream) {
     return noise_fill(q, B, l, V, seed, draw, image_offset, (hipStream_t)stream);

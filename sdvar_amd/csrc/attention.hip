@@ -3,7 +3,8 @@
 // /root/reference/models/basic_var.py:107-117 with the mask rows of models/var.py:108-113 derived in-kernel from the
 // stage boundaries (never materialised).
 //
-// Layouts:  q (R, H, l, 64) (already L2-normalised and scaled), kc/vc (R, H, Lmax, 64) with `Ktot` valid keys
+// Layouts:  q (R, H, l, 64) (already L2-normalised and scaled), kc/vc (R, H, Lmax, 64) fp32 or fp16 (BASELINE config P4:
+//           the cache is stored in half precision and widened while staging; all arithmetic stays fp32) with `Ktot` valid keys
 //           (prefix + the l keys of this call), out (R, l, H*64) row-major for the projection GEMM.
 // Queries of chunk stage j (q index in [qbeg[j], qbeg[j+1])) see keys [0, vis[j]).
 //
@@ -14,6 +15,8 @@
 //   K/V tiles of 64 keys are streamed HBM -> registers -> LDS (double buffered, coalesced 16-byte loads of contiguous
 //   cache rows), K rows padded to 68 floats for conflict-free ds_read_b128.
 // Algorithmic bytes per launch: R*H*64*4 * (2*Ktot + 2*l) (K and V read once, Q read, O written).
+#include <hip/hip_fp16.h>
+
 #include "common.h"
 
 namespace sdvar {
@@ -23,13 +26,14 @@ constexpr int KT = 64;              // keys per LDS tile
 constexpr int KSTR = 68;            // padded K row (floats)
 
 struct AttnArgs {
-    const float* q; const float* kc; const float* vc; float* out;
+    const float* q; const void* kc; const void* vc; float* out;     // kc/vc: fp32 or fp16 (template KVH)
     int R, H, l, Lmax, Ktot;
     int n_chunk;
     int qbeg[ATT_MAX_CHUNK + 1];
     int vis[ATT_MAX_CHUNK];
 };
 
+template <bool KVH>
 __global__ __launch_bounds__(256) void attention_f32_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int STAGE = KT * KSTR + KT * 64;              // floats per pipeline stage: K tile then V tile
@@ -60,28 +64,64 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(AttnArgs a) {
         for (int c = 0; c < 8; ++c) qf[c] = *reinterpret_cast<const f32x4*>(pq + 8 * c);
     }
 
-    const float* kbase = a.kc + ((size_t)r * a.H + h) * a.Lmax * 64;
-    const float* vbase = a.vc + ((size_t)r * a.H + h) * a.Lmax * 64;
-    // staging: 64 keys x 64 floats = 1024 float4 per operand, 4 per thread: key = tid/16 + 16*i, col4 = tid%16
-    const int skey = tid >> 4, scol = (tid & 15) * 4;
+    // staging: 64 keys x 64 channels per operand.  fp32 cache: 4 float4 per thread (key = tid/16 + 16 i, col = 4 (tid%16));
+    // fp16 cache: 2 chunks of 8 halves per thread (key = tid/8 + 32 i, col = 8 (tid%8)), widened to fp32 on the way to LDS.
+    const size_t head_off = ((size_t)r * a.H + h) * a.Lmax * 64;
+    const float* kbase = reinterpret_cast<const float*>(a.kc) + (KVH ? 0 : head_off);
+    const float* vbase = reinterpret_cast<const float*>(a.vc) + (KVH ? 0 : head_off);
+    const __half* kbh = reinterpret_cast<const __half*>(a.kc) + (KVH ? head_off : 0);
+    const __half* vbh = reinterpret_cast<const __half*>(a.vc) + (KVH ? head_off : 0);
+    const int skey = KVH ? (tid >> 3) : (tid >> 4), scol = KVH ? (tid & 7) * 8 : (tid & 15) * 4;
     f32x4 rk[4], rv[4];
     auto load_tile = [&](int k0) {
+        if (KVH) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int key = k0 + skey + 16 * i;
-            if (key < a.Ktot) {
-                rk[i] = *reinterpret_cast<const f32x4*>(kbase + (size_t)key * 64 + scol);
-                rv[i] = *reinterpret_cast<const f32x4*>(vbase + (size_t)key * 64 + scol);
-            } else {
-                rk[i] = f32x4{0.f, 0.f, 0.f, 0.f}; rv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < 2; ++i) {
+                const int key = k0 + skey + 32 * i;
+                if (key < a.Ktot) {
+                    const f32x4 hk = *reinterpret_cast<const f32x4*>(kbh + (size_t)key * 64 + scol);   // 8 halves
+                    const f32x4 hv = *reinterpret_cast<const f32x4*>(vbh + (size_t)key * 64 + scol);
+                    const __half2* pk = reinterpret_cast<const __half2*>(&hk);
+                    const __half2* pv = reinterpret_cast<const __half2*>(&hv);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const float2 a0 = __half22float2(pk[2 * e]), a1 = __half22float2(pk[2 * e + 1]);
+                        const float2 b0 = __half22float2(pv[2 * e]), b1 = __half22float2(pv[2 * e + 1]);
+                        rk[2 * i + e] = f32x4{a0.x, a0.y, a1.x, a1.y};
+                        rv[2 * i + e] = f32x4{b0.x, b0.y, b1.x, b1.y};
+                    }
+                } else {
+                    rk[2 * i] = rk[2 * i + 1] = rv[2 * i] = rv[2 * i + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int key = k0 + skey + 16 * i;
+                if (key < a.Ktot) {
+                    rk[i] = *reinterpret_cast<const f32x4*>(kbase + (size_t)key * 64 + scol);
+                    rv[i] = *reinterpret_cast<const f32x4*>(vbase + (size_t)key * 64 + scol);
+                } else {
+                    rk[i] = f32x4{0.f, 0.f, 0.f, 0.f}; rv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
             }
         }
     };
     auto store_tile = [&](int buf) {
+        if (KVH) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f32x4*>(smem + buf * STAGE + (skey + 16 * i) * KSTR + scol) = rk[i];
-            *reinterpret_cast<f32x4*>(smem + buf * STAGE + KT * KSTR + (skey + 16 * i) * 64 + scol) = rv[i];
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    *reinterpret_cast<f32x4*>(smem + buf * STAGE + (skey + 32 * i) * KSTR + scol + 4 * e) = rk[2 * i + e];
+                    *reinterpret_cast<f32x4*>(smem + buf * STAGE + KT * KSTR + (skey + 32 * i) * 64 + scol + 4 * e) = rv[2 * i + e];
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                *reinterpret_cast<f32x4*>(smem + buf * STAGE + (skey + 16 * i) * KSTR + scol) = rk[i];
+                *reinterpret_cast<f32x4*>(smem + buf * STAGE + KT * KSTR + (skey + 16 * i) * 64 + scol) = rv[i];
+            }
         }
     };
 
@@ -167,7 +207,7 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(AttnArgs a) {
     }
 }
 
-int attention_f32(const float* q, const float* kc, const float* vc, float* out, int R, int H, int l, int Lmax, int Ktot, int n_chunk,
+int attention_f32(const float* q, const void* kc, const void* vc, int kv_f16, float* out, int R, int H, int l, int Lmax, int Ktot, int n_chunk,
                   const int* qbeg, const int* vis, hipStream_t stream) {
     SDVAR_CHECK_ARG(q && kc && vc && out, "attention: null operand");
     SDVAR_CHECK_ARG(n_chunk >= 1 && n_chunk <= ATT_MAX_CHUNK, "attention: chunk of %d stages unsupported (max %d)", n_chunk, ATT_MAX_CHUNK);
@@ -182,10 +222,12 @@ int attention_f32(const float* q, const float* kc, const float* vc, float* out, 
     const size_t lds = 2 * (size_t)(KT * KSTR + KT * 64) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        SDVAR_HIP(hipFuncSetAttribute((const void*)attention_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SDVAR_HIP(hipFuncSetAttribute((const void*)attention_f32_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SDVAR_HIP(hipFuncSetAttribute((const void*)attention_f32_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(attention_f32_kernel, dim3((l + 127) / 128, H, R), dim3(256), lds, stream, a);
+    if (kv_f16) hipLaunchKernelGGL(attention_f32_kernel<true>, dim3((l + 127) / 128, H, R), dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL(attention_f32_kernel<false>, dim3((l + 127) / 128, H, R), dim3(256), lds, stream, a);
     SDVAR_LAUNCH_CHECK();
     return SDVAR_OK;
 }

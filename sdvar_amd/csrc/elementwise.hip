@@ -7,6 +7,8 @@
 //   prologue           cond = class_emb[label | uncond], x0 = cond + pos_start + lvl_pos[0]   var.py:162-183
 //   build_lvl_pos      lvl_embed[lvl(t)] + pos_1LC[t]                               var.py:164
 //   embed_next         word_embed(next) + lvl_pos, written to both CFG rows of a (R, ltot, C) chunk input   var.py:186-188
+#include <hip/hip_fp16.h>
+
 #include "common.h"
 
 namespace sdvar {
@@ -69,9 +71,10 @@ int ln_modulate(const float* x, const float* scale, const float* shift, float* o
 // ------------------------------------------------------------------------------------------------ qk_norm_append
 // qkv (R*l, 3C) with the bias already added.  One wave per (row, head); lane = channel.
 // q_out (R, H, l, 64); k_cache / v_cache (R, H, Lmax, 64) written at positions pos0 .. pos0+l-1.
+template <typename KV>
 __global__ __launch_bounds__(256) void qk_norm_append_kernel(const float* __restrict__ qkv, const float* __restrict__ scale_mul,
-                                                             float* __restrict__ q_out, float* __restrict__ k_cache,
-                                                             float* __restrict__ v_cache, int R, int l, int H, int Lmax, int pos0) {
+                                                             float* __restrict__ q_out, KV* __restrict__ k_cache,
+                                                             KV* __restrict__ v_cache, int R, int l, int H, int Lmax, int pos0) {
     const int lane = threadIdx.x & 63;
     const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (item >= (long long)R * l * H) return;
@@ -86,15 +89,16 @@ __global__ __launch_bounds__(256) void qk_norm_append_kernel(const float* __rest
     const float sm = expf(fminf(scale_mul[h], 4.605170249938965f));    // log(100) as the reference's float32 clamp
     q_out[(((size_t)r * H + h) * l + t) * 64 + lane] = (q / qn) * sm;
     const size_t c = (((size_t)r * H + h) * Lmax + pos0 + t) * 64 + lane;
-    k_cache[c] = k / kn;
-    v_cache[c] = v;
+    k_cache[c] = (KV)(k / kn);           // fp16 cache: round-to-nearest-even, like torch's .half()
+    v_cache[c] = (KV)v;
 }
 
-int qk_norm_append(const float* qkv, const float* scale_mul, float* q_out, float* k_cache, float* v_cache, int R, int l, int H,
+int qk_norm_append(const float* qkv, const float* scale_mul, float* q_out, void* k_cache, void* v_cache, int kv_f16, int R, int l, int H,
                    int Lmax, int pos0, hipStream_t stream) {
     SDVAR_CHECK_ARG(R > 0 && l > 0 && H > 0 && pos0 >= 0 && pos0 + l <= Lmax, "qk_norm_append: cache overflow pos0=%d l=%d Lmax=%d", pos0, l, Lmax);
     const long long items = (long long)R * l * H;
-    hipLaunchKernelGGL(qk_norm_append_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, qkv, scale_mul, q_out, k_cache, v_cache, R, l, H, Lmax, pos0);
+    if (kv_f16) hipLaunchKernelGGL(qk_norm_append_kernel<__half>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, qkv, scale_mul, q_out, (__half*)k_cache, (__half*)v_cache, R, l, H, Lmax, pos0);
+    else hipLaunchKernelGGL(qk_norm_append_kernel<float>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, qkv, scale_mul, q_out, (float*)k_cache, (float*)v_cache, R, l, H, Lmax, pos0);
     SDVAR_LAUNCH_CHECK();
     return SDVAR_OK;
 }

@@ -34,7 +34,7 @@ class SdvarError(RuntimeError):
 
 class _ModelDesc(C.Structure):
     _fields_ = [("depth", C.c_int32), ("n_stages", C.c_int32), ("patch_nums", C.c_int32 * MAX_STAGES), ("vocab", C.c_int32),
-                ("cvae", C.c_int32), ("num_classes", C.c_int32), ("max_batch", C.c_int32), ("max_chunk_stages", C.c_int32)]
+                ("cvae", C.c_int32), ("num_classes", C.c_int32), ("max_batch", C.c_int32), ("max_chunk_stages", C.c_int32), ("kv_dtype", C.c_int32)]
 
 
 _P, _I, _D, _U64, _U32 = C.c_void_p, C.c_int32, C.c_double, C.c_uint64, C.c_uint32
@@ -61,8 +61,8 @@ _SIGNATURES = {
     "sdvar_verify_accept": (_I, [_P, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_D), _P, _I, _D, _P, _P, _P]),
     "sdvar_op_gemm": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P]),
     "sdvar_op_ln_modulate": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "sdvar_op_qk_norm_append": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
-    "sdvar_op_attention": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), _P]),
+    "sdvar_op_qk_norm_append": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "sdvar_op_attention": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), _P]),
     "sdvar_op_noise_fill": (_I, [_P, _I, _I, _I, _U64, _U32, _U32, _P]),
     "sdvar_debug_set_gemm_cfg": (_I, [_I, _I]),
     "sdvar_prof_enable": (_I, [_I]),
@@ -115,7 +115,7 @@ class ModelCtx:
     """sdvar_model_t for one VAR transformer given its state_dict (reference key names)."""
 
     def __init__(self, sd: Dict[str, torch.Tensor], depth: int, patch_nums: Sequence[int], max_batch: int, max_chunk: int,
-                 device, num_classes: int = 1000):
+                 device, num_classes: int = 1000, kv_fp16: bool = False):
         self.lib = load_library()
         self.lad = as_ladder(patch_nums)
         self.depth, self.Cw, self.H = depth, 64 * depth, depth
@@ -124,7 +124,8 @@ class ModelCtx:
         self.max_batch, self.max_chunk = max_batch, max_chunk
         d = _ModelDesc()
         d.depth, d.n_stages, d.vocab, d.cvae, d.num_classes = depth, self.lad.S, self.V, sd["word_embed.weight"].shape[1], num_classes
-        d.max_batch, d.max_chunk_stages = max_batch, max_chunk
+        d.max_batch, d.max_chunk_stages, d.kv_dtype = max_batch, max_chunk, (1 if kv_fp16 else 0)
+        self.kv_fp16 = bool(kv_fp16)
         for i, p in enumerate(self.lad.patch_nums):
             d.patch_nums[i] = p
         self.h = C.c_void_p()

@@ -164,32 +164,44 @@ def vae_state_dict(patch_nums: Sequence[int], mode: str = "perf", seed: int = 12
 
 
 def var_state_dict_device(depth: int, patch_nums: Sequence[int], device, seed: int = 1234, V: int = 4096, Cvae: int = 32,
-                          num_classes: int = 1000) -> "OrderedDict[str, torch.Tensor]":
-    """'perf' init generated directly on the GPU (torch's device generator): same shapes/scales as var_state_dict(mode=
-    'perf'), different values.  For benchmarks only - parity tests use the portable host streams above."""
+                          num_classes: int = 1000, mode: str = "perf") -> "OrderedDict[str, torch.Tensor]":
+    """The 'perf' / 'stress' inits generated directly on the GPU (torch's device generator): same shapes and scales as
+    var_state_dict, different values.  For benchmarks and full-size property tests only - fixture parity uses the
+    portable host streams above."""
     lad = as_ladder(patch_nums)
     C, H, L, S = 64 * depth, depth, lad.L, lad.S
     g = torch.Generator(device=device); g.manual_seed(seed * 31 + depth)
     std0 = math.sqrt(1.0 / C / 3.0)
+    stress = mode == "stress"
     sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
 
-    def tn(shape, scale=1.0):
-        return torch.randn(shape, generator=g, device=device, dtype=torch.float32).clamp_(-2.0, 2.0).mul_(std0 * scale)
+    def w(shape, s_std, scale=1.0):     # weight-like
+        t = torch.randn(shape, generator=g, device=device, dtype=torch.float32)
+        return t.mul_(s_std * scale) if stress else t.clamp_(-2.0, 2.0).mul_(std0 * scale)
 
-    def z(shape): return torch.zeros(shape, device=device, dtype=torch.float32)
-    sd["pos_start"], sd["pos_1LC"] = tn((1, 1, C)), tn((1, L, C))
-    sd["word_embed.weight"], sd["word_embed.bias"] = tn((C, Cvae)), z((C,))
-    sd["class_emb.weight"], sd["lvl_embed.weight"] = tn((num_classes + 1, C)), tn((S, C))
+    def b(shape, s_std):                # bias-like
+        return torch.randn(shape, generator=g, device=device, dtype=torch.float32).mul_(s_std) if stress else torch.zeros(shape, device=device)
+
+    sd["pos_start"], sd["pos_1LC"] = w((1, 1, C), 0.5), w((1, L, C), 0.5)
+    sd["word_embed.weight"], sd["word_embed.bias"] = w((C, Cvae), 1 / math.sqrt(Cvae)), b((C,), 0.1)
+    sd["class_emb.weight"], sd["lvl_embed.weight"] = w((num_classes + 1, C), 1.0), w((S, C), 0.5)
     for i in range(depth):
         p = f"blocks.{i}."
-        sd[p + "attn.scale_mul_1H11"] = torch.full((1, H, 1, 1), math.log(4.0), device=device)
-        sd[p + "attn.q_bias"], sd[p + "attn.v_bias"], sd[p + "attn.zero_k_bias"] = z((C,)), z((C,)), z((C,))
-        sd[p + "attn.mat_qkv.weight"] = tn((3 * C, C))
-        sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"] = tn((C, C), 1 / math.sqrt(2 * depth)), z((C,))
-        sd[p + "ffn.fc1.weight"], sd[p + "ffn.fc1.bias"] = tn((4 * C, C)), z((4 * C,))
-        sd[p + "ffn.fc2.weight"], sd[p + "ffn.fc2.bias"] = tn((C, 4 * C), 1 / math.sqrt(2 * depth)), z((C,))
-        aw = tn((6 * C, C)); aw[2 * C:] *= 0.5; aw[: 2 * C] *= 1e-5
-        sd[p + "ada_lin.1.weight"], sd[p + "ada_lin.1.bias"] = aw, z((6 * C,))
-    sd["head_nm.ada_lin.1.weight"], sd["head_nm.ada_lin.1.bias"] = tn((2 * C, C), 0.5), z((2 * C,))
-    sd["head.weight"], sd["head.bias"] = tn((V, C), 0.02), z((V,))
+        sm = torch.full((1, H, 1, 1), math.log(4.0), device=device)
+        sd[p + "attn.scale_mul_1H11"] = sm + (torch.randn((1, H, 1, 1), generator=g, device=device) * 0.3 if stress else 0.0)
+        sd[p + "attn.q_bias"], sd[p + "attn.v_bias"] = b((C,), 0.1), b((C,), 0.1)
+        sd[p + "attn.zero_k_bias"] = torch.zeros(C, device=device)
+        sd[p + "attn.mat_qkv.weight"] = w((3 * C, C), 1 / math.sqrt(C))
+        sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"] = w((C, C), 1 / math.sqrt(C), 1 / math.sqrt(2 * depth)), b((C,), 0.02)
+        sd[p + "ffn.fc1.weight"], sd[p + "ffn.fc1.bias"] = w((4 * C, C), 1 / math.sqrt(C)), b((4 * C,), 0.1)
+        sd[p + "ffn.fc2.weight"], sd[p + "ffn.fc2.bias"] = w((C, 4 * C), 1 / math.sqrt(4 * C), 1 / math.sqrt(2 * depth)), b((C,), 0.02)
+        aw = w((6 * C, C), 0.5 / math.sqrt(C)); ab = torch.zeros(6 * C, device=device)
+        if stress:
+            ab[: 2 * C] = 1.0
+        else:
+            aw[2 * C:] *= 0.5; aw[: 2 * C] *= 1e-5
+        sd[p + "ada_lin.1.weight"], sd[p + "ada_lin.1.bias"] = aw, ab
+    sd["head_nm.ada_lin.1.weight"] = w((2 * C, C), 0.5 / math.sqrt(C), 1.0 if stress else 0.5)
+    sd["head_nm.ada_lin.1.bias"] = b((2 * C,), 0.1)
+    sd["head.weight"], sd["head.bias"] = w((V, C), 2 / math.sqrt(C), 1.0 if stress else 0.02), b((V,), 0.1)
     return sd

@@ -190,3 +190,20 @@ def test_api_surface_drop_in(dev):
     assert img4.shape == (1, 3, 256, 256)
     with pytest.raises(NotImplementedError):
         target.autoregressive_infer_cfg(B=1, label_B=0, more_smooth=True)
+
+
+def test_fp16_kv_cache_vs_oracle(dev):
+    """BASELINE config P4's cache format on a small model: HIP with kv_fp16 == the oracle that rounds k, v to fp16 at the
+    append (ids bit-exact, logits 1e-3)."""
+    from sdvar_amd.ladder import LADDER_512
+    pns, depth, B = LADDER_512, 4, 1
+    lad = as_ladder(pns)
+    sd, sd_v = state_dicts(depth, pns)
+    ctx = E.ModelCtx(sd, depth, pns, B, 1, dev, kv_fp16=True); qc = E.QuantCtx(sd_v, pns, B, dev)
+    labels = torch.tensor([417])
+    res = E.Sampler(ctx, qc).plain_ar(labels.to(dev), 3.0, 900, 0.96, E.Noise("host", 1), trace=True)
+    tr = orc.plain_ar(orc.OracleVAR(sd, depth, pns, kv_fp16=True), orc.OracleQuant(sd_v, pns), labels, 3.0, 900, 0.96, _noise_o(1), keep=True)
+    errs = [float((res.trace["logits"][s].cpu() - tr.logits[s]).abs().max()) for s in range(lad.S)]
+    assert np.array_equal(res.ids.cpu().numpy(), torch.cat(tr.ids, 1).numpy()), errs
+    assert max(errs) <= LOGIT_TOL, errs
+    ctx.close(); qc.close()

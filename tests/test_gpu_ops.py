@@ -85,7 +85,7 @@ def test_qk_norm_append(dev, R, l, H, pos0):
     sm = (rnd(2, (H,), 0.5) + math.log(4.0)); sm[0] = 6.0                       # one head above the ln(100) clamp
     sm = sm.to(dev)
     qo = torch.zeros(R, H, l, 64, device=dev); kc = torch.zeros(R, H, Lmax, 64, device=dev); vc = torch.zeros_like(kc)
-    E._check(lib.sdvar_op_qk_norm_append(_p(qkv), _p(sm), _p(qo), _p(kc), _p(vc), R, l, H, Lmax, pos0, _st()))
+    E._check(lib.sdvar_op_qk_norm_append(_p(qkv), _p(sm), _p(qo), _p(kc), _p(vc), 0, R, l, H, Lmax, pos0, _st()))
     q, k, v = qkv.cpu().view(R, l, 3, H, 64).permute(2, 0, 3, 1, 4).unbind(0)
     scale = sm.cpu().view(1, H, 1, 1).clamp_max(math.log(100.0)).exp()
     assert (qo.cpu() - F.normalize(q, dim=-1).mul(scale)).abs().max().item() <= 2e-5
@@ -116,7 +116,7 @@ def test_attention_matches_sdpa_with_block_causal_rows(dev, R, H, lens, prefix):
     vis = [prefix + int(sum(lens[:j + 1])) for j in range(len(lens))]
     out = torch.empty(R, l, H * 64, device=dev)
     n = len(lens)
-    E._check(lib.sdvar_op_attention(_p(q), _p(kc), _p(vc), _p(out), R, H, l, Lmax, Ktot, n, (C.c_int32 * n)(*qbeg), (C.c_int32 * n)(*vis), _st()))
+    E._check(lib.sdvar_op_attention(_p(q), _p(kc), _p(vc), 0, _p(out), R, H, l, Lmax, Ktot, n, (C.c_int32 * n)(*qbeg), (C.c_int32 * n)(*vis), _st()))
     ref = _attn_ref(q.cpu(), kc.cpu()[:, :, :Ktot], vc.cpu()[:, :, :Ktot], qbeg, vis).transpose(1, 2).reshape(R, l, H * 64)
     err = (out.cpu().double() - ref).abs().max().item()
     assert err <= 2e-5, err
@@ -133,7 +133,7 @@ def test_attention_forced_online_rescale(dev):
     v = rnd(3, (R, H, Ktot, 64))
     out = torch.empty(R, l, 64, device=dev)
     qd, kd, vd = q.to(dev), k.to(dev).contiguous(), v.to(dev)                  # keep the device copies alive across the call
-    E._check(lib.sdvar_op_attention(_p(qd), _p(kd), _p(vd), _p(out), R, H, l, Ktot, Ktot, 1, (C.c_int32 * 1)(0), (C.c_int32 * 1)(Ktot), _st()))
+    E._check(lib.sdvar_op_attention(_p(qd), _p(kd), _p(vd), 0, _p(out), R, H, l, Ktot, Ktot, 1, (C.c_int32 * 1)(0), (C.c_int32 * 1)(Ktot), _st()))
     ref = _attn_ref(q, k, v, [0], [Ktot]).transpose(1, 2).reshape(R, l, 64)
     assert (out.cpu().double() - ref).abs().max().item() <= 2e-5
 
@@ -264,3 +264,25 @@ def test_quant_next_vs_reference_fixture_and_oracle(dev, lname, pns):
             want = nxt_o.view(B, 32, -1).transpose(1, 2)
             assert (nxt.cpu() - want).abs().max().item() <= 2e-5, si
     np.testing.assert_allclose(f.cpu().numpy(), g["f_hat"], atol=3e-5)         # the reference's own f_hat
+
+
+def test_fp16_kv_cache_append_and_attention(dev):
+    """BASELINE config P4: the cache holds fp16 (round-to-nearest-even of the fp32 values); attention widens while staging."""
+    lib = E.load_library()
+    R, l, H, pos0 = 2, 36, 4, 55
+    Cw, Lmax = 64 * H, pos0 + l
+    qkv = rnd(1, (R * l, 3 * Cw)).to(dev)
+    sm = torch.full((H,), math.log(4.0), device=dev)
+    qo = torch.zeros(R, H, l, 64, device=dev)
+    kc = torch.zeros(R, H, Lmax, 64, device=dev, dtype=torch.float16); vc = torch.zeros_like(kc)
+    kc[:, :, :pos0] = F.normalize(rnd(2, (R, H, pos0, 64)), dim=-1).half().to(dev); vc[:, :, :pos0] = rnd(3, (R, H, pos0, 64)).half().to(dev)
+    E._check(lib.sdvar_op_qk_norm_append(_p(qkv), _p(sm), _p(qo), _p(kc), _p(vc), 1, R, l, H, Lmax, pos0, _st()))
+    q, k, v = qkv.cpu().view(R, l, 3, H, 64).permute(2, 0, 3, 1, 4).unbind(0)
+    k16 = F.normalize(k, dim=-1).half()
+    diff = (kc.cpu()[:, :, pos0:].float() - k16.float()).abs()
+    assert (diff > 0).float().mean().item() < 1e-3 and diff.max().item() <= 1e-3       # same rounding up to 1-ulp fp32 differences before it
+    assert torch.equal(vc.cpu()[:, :, pos0:], v.half())
+    out = torch.empty(R, l, H * 64, device=dev)
+    E._check(lib.sdvar_op_attention(_p(qo), _p(kc), _p(vc), 1, _p(out), R, H, l, Lmax, Lmax, 1, (C.c_int32 * 1)(0), (C.c_int32 * 1)(Lmax), _st()))
+    ref = _attn_ref(qo.cpu(), kc.cpu().float(), vc.cpu().float(), [0], [Lmax]).transpose(1, 2).reshape(R, l, H * 64)
+    assert (out.cpu().double() - ref).abs().max().item() <= 2e-5
