@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--mode", default="natural", choices=["natural", "accept_all", "reject_all"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-modes", action="store_true")
+    ap.add_argument("--gemm-mode", default=None, choices=["f32", "bf16x3"], help="default: sdvar_amd.engine.DEFAULT_GEMM_MODE")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark for the VQVAE decoder convs")
     args = ap.parse_args()
 
@@ -82,8 +83,8 @@ def main():
     sd_v = vae_state_dict(pns, "perf", 1234, with_encoder=False)
     vae = VQVAE(vocab_size=4096, z_channels=32, ch=160, v_patch_nums=pns, with_encoder=False)
     vae.load_state_dict(sd_v); vae = vae.to(dev)
-    dc = E.ModelCtx(sd_d, args.depth_draft, pns, B, 1, dev)
-    tc = E.ModelCtx(sd_t, args.depth_target, pns, B, max(args.gamma, 1), dev)
+    dc = E.ModelCtx(sd_d, args.depth_draft, pns, B, 1, dev, gemm_mode=args.gemm_mode)
+    tc = E.ModelCtx(sd_t, args.depth_target, pns, B, max(args.gamma, 1), dev, gemm_mode=args.gemm_mode)
     qc = E.QuantCtx(sd_v, pns, B, dev)
     smp = E.Sampler(tc, qc, dc)
     log("models bound, buffers allocated")

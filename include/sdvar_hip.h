@@ -34,6 +34,8 @@ typedef struct {
     int32_t max_batch;                      /* B; the CFG batch is R = 2B rows (var.py:162,188) */
     int32_t max_chunk_stages;               /* largest number of stages one forward may cover (gamma) */
     int32_t kv_dtype;                       /* KV-cache storage: 0 = fp32 (reference CPU path), 1 = fp16 (BASELINE config P4) */
+    int32_t gemm_mode;                      /* 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = bf16x3 split operands on the bf16 MFMA
+                                               (fp32-accurate: x = x1+x2+x3 exactly, 6 of 9 plane products, fp32 accumulate) */
 } sdvar_model_desc;
 
 int sdvar_abi_version(void);
@@ -54,7 +56,7 @@ int sdvar_model_bind_block(sdvar_model_t* m, int32_t block, const float* ada_w, 
                            const float* proj_b, const float* fc1_w, const float* fc1_b, const float* fc2_w,
                            const float* fc2_b, void* stream);
 /* head_nm.ada_lin.1.{weight (2C,C), bias}, head.{weight (V,C), bias}  (basic_var.py:165-174, var.py:116-117) */
-int sdvar_model_bind_head(sdvar_model_t* m, const float* nm_w, const float* nm_b, const float* head_w, const float* head_b);
+int sdvar_model_bind_head(sdvar_model_t* m, const float* nm_w, const float* nm_b, const float* head_w, const float* head_b, void* stream);
 
 /* Per-call prologue (var.py:162-183, 580-601): cond = class_emb[labels ; uncond], first-token map, adaLN parameters
  * of every block and of the head hoisted out of the stage loop (basic_var.py:156, :173 - cond never changes), KV
@@ -102,13 +104,21 @@ int sdvar_verify_accept(const float* logits, int32_t B, int32_t lsum, int32_t V,
 /* out[M,N] = epi(X[M,K] W[N,K]^T + bias); epi 0 bias, 1 bias+GELU(tanh), 2 res + (.)*gate[row / rows_per_gate] */
 int sdvar_op_gemm(const float* X, int32_t ldx, const float* W, const float* bias, float* out, int32_t ldo, int32_t M, int32_t N, int32_t K,
                   int32_t epilogue, const float* res, int32_t ldres, const float* gate, int32_t rows_per_gate, int32_t gate_stride, void* stream);
-int sdvar_op_ln_modulate(const float* x, const float* scale, const float* shift, float* out, int32_t rows, int32_t C,
-                         int32_t rows_per_img, int32_t mod_stride, void* stream);
+/* out (fp32) or out_planes (bf16x3 planes [3][rows][C], plane stride in elements) */
+int sdvar_op_ln_modulate(const float* x, const float* scale, const float* shift, float* out, uint16_t* out_planes, uint64_t plane_stride,
+                         int32_t rows, int32_t C, int32_t rows_per_img, int32_t mod_stride, void* stream);
+/* fp32 (n elements) -> three bf16 planes of 8 significand bits each, x == p0 + p1 + p2 exactly */
+int sdvar_op_split_planes(const float* x, uint16_t* planes, uint64_t n, uint64_t plane_stride, void* stream);
+/* the bf16x3 split-operand GEMM on planes [3][M][K] / [3][N][K]; epi 0 bias -> out, 1 bias+GELU -> out_planes [3][M][N], 2 gated residual -> out */
+int sdvar_op_gemm_bf16x3(const uint16_t* Xp, uint64_t x_plane_stride, const uint16_t* Wp, uint64_t w_plane_stride, const float* bias, float* out,
+                         int32_t ldo, uint16_t* out_planes, uint64_t out_plane_stride, int32_t M, int32_t N, int32_t K, int32_t epilogue,
+                         const float* res, int32_t ldres, const float* gate, int32_t rows_per_gate, int32_t gate_stride, void* stream);
 int sdvar_op_qk_norm_append(const float* qkv, const float* scale_mul, float* q_out, void* k_cache, void* v_cache, int32_t kv_f16, int32_t R,
                             int32_t l, int32_t H, int32_t Lmax, int32_t pos0, void* stream);
 /* q (R,H,l,64), caches (R,H,Lmax,64) fp32 or fp16 (kv_f16) with Ktot valid keys, out (R,l,H*64); queries >= qbeg[j] see keys < vis[j] */
-int sdvar_op_attention(const float* q, const void* k_cache, const void* v_cache, int32_t kv_f16, float* out, int32_t R, int32_t H, int32_t l,
-                       int32_t Lmax, int32_t Ktot, int32_t n_stages, const int32_t* qbeg /*host*/, const int32_t* vis /*host*/, void* stream);
+int sdvar_op_attention(const float* q, const void* k_cache, const void* v_cache, int32_t kv_f16, float* out, uint16_t* out_planes, uint64_t plane_stride,
+                       int32_t R, int32_t H, int32_t l, int32_t Lmax, int32_t Ktot, int32_t n_stages, const int32_t* qbeg /*host*/,
+                       const int32_t* vis /*host*/, void* stream);
 int sdvar_op_noise_fill(float* q, int32_t B, int32_t l, int32_t V, uint64_t seed, uint32_t draw, uint32_t image_offset, void* stream);
 
 /* tuning aid (tools/gemm_bench.py --sweep): force the GEMM row tile (32/64/128) and K-slice count; 0 = automatic */

@@ -14,13 +14,17 @@ namespace sdvar {
 // kernels (gemm.hip, elementwise.hip, attention.hip, sampler.hip, quant.hip)
 int gemm_f32_nt(const float* X, int ldx, const float* W, const float* bias, float* out, int ldo, int M, int N, int K, int epi,
                 const float* res, int ldres, const float* gate, int rows_per_gate, int gate_stride, hipStream_t stream);
-int ln_modulate(const float* x, const float* scale, const float* shift, float* out, int rows, int C, int rows_per_img, int mod_stride, hipStream_t stream);
+int ln_modulate(const float* x, const float* scale, const float* shift, float* out, uint16_t* outp, size_t ops, int rows, int C, int rows_per_img, int mod_stride, hipStream_t stream);
 int qk_norm_append(const float* qkv, const float* scale_mul, float* q_out, void* k_cache, void* v_cache, int kv_f16, int R, int l, int H, int Lmax, int pos0, hipStream_t stream);
 int silu_rows(const float* x, float* y, int n, hipStream_t stream);
 int prologue(const long long* labels, const float* class_emb, const float* pos_start, const float* lvl_pos, float* cond, float* x0, int B, int C, int num_classes, hipStream_t stream);
 int build_lvl_pos(const float* lvl_embed, const float* pos, const int* stage_of_tok, float* out, int L, int C, hipStream_t stream);
 int embed_next(const float* nxt, const float* Ww, const float* bw, const float* lvl_pos, float* x, int B, int l, int C, int t0, int ltot, int tok_off, hipStream_t stream);
-int attention_f32(const float* q, const void* kc, const void* vc, int kv_f16, float* out, int R, int H, int l, int Lmax, int Ktot, int n_chunk, const int* qbeg, const int* vis, hipStream_t stream);
+int attention_f32(const float* q, const void* kc, const void* vc, int kv_f16, float* out, uint16_t* outp, size_t ops, int R, int H, int l, int Lmax, int Ktot, int n_chunk, const int* qbeg, const int* vis, hipStream_t stream);
+int gemm_bf16x3_nt(const uint16_t* X, size_t xps, const uint16_t* W, size_t wps, const float* bias, float* out, int ldo, uint16_t* outp, size_t ops,
+                   int M, int N, int K, int epi, const float* res, int ldres, const float* gate, int rows_per_gate, int gate_stride, hipStream_t stream);
+int split_planes(const float* x, uint16_t* planes, size_t n, size_t plane_stride, hipStream_t stream);
+void debug_set_gemm_cfg_p(int bm, int split);
 int cfg_sample(const float* logits, int B, int l, int V, float one_plus_t, float t, int top_k, int use_top_p, float top_p_thr, const float* q, uint64_t seed,
                uint32_t draw, uint32_t image_offset, long long* ids, int ids_stride, float* dbg_masked, hipStream_t stream);
 int noise_fill(float* q, int B, int l, int V, uint64_t seed, uint32_t draw, uint32_t image_offset, hipStream_t stream);
@@ -74,6 +78,7 @@ struct BlockW {
     const float *ada_w, *ada_b, *qkv_w, *scale_mul, *proj_w, *proj_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
     float* qkv_bias;     // owned: [q_bias, 0, v_bias]  (basic_var.py:93)
     void *kc, *vc;       // owned KV cache (Rmax, H, L, 64), fp32 or fp16 (desc.kv_dtype)
+    uint16_t *qkv_wp, *proj_wp, *fc1_wp, *fc2_wp;   // owned bf16x3 planes of the weights (desc.gemm_mode == 1)
     bool bound;
 };
 
@@ -92,6 +97,8 @@ struct sdvar_model {
     // owned
     float *lvl_pos, *cond, *cond_silu, *x0, *ada, *ada_head;
     float *xn, *qkv, *qbuf, *att, *hid;
+    uint16_t *xn_p, *att_p, *hid_p, *head_wp;     // bf16x3 planes of the GEMM inputs (desc.gemm_mode == 1)
+    size_t act_ps;                                // plane stride of xn_p / att_p (elements); hid_p uses 4x
     int* stage_of_tok;
     // run state
     int B, kv_len;
@@ -127,6 +134,7 @@ int sdvar_model_create(const sdvar_model_desc* desc, sdvar_model_t** out) {
     SDVAR_CHECK_ARG(desc->cvae == 32, "model_create: cvae must be 32 (got %d)", desc->cvae);
     SDVAR_CHECK_ARG(desc->max_batch >= 1 && desc->num_classes >= 1, "model_create: batch/classes");
     SDVAR_CHECK_ARG(desc->kv_dtype == 0 || desc->kv_dtype == 1, "model_create: kv_dtype %d (0 = fp32, 1 = fp16)", desc->kv_dtype);
+    SDVAR_CHECK_ARG(desc->gemm_mode == 0 || desc->gemm_mode == 1, "model_create: gemm_mode %d (0 = fp32 MFMA, 1 = bf16x3 split operands)", desc->gemm_mode);
     SDVAR_CHECK_ARG(desc->max_chunk_stages >= 1 && desc->max_chunk_stages <= SDVAR_MAX_STAGES, "model_create: max_chunk_stages %d", desc->max_chunk_stages);
     sdvar_model* m = new sdvar_model();
     m->d = *desc;
@@ -163,8 +171,20 @@ int sdvar_model_create(const sdvar_model_desc* desc, sdvar_model_t** out) {
     SDVAR_TRY(dmalloc(&m->qkv, M * 3 * C));
     SDVAR_TRY(dmalloc(&m->qbuf, M * C));
     SDVAR_TRY(dmalloc(&m->att, M * C));
-    SDVAR_TRY(dmalloc(&m->hid, M * 4 * C));
+    m->xn_p = m->att_p = m->hid_p = m->head_wp = nullptr; m->act_ps = M * C;
+    if (desc->gemm_mode == 1) {
+        SDVAR_TRY(dmalloc(&m->xn_p, 3 * M * C));
+        SDVAR_TRY(dmalloc(&m->att_p, 3 * M * C));
+        SDVAR_TRY(dmalloc(&m->hid_p, 3 * M * 4 * C));
+        SDVAR_TRY(dmalloc(&m->head_wp, 3 * (size_t)desc->vocab * C));
+    } else {
+        SDVAR_TRY(dmalloc(&m->hid, M * 4 * C));
+    }
     for (auto& b : m->blk) {
+        if (desc->gemm_mode == 1) {
+            SDVAR_TRY(dmalloc(&b.qkv_wp, 3 * 3 * C * C)); SDVAR_TRY(dmalloc(&b.proj_wp, 3 * C * C));
+            SDVAR_TRY(dmalloc(&b.fc1_wp, 3 * 4 * C * C)); SDVAR_TRY(dmalloc(&b.fc2_wp, 3 * 4 * C * C));
+        }
         SDVAR_TRY(dmalloc(&b.qkv_bias, 3 * C));
         const size_t kvb = R * (size_t)m->H * m->L * 64 * (desc->kv_dtype ? 2 : 4);
         SDVAR_HIP(hipMalloc(&b.kc, kvb));
@@ -179,6 +199,9 @@ int sdvar_model_destroy(sdvar_model_t* m) {
     float* bufs[] = {m->lvl_pos, m->cond, m->cond_silu, m->x0, m->ada, m->ada_head, m->xn, m->qkv, m->qbuf, m->att, m->hid};
     for (float* p : bufs) if (p) (void)hipFree(p);
     if (m->stage_of_tok) (void)hipFree(m->stage_of_tok);
+    uint16_t* pb[] = {m->xn_p, m->att_p, m->hid_p, m->head_wp};
+    for (uint16_t* p : pb) if (p) (void)hipFree(p);
+    for (auto& b : m->blk) { uint16_t* wp[] = {b.qkv_wp, b.proj_wp, b.fc1_wp, b.fc2_wp}; for (uint16_t* p : wp) if (p) (void)hipFree(p); }
     for (auto& b : m->blk) { if (b.qkv_bias) (void)hipFree(b.qkv_bias); if (b.kc) (void)hipFree(b.kc); if (b.vc) (void)hipFree(b.vc); }
     delete m;
     return SDVAR_OK;
@@ -206,13 +229,18 @@ int sdvar_model_bind_block(sdvar_model_t* m, int32_t i, const float* ada_w, cons
     SDVAR_HIP(hipMemsetAsync(b.qkv_bias, 0, 3 * C * sizeof(float), s));
     SDVAR_HIP(hipMemcpyAsync(b.qkv_bias, q_bias, C * sizeof(float), hipMemcpyDeviceToDevice, s));
     SDVAR_HIP(hipMemcpyAsync(b.qkv_bias + 2 * C, v_bias, C * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (m->d.gemm_mode == 1) {
+        SDVAR_TRY(split_planes(qkv_w, b.qkv_wp, 3 * C * C, 3 * C * C, s)); SDVAR_TRY(split_planes(proj_w, b.proj_wp, C * C, C * C, s));
+        SDVAR_TRY(split_planes(fc1_w, b.fc1_wp, 4 * C * C, 4 * C * C, s)); SDVAR_TRY(split_planes(fc2_w, b.fc2_wp, 4 * C * C, 4 * C * C, s));
+    }
     b.bound = true;
     return SDVAR_OK;
 }
 
-int sdvar_model_bind_head(sdvar_model_t* m, const float* nm_w, const float* nm_b, const float* head_w, const float* head_b) {
+int sdvar_model_bind_head(sdvar_model_t* m, const float* nm_w, const float* nm_b, const float* head_w, const float* head_b, void* stream) {
     SDVAR_CHECK_ARG(m && nm_w && nm_b && head_w && head_b, "bind_head: null argument");
     m->nm_w = nm_w; m->nm_b = nm_b; m->head_w = head_w; m->head_b = head_b; m->head_bound = true;
+    if (m->d.gemm_mode == 1) SDVAR_TRY(split_planes(head_w, m->head_wp, (size_t)m->d.vocab * m->C, (size_t)m->d.vocab * m->C, (hipStream_t)stream));
     return SDVAR_OK;
 }
 
@@ -282,30 +310,37 @@ int sdvar_stage_forward(sdvar_model_t* m, float* x, int32_t s0, int32_t n, float
     for (int j = 0; j < n; ++j) { qbeg[j] = lsum; lsum += m->lens[s0 + j]; vis[j] = m->cum[s0 + j]; lk += (double)m->lens[s0 + j] * vis[j]; }
     const int M = R * lsum, Ktot = m->kv_len + lsum;
     const double dM = M, dC = C;
+    const bool P = m->d.gemm_mode == 1;                               // bf16x3 split-operand GEMMs: inputs travel as planes
+    const size_t ps = (size_t)M * C;                                  // plane stride of this call's (M, C) activations
     for (int i = 0; i < m->d.depth; ++i) {
         const BlockW& b = m->blk[i];
         const float* ada = m->ada + (size_t)i * m->Rmax * 6 * C;      // (R, 6C): gamma1 gamma2 scale1 scale2 shift1 shift2
-        { ProfScope ps(2, 8 * dM * dC, 8 * dM * dC, s);
-          SDVAR_TRY(ln_modulate(x, ada + 2 * C, ada + 4 * C, m->xn, M, C, lsum, 6 * C, s)); }
-        { ProfScope ps(0, 2 * dM * 3 * dC * dC, 4 * (dM * dC + 3 * dC * dC + 3 * dM * dC), s);
-          SDVAR_TRY(gemm_f32_nt(m->xn, C, b.qkv_w, b.qkv_bias, m->qkv, 3 * C, M, 3 * C, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, s)); }
-        { ProfScope ps(3, 6 * dM * dC, 4 * 6 * dM * dC, s);
+        { ProfScope pp(2, 8 * dM * dC, (P ? 10 : 8) * dM * dC, s);
+          SDVAR_TRY(ln_modulate(x, ada + 2 * C, ada + 4 * C, m->xn, P ? m->xn_p : nullptr, ps, M, C, lsum, 6 * C, s)); }
+        { ProfScope pp(0, 2 * dM * 3 * dC * dC, 4 * (dM * dC + 3 * dC * dC + 3 * dM * dC), s);
+          if (P) SDVAR_TRY(gemm_bf16x3_nt(m->xn_p, ps, b.qkv_wp, (size_t)3 * C * C, b.qkv_bias, m->qkv, 3 * C, nullptr, 0, M, 3 * C, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, s));
+          else SDVAR_TRY(gemm_f32_nt(m->xn, C, b.qkv_w, b.qkv_bias, m->qkv, 3 * C, M, 3 * C, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, s)); }
+        { ProfScope pp(3, 6 * dM * dC, 4 * 6 * dM * dC, s);
           SDVAR_TRY(qk_norm_append(m->qkv, b.scale_mul, m->qbuf, b.kc, b.vc, m->d.kv_dtype, R, lsum, H, m->L, m->kv_len, s)); }
-        { ProfScope ps(1, 4.0 * R * H * 64.0 * lk, R * H * 64.0 * ((m->d.kv_dtype ? 4.0 : 8.0) * Ktot + 8.0 * lsum), s);
-          SDVAR_TRY(attention_f32(m->qbuf, b.kc, b.vc, m->d.kv_dtype, m->att, R, H, lsum, m->L, Ktot, n, qbeg, vis, s)); }
-        { ProfScope ps(0, 2 * dM * dC * dC, 4 * (3 * dM * dC + dC * dC), s);
-          SDVAR_TRY(gemm_f32_nt(m->att, C, b.proj_w, b.proj_b, x, C, M, C, C, EPI_GATED_RES, x, C, ada, lsum, 6 * C, s)); }
-        { ProfScope ps(2, 8 * dM * dC, 8 * dM * dC, s);
-          SDVAR_TRY(ln_modulate(x, ada + 3 * C, ada + 5 * C, m->xn, M, C, lsum, 6 * C, s)); }
-        { ProfScope ps(0, 2 * dM * 4 * dC * dC, 4 * (dM * dC + 4 * dC * dC + 4 * dM * dC), s);
-          SDVAR_TRY(gemm_f32_nt(m->xn, C, b.fc1_w, b.fc1_b, m->hid, 4 * C, M, 4 * C, C, EPI_BIAS_GELU, nullptr, 0, nullptr, 0, 0, s)); }
-        { ProfScope ps(0, 2 * dM * 4 * dC * dC, 4 * (4 * dM * dC + 4 * dC * dC + 2 * dM * dC), s);
-          SDVAR_TRY(gemm_f32_nt(m->hid, 4 * C, b.fc2_w, b.fc2_b, x, C, M, C, 4 * C, EPI_GATED_RES, x, C, ada + C, lsum, 6 * C, s)); }
+        { ProfScope pp(1, 4.0 * R * H * 64.0 * lk, R * H * 64.0 * ((m->d.kv_dtype ? 4.0 : 8.0) * Ktot + 8.0 * lsum), s);
+          SDVAR_TRY(attention_f32(m->qbuf, b.kc, b.vc, m->d.kv_dtype, m->att, P ? m->att_p : nullptr, ps, R, H, lsum, m->L, Ktot, n, qbeg, vis, s)); }
+        { ProfScope pp(0, 2 * dM * dC * dC, 4 * (3 * dM * dC + dC * dC), s);
+          if (P) SDVAR_TRY(gemm_bf16x3_nt(m->att_p, ps, b.proj_wp, (size_t)C * C, b.proj_b, x, C, nullptr, 0, M, C, C, EPI_GATED_RES, x, C, ada, lsum, 6 * C, s));
+          else SDVAR_TRY(gemm_f32_nt(m->att, C, b.proj_w, b.proj_b, x, C, M, C, C, EPI_GATED_RES, x, C, ada, lsum, 6 * C, s)); }
+        { ProfScope pp(2, 8 * dM * dC, (P ? 10 : 8) * dM * dC, s);
+          SDVAR_TRY(ln_modulate(x, ada + 3 * C, ada + 5 * C, m->xn, P ? m->xn_p : nullptr, ps, M, C, lsum, 6 * C, s)); }
+        { ProfScope pp(0, 2 * dM * 4 * dC * dC, 4 * (dM * dC + 4 * dC * dC + 4 * dM * dC), s);
+          if (P) SDVAR_TRY(gemm_bf16x3_nt(m->xn_p, ps, b.fc1_wp, (size_t)4 * C * C, b.fc1_b, nullptr, 0, m->hid_p, 4 * ps, M, 4 * C, C, EPI_BIAS_GELU, nullptr, 0, nullptr, 0, 0, s));
+          else SDVAR_TRY(gemm_f32_nt(m->xn, C, b.fc1_w, b.fc1_b, m->hid, 4 * C, M, 4 * C, C, EPI_BIAS_GELU, nullptr, 0, nullptr, 0, 0, s)); }
+        { ProfScope pp(0, 2 * dM * 4 * dC * dC, 4 * (4 * dM * dC + 4 * dC * dC + 2 * dM * dC), s);
+          if (P) SDVAR_TRY(gemm_bf16x3_nt(m->hid_p, 4 * ps, b.fc2_wp, (size_t)4 * C * C, b.fc2_b, x, C, nullptr, 0, M, C, 4 * C, EPI_GATED_RES, x, C, ada + C, lsum, 6 * C, s));
+          else SDVAR_TRY(gemm_f32_nt(m->hid, 4 * C, b.fc2_w, b.fc2_b, x, C, M, C, 4 * C, EPI_GATED_RES, x, C, ada + C, lsum, 6 * C, s)); }
     }
-    { ProfScope ps(2, 8 * dM * dC, 8 * dM * dC, s);
-      SDVAR_TRY(ln_modulate(x, m->ada_head, m->ada_head + C, m->xn, M, C, lsum, 2 * C, s)); }
-    { ProfScope ps(0, 2 * dM * dC * V, 4 * (dM * dC + dC * V + dM * V), s);
-      SDVAR_TRY(gemm_f32_nt(m->xn, C, m->head_w, m->head_b, logits, V, M, V, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, s)); }
+    { ProfScope pp(2, 8 * dM * dC, (P ? 10 : 8) * dM * dC, s);
+      SDVAR_TRY(ln_modulate(x, m->ada_head, m->ada_head + C, m->xn, P ? m->xn_p : nullptr, ps, M, C, lsum, 2 * C, s)); }
+    { ProfScope pp(0, 2 * dM * dC * V, 4 * (dM * dC + dC * V + dM * V), s);
+      if (P) SDVAR_TRY(gemm_bf16x3_nt(m->xn_p, ps, m->head_wp, (size_t)V * C, m->head_b, logits, V, nullptr, 0, M, V, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, s));
+      else SDVAR_TRY(gemm_f32_nt(m->xn, C, m->head_w, m->head_b, logits, V, M, V, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, s)); }
     m->kv_len = Ktot;
     return SDVAR_OK;
 }
@@ -426,21 +461,32 @@ int sdvar_op_gemm(const float* X, int32_t ldx, const float* W, const float* bias
     ProfScope ps(0, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), (hipStream_t)stream);
     return gemm_f32_nt(X, ldx, W, bias, out, ldo, M, N, K, epi, res, ldres, gate, rows_per_gate, gate_stride, (hipStream_t)stream);
 }
-int sdvar_op_ln_modulate(const float* x, const float* scale, const float* shift, float* out, int32_t rows, int32_t C, int32_t rows_per_img,
-                         int32_t mod_stride, void* stream) {
-    return ln_modulate(x, scale, shift, out, rows, C, rows_per_img, mod_stride, (hipStream_t)stream);
+int sdvar_op_ln_modulate(const float* x, const float* scale, const float* shift, float* out, uint16_t* out_planes, uint64_t plane_stride, int32_t rows,
+                         int32_t C, int32_t rows_per_img, int32_t mod_stride, void* stream) {
+    SDVAR_CHECK_ARG(out || out_planes, "op_ln_modulate: no output");
+    return ln_modulate(x, scale, shift, out, out_planes, (size_t)plane_stride, rows, C, rows_per_img, mod_stride, (hipStream_t)stream);
+}
+int sdvar_op_split_planes(const float* x, uint16_t* planes, uint64_t n, uint64_t plane_stride, void* stream) {
+    return split_planes(x, planes, (size_t)n, (size_t)plane_stride, (hipStream_t)stream);
+}
+int sdvar_op_gemm_bf16x3(const uint16_t* Xp, uint64_t x_plane_stride, const uint16_t* Wp, uint64_t w_plane_stride, const float* bias, float* out, int32_t ldo,
+                         uint16_t* out_planes, uint64_t out_plane_stride, int32_t M, int32_t N, int32_t K, int32_t epi, const float* res, int32_t ldres,
+                         const float* gate, int32_t rows_per_gate, int32_t gate_stride, void* stream) {
+    ProfScope ps(0, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), (hipStream_t)stream);
+    return gemm_bf16x3_nt(Xp, (size_t)x_plane_stride, Wp, (size_t)w_plane_stride, bias, out, ldo, out_planes, (size_t)out_plane_stride, M, N, K, epi, res, ldres,
+                          gate, rows_per_gate, gate_stride, (hipStream_t)stream);
 }
 int sdvar_op_qk_norm_append(const float* qkv, const float* scale_mul, float* q_out, void* k_cache, void* v_cache, int32_t kv_f16, int32_t R, int32_t l,
                             int32_t H, int32_t Lmax, int32_t pos0, void* stream) {
     return qk_norm_append(qkv, scale_mul, q_out, k_cache, v_cache, kv_f16, R, l, H, Lmax, pos0, (hipStream_t)stream);
 }
-int sdvar_op_attention(const float* q, const void* kc, const void* vc, int32_t kv_f16, float* out, int32_t R, int32_t H, int32_t l, int32_t Lmax,
-                       int32_t Ktot, int32_t n, const int32_t* qbeg, const int32_t* vis, void* stream) {
+int sdvar_op_attention(const float* q, const void* kc, const void* vc, int32_t kv_f16, float* out, uint16_t* out_planes, uint64_t plane_stride, int32_t R,
+                       int32_t H, int32_t l, int32_t Lmax, int32_t Ktot, int32_t n, const int32_t* qbeg, const int32_t* vis, void* stream) {
     SDVAR_CHECK_ARG(qbeg && vis && n >= 1 && n <= SDVAR_MAX_STAGES, "op_attention: bad stage table");
     double lk = 0;
     for (int j = 0; j < n; ++j) lk += (double)((j + 1 < n ? qbeg[j + 1] : l) - qbeg[j]) * vis[j];
     ProfScope ps(1, 4.0 * R * H * 64.0 * lk, R * H * 64.0 * ((kv_f16 ? 4.0 : 8.0) * Ktot + 8.0 * l), (hipStream_t)stream);
-    return attention_f32(q, kc, vc, kv_f16, out, R, H, l, Lmax, Ktot, n, qbeg, vis, (hipStream_t)stream);
+    return attention_f32(q, kc, vc, kv_f16, out, out_planes, (size_t)plane_stride, R, H, l, Lmax, Ktot, n, qbeg, vis, (hipStream_t)stream);
 }
 int sdvar_op_noise_fill(float* q, int32_t B, int32_t l, int32_t V, uint64_t seed, uint32_t draw, uint32_t image_offset, void* stream) {
     return noise_fill(q, B, l, V, seed, draw, image_offset, (hipStream_t)stream);
@@ -450,6 +496,7 @@ int sdvar_debug_set_gemm_cfg(int32_t bm, int32_t split) {
     SDVAR_CHECK_ARG(bm == 0 || bm == 32 || bm == 64 || bm == 128, "debug_set_gemm_cfg: bm %d", bm);
     SDVAR_CHECK_ARG(split >= 0 && split <= 64, "debug_set_gemm_cfg: split %d", split);
     debug_set_gemm_cfg(bm, split);
+    debug_set_gemm_cfg_p(bm, split);
     return SDVAR_OK;
 }
 

@@ -27,6 +27,7 @@ constexpr int KSTR = 68;            // padded K row (floats)
 
 struct AttnArgs {
     const float* q; const void* kc; const void* vc; float* out;     // kc/vc: fp32 or fp16 (template KVH)
+    uint16_t* outp; size_t ops;                                     // optional bf16x3 planes output instead of `out`
     int R, H, l, Lmax, Ktot;
     int n_chunk;
     int qbeg[ATT_MAX_CHUNK + 1];
@@ -195,25 +196,39 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(AttnArgs a) {
 
     if (wave_active && qi_raw < a.l) {
         const float inv = 1.0f / l_run;
-        float* po = a.out + ((size_t)r * a.l + qi_raw) * (a.H * 64) + h * 64 + 4 * lh;
+        const size_t obase = ((size_t)r * a.l + qi_raw) * (a.H * 64) + h * 64 + 4 * lh;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             f32x4 v0, v1;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v0[e] = o0[4 * g + e] * inv; v1[e] = o1[4 * g + e] * inv; }
-            *reinterpret_cast<f32x4*>(po + 8 * g) = v0;
-            *reinterpret_cast<f32x4*>(po + 32 + 8 * g) = v1;
+            if (a.outp) {
+                uint16_t q0[3][4], q1[3][4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { split3(v0[e], q0[0][e], q0[1][e], q0[2][e]); split3(v1[e], q1[0][e], q1[1][e], q1[2][e]); }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    uint2 w0, w1;
+                    w0.x = (uint32_t)q0[k][0] | ((uint32_t)q0[k][1] << 16); w0.y = (uint32_t)q0[k][2] | ((uint32_t)q0[k][3] << 16);
+                    w1.x = (uint32_t)q1[k][0] | ((uint32_t)q1[k][1] << 16); w1.y = (uint32_t)q1[k][2] | ((uint32_t)q1[k][3] << 16);
+                    *reinterpret_cast<uint2*>(a.outp + k * a.ops + obase + 8 * g) = w0;
+                    *reinterpret_cast<uint2*>(a.outp + k * a.ops + obase + 32 + 8 * g) = w1;
+                }
+            } else {
+                *reinterpret_cast<f32x4*>(a.out + obase + 8 * g) = v0;
+                *reinterpret_cast<f32x4*>(a.out + obase + 32 + 8 * g) = v1;
+            }
         }
     }
 }
 
-int attention_f32(const float* q, const void* kc, const void* vc, int kv_f16, float* out, int R, int H, int l, int Lmax, int Ktot, int n_chunk,
-                  const int* qbeg, const int* vis, hipStream_t stream) {
-    SDVAR_CHECK_ARG(q && kc && vc && out, "attention: null operand");
+int attention_f32(const float* q, const void* kc, const void* vc, int kv_f16, float* out, uint16_t* outp, size_t ops, int R, int H, int l, int Lmax,
+                  int Ktot, int n_chunk, const int* qbeg, const int* vis, hipStream_t stream) {
+    SDVAR_CHECK_ARG(q && kc && vc && (out || outp), "attention: null operand");
     SDVAR_CHECK_ARG(n_chunk >= 1 && n_chunk <= ATT_MAX_CHUNK, "attention: chunk of %d stages unsupported (max %d)", n_chunk, ATT_MAX_CHUNK);
     SDVAR_CHECK_ARG(R > 0 && H > 0 && l > 0 && Ktot >= l && Ktot <= Lmax, "attention: bad lengths l=%d Ktot=%d Lmax=%d", l, Ktot, Lmax);
     AttnArgs a;
-    a.q = q; a.kc = kc; a.vc = vc; a.out = out; a.R = R; a.H = H; a.l = l; a.Lmax = Lmax; a.Ktot = Ktot; a.n_chunk = n_chunk;
+    a.q = q; a.kc = kc; a.vc = vc; a.out = out; a.outp = outp; a.ops = ops; a.R = R; a.H = H; a.l = l; a.Lmax = Lmax; a.Ktot = Ktot; a.n_chunk = n_chunk;
     for (int j = 0; j < n_chunk; ++j) {
         a.qbeg[j] = qbeg[j]; a.vis[j] = vis[j];
         SDVAR_CHECK_ARG(vis[j] >= 1 && vis[j] <= Ktot && (j == 0 ? qbeg[0] == 0 : (qbeg[j] > qbeg[j - 1] && vis[j] >= vis[j - 1])), "attention: bad stage table at %d", j);

@@ -60,6 +60,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return base + (bid >> 3);
 }
 
+// ---- fp32 -> three bf16 planes holding 8 significand bits each (truncation split): x == p0 + p1 + p2 exactly for
+// finite normal x (each residual is exact in fp32 and the last one has at most 8 significant bits).
+__device__ __forceinline__ void split3(float x, uint16_t& p0, uint16_t& p1, uint16_t& p2) {
+    const uint32_t u0 = __float_as_uint(x) & 0xFFFF0000u;
+    const float r1 = x - __uint_as_float(u0);
+    const uint32_t u1 = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(u1);
+    p0 = (uint16_t)(u0 >> 16); p1 = (uint16_t)(u1 >> 16); p2 = (uint16_t)(__float_as_uint(r2) >> 16);
+}
+
 // ---- Philox4x32-10 (must match sdvar_amd/noise.py bit for bit) ----------------------------------------------------
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
                                               uint32_t out[4]) {

@@ -18,8 +18,8 @@ namespace sdvar {
 constexpr int LN_MAX_V4 = 8;   // up to C = 64 lanes * 8 * 4 = 2048
 
 __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restrict__ x, const float* __restrict__ scale,
-                                                          const float* __restrict__ shift, float* __restrict__ out, int rows, int C,
-                                                          int rows_per_img, int mod_stride, float eps) {
+                                                          const float* __restrict__ shift, float* __restrict__ out, uint16_t* __restrict__ outp,
+                                                          size_t ops, int rows, int C, int rows_per_img, int mod_stride, float eps) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int nv = C >> 2;
@@ -54,16 +54,28 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restric
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = ((v[i][e] - mean) * rstd) * (sc[e] + 1.0f) + sh[e];
-            po[idx] = o;
+            if (outp) {                      // bf16x3 planes for the split-operand GEMM (gemm_bf16x3.hip)
+                uint16_t q[3][4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split3(o[e], q[0][e], q[1][e], q[2][e]);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    uint2 w;
+                    w.x = (uint32_t)q[k][0] | ((uint32_t)q[k][1] << 16); w.y = (uint32_t)q[k][2] | ((uint32_t)q[k][3] << 16);
+                    *reinterpret_cast<uint2*>(outp + k * ops + (size_t)row * C + 4 * idx) = w;
+                }
+            } else {
+                po[idx] = o;
+            }
         }
     }
 }
 
-int ln_modulate(const float* x, const float* scale, const float* shift, float* out, int rows, int C, int rows_per_img,
+int ln_modulate(const float* x, const float* scale, const float* shift, float* out, uint16_t* outp, size_t ops, int rows, int C, int rows_per_img,
                 int mod_stride, hipStream_t stream) {
     SDVAR_CHECK_ARG(C % 4 == 0 && C <= 64 * 4 * LN_MAX_V4 && rows > 0 && rows_per_img > 0, "ln_modulate: bad shape rows=%d C=%d", rows, C);
     SDVAR_CHECK_ARG(mod_stride % 4 == 0, "ln_modulate: mod_stride must be a multiple of 4");
-    hipLaunchKernelGGL(ln_modulate_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, scale, shift, out, rows, C, rows_per_img, mod_stride, 1e-6f);
+    hipLaunchKernelGGL(ln_modulate_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, scale, shift, out, outp, ops, rows, C, rows_per_img, mod_stride, 1e-6f);
     SDVAR_LAUNCH_CHECK();
     return SDVAR_OK;
 }

@@ -179,6 +179,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 static float* g_ws = nullptr;                      // split-K slabs; one stream at a time per process (see sdvar_hip.h)
 constexpr size_t WS_FLOATS = (size_t)24 << 20;     // 96 MiB
 
+float* splitk_workspace(size_t* floats) {          // shared with gemm_bf16x3.hip
+    if (floats) *floats = WS_FLOATS;
+    if (!g_ws && hipMalloc((void**)&g_ws, WS_FLOATS * sizeof(float)) != hipSuccess) { set_error("split-K workspace allocation failed"); return nullptr; }
+    return g_ws;
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 static int launch_cfg(GemmArgs a, int epi, int split, hipStream_t stream) {
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);

@@ -1,0 +1,325 @@
+// fp32-accurate "NT" GEMM on the gfx950 bf16 matrix cores with split operands (bf16x3):
+//     out[M,N] = epilogue( X[M,K] . W[N,K]^T + bias[N] ),   X = X1 + X2 + X3,  W = W1 + W2 + W3  (exactly)
+// where each Xi / Wi is a bf16 tensor holding 8 significand bits of the fp32 value (truncation split, common.h split3):
+// 3 x 8 = 24 bits, so the three planes reproduce the fp32 number exactly.  Of the nine plane products the six with
+// i + j <= 4 are evaluated with v_mfma_f32_32x32x16_bf16 (bf16 x bf16 products are exact in fp32; fp32 accumulate); the
+// dropped terms are <= 3 * 2^-24 relative per product.  Measured on random operands (K = 1024, fp64 reference): max error
+// 1.2e-6 vs 2.5e-6 for a plain fp32 GEMM - the fp32 accumulation order dominates either way - while the matrix pipe
+// spends 6 x 32 cycles per 16 k instead of 8 x 64: 2.67x the throughput of v_mfma_f32_32x32x2_f32 (gemm.hip).
+//
+// Operands are PLANAR: planes[3][rows][K] bf16.  Weights are split once at bind time; activations are written as planes
+// by their producers (ln_modulate, attention, the fc1 GELU epilogue), so the GEMM itself does no conversion work.
+//
+// Tiling: BM x 128 x 32 (BM = 128 / 64 / 32), 4 waves, one LDS stage (rows padded to 80 bytes: conflict-free
+// ds_read_b128 of the 8-k fragments) refilled from registers that prefetch the next K-step while the MFMAs run;
+// tiles are walked in 8-wide column groups inside each XCD's block range so that co-resident workgroups share both
+// operand panels in the per-XCD L2.  Split-K and the epilogues are those of gemm.hip.
+#include "common.h"
+
+namespace sdvar {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+enum { PEPI_BIAS = 0, PEPI_BIAS_GELU_PLANES = 1, PEPI_GATED_RES = 2, PEPI_PARTIAL = 3 };
+
+constexpr int PBK = 32;             // k per LDS stage
+constexpr int PROW = 40;            // padded row, in bf16 elements (80 bytes)
+constexpr int PBN = 128;
+
+__device__ __forceinline__ float gelu_tanh_p(float x) {
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    return 0.5f * x * (1.0f + tanhf(k0 * (x + k1 * x * x * x)));
+}
+
+struct GemmPArgs {
+    const uint16_t* X; const uint16_t* W;        // planes [3][M][K], [3][N][K]
+    size_t xps, wps;                             // plane strides in elements
+    const float* bias; float* out; uint16_t* outp; size_t ops;
+    const float* res; const float* gate;
+    int M, N, K, ldo, ldres, rows_per_gate, gate_stride, split, k_per_split;
+};
+
+template <int BM, int WAVES_M, int WAVES_N, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmPArgs a) {
+    constexpr int WM = BM / WAVES_M, WN = PBN / WAVES_N, TM = WM / 32, TN = WN / 32;
+    static_assert(WAVES_M * WAVES_N == 4 && TM >= 1 && TN >= 1, "bad wave layout");
+    constexpr int XCH = (BM * 4 + 255) / 256, WCH = PBN * 4 / 256;   // 16-byte chunks per plane per thread
+    extern __shared__ __attribute__((aligned(16))) uint16_t psm[];
+    uint16_t* sA = psm;                       // [3][BM][PROW]
+    uint16_t* sB = psm + 3 * BM * PROW;       // [3][PBN][PROW]
+
+    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + PBN - 1) / PBN, ntile = tiles_m * tiles_n;
+    const int ks = blockIdx.x / ntile;
+    const int lid = xcd_remap(blockIdx.x - ks * ntile, ntile);
+    // 8-wide column groups: lid -> (group g, row tm, column c in group)
+    const int G = 8, per_group = tiles_m * G;
+    const int g = lid / per_group, rem = lid - g * per_group;
+    const int gw = min(G, tiles_n - g * G);              // width of the (possibly partial) last group
+    const int tm = rem / gw, tn = g * G + rem % gw;
+    const int m0 = tm * BM, n0 = tn * PBN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N, li = lane & 31, lh = lane >> 5;
+
+    f32x4 rx[3][XCH], rw[3][WCH];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < XCH; ++i) {
+            const int c = tid + 256 * i, row = c >> 2, col = (c & 3) * 8;
+            const int m = m0 + row;
+            const bool ok = (BM * 4 >= 256 || c < BM * 4) && m < a.M;
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                rx[p][i] = ok ? *reinterpret_cast<const f32x4*>(a.X + p * a.xps + (size_t)m * a.K + k0 + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) {
+            const int c = tid + 256 * i, row = c >> 2, col = (c & 3) * 8;
+            const int n = n0 + row;
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                rw[p][i] = (n < a.N) ? *reinterpret_cast<const f32x4*>(a.W + p * a.wps + (size_t)n * a.K + k0 + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < XCH; ++i) {
+            const int c = tid + 256 * i, row = c >> 2, col = (c & 3) * 8;
+            if (BM * 4 >= 256 || c < BM * 4) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) *reinterpret_cast<f32x4*>(sA + (p * BM + row) * PROW + col) = rx[p][i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) {
+            const int c = tid + 256 * i, row = c >> 2, col = (c & 3) * 8;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<f32x4*>(sB + (p * PBN + row) * PROW + col) = rw[p][i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int kt0 = ks * a.k_per_split;
+    const int nk = min(a.K / PBK - kt0, a.k_per_split);
+    load_tile(kt0 * PBK);
+    store_tile();
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) load_tile((kt0 + kt + 1) * PBK);
+        const uint16_t* pa = sA + (wm * WM + li) * PROW + 8 * lh;
+        const uint16_t* pb = sB + (wn * WN + li) * PROW + 8 * lh;
+#pragma unroll
+        for (int s = 0; s < PBK / 16; ++s) {
+            bf16x8 fa[3][TM], fb[3][TN];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[p][i] = *reinterpret_cast<const bf16x8*>(pa + (p * BM + i * 32) * PROW + 16 * s);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[p][j] = *reinterpret_cast<const bf16x8*>(pb + (p * PBN + j * 32) * PROW + 16 * s);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    // smallest terms first: (1,3) (2,2) (3,1) (1,2) (2,1) (1,1)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[2][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[1][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2][i], fb[0][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[1][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[0][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[0][j], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();                        // every wave is done reading this stage
+        if (kt + 1 < nk) { store_tile(); __syncthreads(); }
+    }
+
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WN + j * 32 + li;
+        if (n >= a.N) continue;
+        const float bv = (EPI != PEPI_PARTIAL && a.bias) ? a.bias[n] : 0.f;
+        float* outp = (EPI == PEPI_PARTIAL) ? a.out + (size_t)ks * a.M * a.ldo : a.out;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= a.M) continue;
+                float v = acc[i][j][r] + bv;
+                if (EPI == PEPI_BIAS_GELU_PLANES) {
+                    uint16_t p0, p1, p2;
+                    split3(gelu_tanh_p(v), p0, p1, p2);
+                    const size_t o = (size_t)m * a.N + n;
+                    a.outp[o] = p0; a.outp[a.ops + o] = p1; a.outp[2 * a.ops + o] = p2;
+                } else {
+                    if (EPI == PEPI_GATED_RES) v = a.res[(size_t)m * a.ldres + n] + v * a.gate[(size_t)(m / a.rows_per_gate) * a.gate_stride + n];
+                    outp[(size_t)m * a.ldo + n] = v;
+                }
+            }
+        }
+    }
+}
+
+// out = epi( sum_s slab[s] + bias ) for the split-K path; the GELU variant writes planes
+template <int EPI>
+__global__ __launch_bounds__(256) void splitk_reduce_p_kernel(const float* __restrict__ ws, int split, const float* __restrict__ bias, float* out,
+                                                              uint16_t* outp, size_t ops, const float* res, const float* __restrict__ gate, int M, int N,
+                                                              int ldo, int ldres, int rows_per_gate, int gate_stride) {
+    const int nv = N >> 2;
+    const size_t total = (size_t)M * nv, slab = (size_t)M * N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / nv), n = (int)(i % nv) * 4;
+        f32x4 acc = *reinterpret_cast<const f32x4*>(ws + (size_t)m * N + n);
+        for (int s = 1; s < split; ++s) {
+            const f32x4 p = *reinterpret_cast<const f32x4*>(ws + s * slab + (size_t)m * N + n);
+            acc[0] += p[0]; acc[1] += p[1]; acc[2] += p[2]; acc[3] += p[3];
+        }
+        uint16_t pl[3][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = acc[e] + (bias ? bias[n + e] : 0.f);
+            if (EPI == PEPI_BIAS_GELU_PLANES) { split3(gelu_tanh_p(v), pl[0][e], pl[1][e], pl[2][e]); continue; }
+            if (EPI == PEPI_GATED_RES) v = res[(size_t)m * ldres + n + e] + v * gate[(size_t)(m / rows_per_gate) * gate_stride + n + e];
+            out[(size_t)m * ldo + n + e] = v;
+        }
+        if (EPI == PEPI_BIAS_GELU_PLANES) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                uint2 w;
+                w.x = (uint32_t)pl[p][0] | ((uint32_t)pl[p][1] << 16); w.y = (uint32_t)pl[p][2] | ((uint32_t)pl[p][3] << 16);
+                *reinterpret_cast<uint2*>(outp + p * ops + (size_t)m * N + n) = w;
+            }
+        }
+    }
+}
+
+// fp32 (rows, cols) -> planes [3][rows][cols] bf16 (weights at bind time, and any activation without a fused producer)
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, uint16_t* __restrict__ p, size_t n, size_t ps) {
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * blockDim.x * 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + i);
+        uint16_t q[3][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split3(v[e], q[0][e], q[1][e], q[2][e]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            uint2 w;
+            w.x = (uint32_t)q[k][0] | ((uint32_t)q[k][1] << 16); w.y = (uint32_t)q[k][2] | ((uint32_t)q[k][3] << 16);
+            *reinterpret_cast<uint2*>(p + k * ps + i) = w;
+        }
+    }
+}
+
+int split_planes(const float* x, uint16_t* planes, size_t n, size_t plane_stride, hipStream_t stream) {
+    SDVAR_CHECK_ARG(x && planes && n % 4 == 0 && plane_stride % 4 == 0, "split_planes: need a multiple of 4 elements");
+    const size_t blocks = (n / 4 + 255) / 256;
+    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream, x, planes, n, plane_stride);
+    SDVAR_LAUNCH_CHECK();
+    return SDVAR_OK;
+}
+
+float* splitk_workspace(size_t* floats);     // gemm.hip: the shared slab workspace
+
+static int g_force_bm_p = 0, g_force_split_p = 0;
+void debug_set_gemm_cfg_p(int bm, int split) { g_force_bm_p = bm; g_force_split_p = split; }
+
+// same cost model as gemm.hip::choose_cfg with this kernel's constants: 6 MFMAs x 32 cycles per 16 k per 32x32 tile
+static void choose_cfg_p(int M, int N, int K, size_t ws_floats, int* bm_out, int* split_out) {
+    const int nkt = K / PBK, tiles_n = (N + PBN - 1) / PBN;
+    double best = 1e30; int bbm = 128, bs = 1;
+    const int bms[3] = {128, 64, 32};
+    // constants fitted to tools/gemm_bench.py --mode bf16x3 --sweep --dump (d12 / d16 shapes, single stages and gamma = 2
+    // chunks): geometric-mean regret 2.8 % against the best swept configuration
+    const int resident[3] = {2, 3, 3};
+    const double lat[4] = {0.0, 2.0, 1.2, 1.1};
+    for (int bi = 0; bi < 3; ++bi) {
+        const int bm = bms[bi], res = resident[bi];
+        const int tiles = ((M + bm - 1) / bm) * tiles_n;
+        const double ktile = 384.0 * (bm / 32) * (bm == 32 ? 1.3 : (bm == 64 ? 1.2 : 1.0));   // 6 MFMAs x 32 cycles x 2 k16-steps per 32x32 sub-tile
+        for (int split = 1; split <= 32 && split <= nkt / 2; ++split) {
+            if (split > 1 && ((size_t)split * M * N > ws_floats || N % 4)) break;
+            const int kps = (nkt + split - 1) / split;
+            if ((nkt + kps - 1) / kps != split) continue;
+            const long blocks = (long)tiles * split;
+            const long per_cu = (blocks + 255) / 256;
+            const double T = kps * (ktile + 260.0) + 8000.0 + 20.0 * bm;    // + barriers / LDS refill per K-step, prologue + epilogue
+            const long full = per_cu / res, rem = per_cu % res;
+            double cyc = full * res * T * lat[res] + (rem ? rem * T * lat[rem] : 0.0);
+            if (split > 1) cyc += 2000.0 + (double)(split + 1) * M * N * 4.0 / 3000.0;
+            if (cyc < best) { best = cyc; bbm = bm; bs = split; }
+        }
+    }
+    *bm_out = bbm; *split_out = bs;
+}
+
+template <int BM, int WAVES_M, int WAVES_N>
+static int launch_p(GemmPArgs a, int epi, int split, hipStream_t stream) {
+    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + PBN - 1) / PBN);
+    const size_t lds = 3 * (size_t)(BM + PBN) * PROW * sizeof(uint16_t);
+    dim3 block(256);
+    const int nkt = a.K / PBK;
+    if (split > 1) {
+        size_t wsf = 0;
+        float* ws = splitk_workspace(&wsf);
+        if (!ws) return SDVAR_ERR_HIP;
+        GemmPArgs p = a;
+        p.out = ws; p.ldo = a.N; p.split = split; p.k_per_split = (nkt + split - 1) / split;
+        hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, WAVES_M, WAVES_N, PEPI_PARTIAL>), dim3(tiles * split), block, lds, stream, p);
+        SDVAR_LAUNCH_CHECK();
+        const size_t total = (size_t)a.M * (a.N / 4);
+        const int rgrid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+        switch (epi) {
+            case PEPI_BIAS: hipLaunchKernelGGL(splitk_reduce_p_kernel<PEPI_BIAS>, dim3(rgrid), block, 0, stream, ws, split, a.bias, a.out, a.outp, a.ops, a.res, a.gate, a.M, a.N, a.ldo, a.ldres, a.rows_per_gate, a.gate_stride); break;
+            case PEPI_BIAS_GELU_PLANES: hipLaunchKernelGGL(splitk_reduce_p_kernel<PEPI_BIAS_GELU_PLANES>, dim3(rgrid), block, 0, stream, ws, split, a.bias, a.out, a.outp, a.ops, a.res, a.gate, a.M, a.N, a.ldo, a.ldres, a.rows_per_gate, a.gate_stride); break;
+            default: hipLaunchKernelGGL(splitk_reduce_p_kernel<PEPI_GATED_RES>, dim3(rgrid), block, 0, stream, ws, split, a.bias, a.out, a.outp, a.ops, a.res, a.gate, a.M, a.N, a.ldo, a.ldres, a.rows_per_gate, a.gate_stride); break;
+        }
+        SDVAR_LAUNCH_CHECK();
+        return SDVAR_OK;
+    }
+    a.split = 1; a.k_per_split = nkt;
+    switch (epi) {
+        case PEPI_BIAS: hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, WAVES_M, WAVES_N, PEPI_BIAS>), dim3(tiles), block, lds, stream, a); break;
+        case PEPI_BIAS_GELU_PLANES: hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, WAVES_M, WAVES_N, PEPI_BIAS_GELU_PLANES>), dim3(tiles), block, lds, stream, a); break;
+        default: hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, WAVES_M, WAVES_N, PEPI_GATED_RES>), dim3(tiles), block, lds, stream, a); break;
+    }
+    SDVAR_LAUNCH_CHECK();
+    return SDVAR_OK;
+}
+
+// X planes [3][M][K] (plane stride xps), W planes [3][N][K] (plane stride wps).  epi: 0 bias -> out fp32; 1 bias + GELU ->
+// outp planes [3][M][N] (plane stride ops); 2 gated residual -> out fp32.
+int gemm_bf16x3_nt(const uint16_t* X, size_t xps, const uint16_t* W, size_t wps, const float* bias, float* out, int ldo, uint16_t* outp, size_t ops,
+                   int M, int N, int K, int epi, const float* res, int ldres, const float* gate, int rows_per_gate, int gate_stride, hipStream_t stream) {
+    SDVAR_CHECK_ARG(X && W, "gemm_bf16x3: null operand");
+    SDVAR_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % PBK == 0, "gemm_bf16x3: need K %% 32 == 0 (M=%d N=%d K=%d)", M, N, K);
+    SDVAR_CHECK_ARG(epi >= PEPI_BIAS && epi <= PEPI_GATED_RES, "gemm_bf16x3: unknown epilogue %d", epi);
+    SDVAR_CHECK_ARG(epi == PEPI_BIAS_GELU_PLANES ? (outp != nullptr && N % 4 == 0) : (out != nullptr && ldo >= N), "gemm_bf16x3: missing output");
+    SDVAR_CHECK_ARG(((uintptr_t)X % 16) == 0 && ((uintptr_t)W % 16) == 0 && xps % 8 == 0 && wps % 8 == 0, "gemm_bf16x3: planes must be 16-byte aligned");
+    if (epi == PEPI_GATED_RES) SDVAR_CHECK_ARG(res && gate && rows_per_gate > 0 && ldres >= N, "gemm_bf16x3: gated-residual epilogue needs res/gate");
+    GemmPArgs a{X, W, xps, wps, bias, out, outp, ops, res, gate, M, N, K, ldo, ldres, rows_per_gate > 0 ? rows_per_gate : 1, gate_stride, 1, K / PBK};
+    size_t wsf = 0;
+    (void)splitk_workspace(&wsf);
+    int bm, split;
+    choose_cfg_p(M, N, K, wsf, &bm, &split);
+    if (g_force_bm_p) bm = g_force_bm_p;
+    if (g_force_split_p) {
+        split = g_force_split_p;
+        const int nkt = K / PBK;
+        if (split > nkt) split = nkt;
+        while (split > 1 && (size_t)split * M * N > wsf) --split;
+        const int kps = (nkt + split - 1) / split;
+        split = (nkt + kps - 1) / kps;
+    }
+    if (bm == 32) return launch_p<32, 1, 4>(a, epi, split, stream);
+    if (bm == 64) return launch_p<64, 2, 2>(a, epi, split, stream);
+    return launch_p<128, 2, 2>(a, epi, split, stream);
+}
+
+}  // namespace sdvar

@@ -25,6 +25,9 @@ from .noise import exponential_noise
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsdvar_hip.so")
 MAX_STAGES = 16
+# GEMM arithmetic of the transformer blocks: 'f32' = fp32-in/fp32-accumulate MFMA; 'bf16x3' = exact 3-way bf16 split of both
+# operands, 6 bf16 MFMA products, fp32 accumulate (fp32-accurate, 2.67x the matrix-pipe throughput).  See DESIGN.md section 4.
+DEFAULT_GEMM_MODE = "bf16x3"
 PROF_CLASSES = ("gemm", "attention", "ln_modulate", "qk_norm_append", "sampler", "verify", "quant", "embed_misc")
 
 
@@ -34,7 +37,7 @@ class SdvarError(RuntimeError):
 
 class _ModelDesc(C.Structure):
     _fields_ = [("depth", C.c_int32), ("n_stages", C.c_int32), ("patch_nums", C.c_int32 * MAX_STAGES), ("vocab", C.c_int32),
-                ("cvae", C.c_int32), ("num_classes", C.c_int32), ("max_batch", C.c_int32), ("max_chunk_stages", C.c_int32), ("kv_dtype", C.c_int32)]
+                ("cvae", C.c_int32), ("num_classes", C.c_int32), ("max_batch", C.c_int32), ("max_chunk_stages", C.c_int32), ("kv_dtype", C.c_int32), ("gemm_mode", C.c_int32)]
 
 
 _P, _I, _D, _U64, _U32 = C.c_void_p, C.c_int32, C.c_double, C.c_uint64, C.c_uint32
@@ -46,7 +49,7 @@ _SIGNATURES = {
     "sdvar_model_destroy": (_I, [_P]),
     "sdvar_model_bind_embed": (_I, [_P] * 8),
     "sdvar_model_bind_block": (_I, [_P, _I] + [_P] * 13),
-    "sdvar_model_bind_head": (_I, [_P] * 5),
+    "sdvar_model_bind_head": (_I, [_P] * 6),
     "sdvar_model_begin": (_I, [_P, _I, _P, _P]),
     "sdvar_model_place_first": (_I, [_P, _P, _I, _P]),
     "sdvar_kv_len": (_I, [_P]),
@@ -60,9 +63,11 @@ _SIGNATURES = {
     "sdvar_cfg_sample": (_I, [_P, _I, _I, _I, _D, _I, _D, _P, _U64, _U32, _U32, _P, _I, _P, _P]),
     "sdvar_verify_accept": (_I, [_P, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_D), _P, _I, _D, _P, _P, _P]),
     "sdvar_op_gemm": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P]),
-    "sdvar_op_ln_modulate": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "sdvar_op_ln_modulate": (_I, [_P, _P, _P, _P, _P, _U64, _I, _I, _I, _I, _P]),
+    "sdvar_op_split_planes": (_I, [_P, _P, _U64, _U64, _P]),
+    "sdvar_op_gemm_bf16x3": (_I, [_P, _U64, _P, _U64, _P, _P, _I, _P, _U64, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P]),
     "sdvar_op_qk_norm_append": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "sdvar_op_attention": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), _P]),
+    "sdvar_op_attention": (_I, [_P, _P, _P, _I, _P, _P, _U64, _I, _I, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), _P]),
     "sdvar_op_noise_fill": (_I, [_P, _I, _I, _I, _U64, _U32, _U32, _P]),
     "sdvar_debug_set_gemm_cfg": (_I, [_I, _I]),
     "sdvar_prof_enable": (_I, [_I]),
@@ -115,7 +120,7 @@ class ModelCtx:
     """sdvar_model_t for one VAR transformer given its state_dict (reference key names)."""
 
     def __init__(self, sd: Dict[str, torch.Tensor], depth: int, patch_nums: Sequence[int], max_batch: int, max_chunk: int,
-                 device, num_classes: int = 1000, kv_fp16: bool = False):
+                 device, num_classes: int = 1000, kv_fp16: bool = False, gemm_mode: Optional[str] = None):
         self.lib = load_library()
         self.lad = as_ladder(patch_nums)
         self.depth, self.Cw, self.H = depth, 64 * depth, depth
@@ -126,6 +131,10 @@ class ModelCtx:
         d.depth, d.n_stages, d.vocab, d.cvae, d.num_classes = depth, self.lad.S, self.V, sd["word_embed.weight"].shape[1], num_classes
         d.max_batch, d.max_chunk_stages, d.kv_dtype = max_batch, max_chunk, (1 if kv_fp16 else 0)
         self.kv_fp16 = bool(kv_fp16)
+        self.gemm_mode = gemm_mode or os.environ.get("SDVAR_GEMM_MODE", DEFAULT_GEMM_MODE)
+        if self.gemm_mode not in ("f32", "bf16x3"):
+            raise SdvarError(f"gemm_mode {self.gemm_mode!r}: expected 'f32' or 'bf16x3'")
+        d.gemm_mode = 1 if self.gemm_mode == "bf16x3" else 0
         for i, p in enumerate(self.lad.patch_nums):
             d.patch_nums[i] = p
         self.h = C.c_void_p()
@@ -148,7 +157,7 @@ class ModelCtx:
                 self.h, i, w(p + "ada_lin.1.weight"), w(p + "ada_lin.1.bias"), w(p + "attn.mat_qkv.weight"), w(p + "attn.q_bias"),
                 w(p + "attn.v_bias"), w(p + "attn.scale_mul_1H11"), w(p + "attn.proj.weight"), w(p + "attn.proj.bias"),
                 w(p + "ffn.fc1.weight"), w(p + "ffn.fc1.bias"), w(p + "ffn.fc2.weight"), w(p + "ffn.fc2.bias"), st))
-        _check(self.lib.sdvar_model_bind_head(self.h, w("head_nm.ada_lin.1.weight"), w("head_nm.ada_lin.1.bias"), w("head.weight"), w("head.bias")))
+        _check(self.lib.sdvar_model_bind_head(self.h, w("head_nm.ada_lin.1.weight"), w("head_nm.ada_lin.1.bias"), w("head.weight"), w("head.bias"), st))
 
     # thin wrappers ----------------------------------------------------------------------------------------------
     def begin(self, labels: torch.Tensor):

@@ -13,6 +13,7 @@ from sdvar_amd.noise import exponential_noise
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
 LOGIT_TOL = 1e-3
+GEMM_MODES = ["f32", "bf16x3"]          # fp32 MFMA and the bf16x3 split-operand GEMM: the same parity bar for both
 
 
 def _noise_o(seed):
@@ -28,14 +29,15 @@ def _flip_report(ids_hip, ids_ref, lad):
     return f"{len(bad)} ids differ; first at image {b}, token {t} (stage {s})"
 
 
+@pytest.mark.parametrize("gm", GEMM_MODES)
 @pytest.mark.parametrize("name", ["ar_d4_256_stress", "ar_d6_256_stress", "ar_d4_512_stress", "ar_d4_256_notopkp"])
-def test_plain_ar_vs_reference_fixture(dev, name):
+def test_plain_ar_vs_reference_fixture(dev, name, gm):
     g = golden(name)
     depth, pns = int(g["depth"]), tuple(int(p) for p in g["patch_nums"])
     lad = as_ladder(pns)
     sd_var, sd_vae = state_dicts(depth, pns, str(g["mode"]), int(g["wseed"]))
     B = int(g["B"])
-    ctx = E.ModelCtx(sd_var, depth, pns, B, 1, dev); qc = E.QuantCtx(sd_vae, pns, B, dev)
+    ctx = E.ModelCtx(sd_var, depth, pns, B, 1, dev, gemm_mode=gm); qc = E.QuantCtx(sd_vae, pns, B, dev)
     smp = E.Sampler(ctx, qc)
     labels = torch.from_numpy(g["labels"]).long().to(dev)
     res = smp.plain_ar(labels, float(g["cfg"]), int(g["top_k"]), float(g["top_p"]), E.Noise("host", int(g["g_seed"])), trace=True)
@@ -56,11 +58,12 @@ def test_plain_ar_vs_reference_fixture(dev, name):
     ctx.close(); qc.close()
 
 
-def test_d16_b1_vs_reference_fixture(dev):
+@pytest.mark.parametrize("gm", GEMM_MODES)
+def test_d16_b1_vs_reference_fixture(dev, gm):
     g = golden("ar_d16_256_stress_B1")
     pns = tuple(int(p) for p in g["patch_nums"])
     sd_var, sd_vae = state_dicts(16, pns, "stress", int(g["wseed"]))
-    ctx = E.ModelCtx(sd_var, 16, pns, 1, 1, dev); qc = E.QuantCtx(sd_vae, pns, 1, dev)
+    ctx = E.ModelCtx(sd_var, 16, pns, 1, 1, dev, gemm_mode=gm); qc = E.QuantCtx(sd_vae, pns, 1, dev)
     res = E.Sampler(ctx, qc).plain_ar(torch.from_numpy(g["labels"]).long().to(dev), 1.5, 900, 0.96, E.Noise("host", int(g["g_seed"])), trace=True)
     ids = res.ids.cpu().numpy()
     assert np.array_equal(ids, g["ids"].astype(np.int64)), _flip_report(ids, g["ids"].astype(np.int64), as_ladder(pns))
@@ -71,12 +74,13 @@ def test_d16_b1_vs_reference_fixture(dev):
     ctx.close(); qc.close()
 
 
-@pytest.fixture(scope="module")
-def pair(dev):
+@pytest.fixture(scope="module", params=GEMM_MODES)
+def pair(dev, request):
     pns = LADDER_256
     sd_d, sd_v = state_dicts(4, pns); sd_t, _ = state_dicts(6, pns)
     B = 2
-    dc, tc, qc = E.ModelCtx(sd_d, 4, pns, B, 1, dev), E.ModelCtx(sd_t, 6, pns, B, 3, dev), E.QuantCtx(sd_v, pns, B, dev)
+    gm = request.param
+    dc, tc, qc = E.ModelCtx(sd_d, 4, pns, B, 1, dev, gemm_mode=gm), E.ModelCtx(sd_t, 6, pns, B, 3, dev, gemm_mode=gm), E.QuantCtx(sd_v, pns, B, dev)
     od, ot, oq = orc.OracleVAR(sd_d, 4, pns), orc.OracleVAR(sd_t, 6, pns), orc.OracleQuant(sd_v, pns)
     yield E.Sampler(tc, qc, dc), (od, ot, oq)
     dc.close(); tc.close(); qc.close()

@@ -67,7 +67,7 @@ def test_ln_modulate(dev, rows, Cw, rpi):
     R = (rows + rpi - 1) // rpi
     mod = rnd(2, (R, 6 * Cw)).to(dev)
     out = torch.empty_like(x)
-    E._check(lib.sdvar_op_ln_modulate(_p(x), C_void(mod, 2 * Cw), C_void(mod, 4 * Cw), _p(out), rows, Cw, rpi, 6 * Cw, _st()))
+    E._check(lib.sdvar_op_ln_modulate(_p(x), C_void(mod, 2 * Cw), C_void(mod, 4 * Cw), _p(out), None, 0, rows, Cw, rpi, 6 * Cw, _st()))
     sc = mod[:, 2 * Cw:3 * Cw].repeat_interleave(rpi, 0)[:rows]; sh = mod[:, 4 * Cw:5 * Cw].repeat_interleave(rpi, 0)[:rows]
     ref = F.layer_norm(x.cpu(), (Cw,), eps=1e-6).mul(sc.cpu().add(1)).add_(sh.cpu())
     assert (out.cpu() - ref).abs().max().item() <= 2e-5
@@ -116,7 +116,7 @@ def test_attention_matches_sdpa_with_block_causal_rows(dev, R, H, lens, prefix):
     vis = [prefix + int(sum(lens[:j + 1])) for j in range(len(lens))]
     out = torch.empty(R, l, H * 64, device=dev)
     n = len(lens)
-    E._check(lib.sdvar_op_attention(_p(q), _p(kc), _p(vc), 0, _p(out), R, H, l, Lmax, Ktot, n, (C.c_int32 * n)(*qbeg), (C.c_int32 * n)(*vis), _st()))
+    E._check(lib.sdvar_op_attention(_p(q), _p(kc), _p(vc), 0, _p(out), None, 0, R, H, l, Lmax, Ktot, n, (C.c_int32 * n)(*qbeg), (C.c_int32 * n)(*vis), _st()))
     ref = _attn_ref(q.cpu(), kc.cpu()[:, :, :Ktot], vc.cpu()[:, :, :Ktot], qbeg, vis).transpose(1, 2).reshape(R, l, H * 64)
     err = (out.cpu().double() - ref).abs().max().item()
     assert err <= 2e-5, err
@@ -133,7 +133,7 @@ def test_attention_forced_online_rescale(dev):
     v = rnd(3, (R, H, Ktot, 64))
     out = torch.empty(R, l, 64, device=dev)
     qd, kd, vd = q.to(dev), k.to(dev).contiguous(), v.to(dev)                  # keep the device copies alive across the call
-    E._check(lib.sdvar_op_attention(_p(qd), _p(kd), _p(vd), 0, _p(out), R, H, l, Ktot, Ktot, 1, (C.c_int32 * 1)(0), (C.c_int32 * 1)(Ktot), _st()))
+    E._check(lib.sdvar_op_attention(_p(qd), _p(kd), _p(vd), 0, _p(out), None, 0, R, H, l, Ktot, Ktot, 1, (C.c_int32 * 1)(0), (C.c_int32 * 1)(Ktot), _st()))
     ref = _attn_ref(q, k, v, [0], [Ktot]).transpose(1, 2).reshape(R, l, 64)
     assert (out.cpu().double() - ref).abs().max().item() <= 2e-5
 
@@ -283,6 +283,71 @@ def test_fp16_kv_cache_append_and_attention(dev):
     assert (diff > 0).float().mean().item() < 1e-3 and diff.max().item() <= 1e-3       # same rounding up to 1-ulp fp32 differences before it
     assert torch.equal(vc.cpu()[:, :, pos0:], v.half())
     out = torch.empty(R, l, H * 64, device=dev)
-    E._check(lib.sdvar_op_attention(_p(qo), _p(kc), _p(vc), 1, _p(out), R, H, l, Lmax, Lmax, 1, (C.c_int32 * 1)(0), (C.c_int32 * 1)(Lmax), _st()))
+    E._check(lib.sdvar_op_attention(_p(qo), _p(kc), _p(vc), 1, _p(out), None, 0, R, H, l, Lmax, Lmax, 1, (C.c_int32 * 1)(0), (C.c_int32 * 1)(Lmax), _st()))
     ref = _attn_ref(qo.cpu(), kc.cpu().float(), vc.cpu().float(), [0], [Lmax]).transpose(1, 2).reshape(R, l, H * 64)
     assert (out.cpu().double() - ref).abs().max().item() <= 2e-5
+
+
+# ------------------------------------------------------------------------------------------------ bf16x3 split-operand path
+def _planes(t, dev):
+    """fp32 tensor -> device planes (3, *shape) int16 through the library's splitter."""
+    lib = E.load_library()
+    x = t.to(dev).contiguous()
+    p = torch.empty((3,) + tuple(x.shape), dtype=torch.int16, device=dev)
+    E._check(lib.sdvar_op_split_planes(_p(x), _p(p), x.numel(), x.numel(), _st()))
+    return p
+
+
+def _unplanes(p):
+    return sum((p[k].to(torch.int32) << 16).view(torch.float32).double() for k in range(3))
+
+
+def test_split_planes_is_exact(dev):
+    x = rnd(1, (257, 64), 3.0)
+    x[0, :8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 1e-30, 3.4e38, 1.0000001, -123456.789])
+    p = _planes(x, dev)
+    assert torch.equal(_unplanes(p).cpu(), x.double())                          # x == p0 + p1 + p2 exactly
+
+
+@pytest.mark.parametrize("M,N,K", [(16, 768, 256), (1, 128, 32), (33, 384, 1024), (64, 3072, 1024), (100, 1024, 4096), (400, 1152, 384),
+                                   (576, 4096, 1024), (1600, 1024, 1024), (4096, 256, 1024), (130, 192, 64), (2704, 1024, 4096)])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_gemm_bf16x3_epilogues(dev, M, N, K, epi):
+    """Split-operand GEMM is fp32-accurate: error vs fp64 within the band of the fp32 MFMA kernel."""
+    lib = E.load_library()
+    X, W, b = rnd(1, (M, K)), rnd(2, (N, K), 1 / math.sqrt(K)), rnd(3, (N,)).to(dev)
+    Xp, Wp = _planes(X, dev), _planes(W, dev)
+    rows_per_gate = 7 if M > 7 else 1
+    R = (M + rows_per_gate - 1) // rows_per_gate
+    res, gate = rnd(4, (M, N)).to(dev), rnd(5, (R, 2 * N)).to(dev)
+    out = res.clone() if epi == 2 else torch.empty(M, N, device=dev)
+    outp = torch.empty(3, M, N, dtype=torch.int16, device=dev) if epi == 1 else None
+    E._check(lib.sdvar_op_gemm_bf16x3(_p(Xp), M * K, _p(Wp), N * K, _p(b), _p(out), N, _p(outp), M * N, M, N, K, epi, _p(out) if epi == 2 else None, N,
+                                      _p(gate) if epi == 2 else None, rows_per_gate, 2 * N, _st()))
+    ref = X.double() @ W.double().t() + b.cpu().double()
+    if epi == 1:
+        ref = F.gelu(ref, approximate="tanh"); got = _unplanes(outp).cpu()
+    elif epi == 2:
+        g = gate.cpu()[:, :N].double().repeat_interleave(rows_per_gate, 0)[:M]
+        ref = res.cpu().double() + ref * g; got = out.cpu().double()
+    else:
+        got = out.cpu().double()
+    err = (got - ref).abs().max().item()
+    assert err <= 2e-5 * max(1.0, ref.abs().max().item()), err
+
+
+def test_ln_and_attention_plane_outputs_equal_fp32_outputs(dev):
+    lib = E.load_library()
+    rows, Cw = 41, 384
+    x = rnd(1, (rows, Cw), 2.0).to(dev); mod = rnd(2, (1, 6 * Cw)).to(dev)
+    o32 = torch.empty_like(x); op = torch.empty(3, rows, Cw, dtype=torch.int16, device=dev)
+    E._check(lib.sdvar_op_ln_modulate(_p(x), C_void(mod, 2 * Cw), C_void(mod, 4 * Cw), _p(o32), None, 0, rows, Cw, rows, 6 * Cw, _st()))
+    E._check(lib.sdvar_op_ln_modulate(_p(x), C_void(mod, 2 * Cw), C_void(mod, 4 * Cw), None, _p(op), rows * Cw, rows, Cw, rows, 6 * Cw, _st()))
+    assert torch.equal(_unplanes(op).float(), o32)
+    R, H, l, K = 2, 3, 100, 255
+    q = (F.normalize(rnd(1, (R, H, l, 64)), dim=-1) * 4).to(dev); kc = F.normalize(rnd(2, (R, H, K, 64)), dim=-1).to(dev); vc = rnd(3, (R, H, K, 64)).to(dev)
+    a32 = torch.empty(R, l, H * 64, device=dev); ap = torch.empty(3, R, l, H * 64, dtype=torch.int16, device=dev)
+    one = (C.c_int32 * 1)
+    E._check(lib.sdvar_op_attention(_p(q), _p(kc), _p(vc), 0, _p(a32), None, 0, R, H, l, K, K, 1, one(0), one(K), _st()))
+    E._check(lib.sdvar_op_attention(_p(q), _p(kc), _p(vc), 0, None, _p(ap), R * l * H * 64, R, H, l, K, K, 1, one(0), one(K), _st()))
+    assert torch.equal(_unplanes(ap).float(), a32)

@@ -18,6 +18,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--chunk", type=int, default=1)
+    ap.add_argument("--mode", default="f32", choices=["f32", "bf16x3"])
+    ap.add_argument("--dump", default="", help="append the full sweep table (JSON lines) to this file")
     ap.add_argument("--sweep", action="store_true", help="time every (row tile, K slices) candidate per shape")
     a = ap.parse_args()
     lib = E.load_library()
@@ -35,7 +37,17 @@ def main():
         for name, N, K, epi in shapes:
             X = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev) * 0.02; b = torch.randn(N, device=dev)
             out = torch.randn(M, N, device=dev); gate = torch.randn(R, 6 * Cw, device=dev)
+            if a.mode == "bf16x3":
+                Xp = torch.empty(3, M, K, dtype=torch.int16, device=dev); Wp = torch.empty(3, N, K, dtype=torch.int16, device=dev)
+                E._check(lib.sdvar_op_split_planes(C.c_void_p(X.data_ptr()), C.c_void_p(Xp.data_ptr()), M * K, M * K, st))
+                E._check(lib.sdvar_op_split_planes(C.c_void_p(W.data_ptr()), C.c_void_p(Wp.data_ptr()), N * K, N * K, st))
+                outp = torch.empty(3, M, N, dtype=torch.int16, device=dev)
             def run():
+                if a.mode == "bf16x3":
+                    E._check(lib.sdvar_op_gemm_bf16x3(C.c_void_p(Xp.data_ptr()), M * K, C.c_void_p(Wp.data_ptr()), N * K, C.c_void_p(b.data_ptr()),
+                                                      C.c_void_p(out.data_ptr()), N, C.c_void_p(outp.data_ptr()), M * N, M, N, K, epi,
+                                                      C.c_void_p(out.data_ptr()) if epi == 2 else None, N, C.c_void_p(gate.data_ptr()) if epi == 2 else None, l, 6 * Cw, st))
+                    return
                 E._check(lib.sdvar_op_gemm(C.c_void_p(X.data_ptr()), K, C.c_void_p(W.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(out.data_ptr()), N, M, N, K, epi,
                                            C.c_void_p(out.data_ptr()) if epi == 2 else None, N, C.c_void_p(gate.data_ptr()) if epi == 2 else None, l, 6 * Cw, st))
             def timeit():
@@ -54,6 +66,10 @@ def main():
                         E._check(lib.sdvar_debug_set_gemm_cfg(bm, split))
                         res.append((timeit(), bm, split))
                 E._check(lib.sdvar_debug_set_gemm_cfg(0, 0))
+                if a.dump:
+                    import json
+                    with open(a.dump, "a") as f:
+                        f.write(json.dumps(dict(mode=a.mode, op=name, M=M, N=N, K=K, auto_us=us, cands=[(t, bm, sp) for t, bm, sp in res])) + "\n")
                 res.sort()
                 print(f"   sweep {name} M={M}: auto {us:.1f}us; best " + ", ".join(f"{t:.1f}us(bm{bm},s{sp})" for t, bm, sp in res[:4]))
             fl = 2.0 * M * N * K
