@@ -104,12 +104,13 @@ int sdvar_verify_accept(const float* logits, int32_t B, int32_t lsum, int32_t V,
 /* out[M,N] = epi(X[M,K] W[N,K]^T + bias); epi 0 bias, 1 bias+GELU(tanh), 2 res + (.)*gate[row / rows_per_gate] */
 int sdvar_op_gemm(const float* X, int32_t ldx, const float* W, const float* bias, float* out, int32_t ldo, int32_t M, int32_t N, int32_t K,
                   int32_t epilogue, const float* res, int32_t ldres, const float* gate, int32_t rows_per_gate, int32_t gate_stride, void* stream);
-/* out (fp32) or out_planes (bf16x3 planes [3][rows][C], plane stride in elements) */
+/* bf16x3 plane tensors are K-blocked: element (row, k) of plane p is at p*plane_stride + ((k/32)*rows + row)*32 + k%32.
+ * out (fp32) or out_planes (planes of the (rows, C) result, plane stride in elements) */
 int sdvar_op_ln_modulate(const float* x, const float* scale, const float* shift, float* out, uint16_t* out_planes, uint64_t plane_stride,
                          int32_t rows, int32_t C, int32_t rows_per_img, int32_t mod_stride, void* stream);
-/* fp32 (n elements) -> three bf16 planes of 8 significand bits each, x == p0 + p1 + p2 exactly */
-int sdvar_op_split_planes(const float* x, uint16_t* planes, uint64_t n, uint64_t plane_stride, void* stream);
-/* the bf16x3 split-operand GEMM on planes [3][M][K] / [3][N][K]; epi 0 bias -> out, 1 bias+GELU -> out_planes [3][M][N], 2 gated residual -> out */
+/* fp32 (rows, cols) row-major -> three K-blocked bf16 planes of 8 significand bits each, x == p0 + p1 + p2 exactly */
+int sdvar_op_split_planes(const float* x, uint16_t* planes, int32_t rows, int32_t cols, uint64_t plane_stride, void* stream);
+/* the bf16x3 split-operand GEMM on K-blocked planes of X (M,K) and W (N,K); epi 0 bias -> out, 1 bias+GELU -> out_planes of (M,N), 2 gated residual -> out */
 int sdvar_op_gemm_bf16x3(const uint16_t* Xp, uint64_t x_plane_stride, const uint16_t* Wp, uint64_t w_plane_stride, const float* bias, float* out,
                          int32_t ldo, uint16_t* out_planes, uint64_t out_plane_stride, int32_t M, int32_t N, int32_t K, int32_t epilogue,
                          const float* res, int32_t ldres, const float* gate, int32_t rows_per_gate, int32_t gate_stride, void* stream);

@@ -23,7 +23,7 @@ int embed_next(const float* nxt, const float* Ww, const float* bw, const float* 
 int attention_f32(const float* q, const void* kc, const void* vc, int kv_f16, float* out, uint16_t* outp, size_t ops, int R, int H, int l, int Lmax, int Ktot, int n_chunk, const int* qbeg, const int* vis, hipStream_t stream);
 int gemm_bf16x3_nt(const uint16_t* X, size_t xps, const uint16_t* W, size_t wps, const float* bias, float* out, int ldo, uint16_t* outp, size_t ops,
                    int M, int N, int K, int epi, const float* res, int ldres, const float* gate, int rows_per_gate, int gate_stride, hipStream_t stream);
-int split_planes(const float* x, uint16_t* planes, size_t n, size_t plane_stride, hipStream_t stream);
+int split_planes(const float* x, uint16_t* planes, int rows, int cols, size_t plane_stride, hipStream_t stream);
 void debug_set_gemm_cfg_p(int bm, int split);
 int cfg_sample(const float* logits, int B, int l, int V, float one_plus_t, float t, int top_k, int use_top_p, float top_p_thr, const float* q, uint64_t seed,
                uint32_t draw, uint32_t image_offset, long long* ids, int ids_stride, float* dbg_masked, hipStream_t stream);
@@ -230,8 +230,9 @@ int sdvar_model_bind_block(sdvar_model_t* m, int32_t i, const float* ada_w, cons
     SDVAR_HIP(hipMemcpyAsync(b.qkv_bias, q_bias, C * sizeof(float), hipMemcpyDeviceToDevice, s));
     SDVAR_HIP(hipMemcpyAsync(b.qkv_bias + 2 * C, v_bias, C * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (m->d.gemm_mode == 1) {
-        SDVAR_TRY(split_planes(qkv_w, b.qkv_wp, 3 * C * C, 3 * C * C, s)); SDVAR_TRY(split_planes(proj_w, b.proj_wp, C * C, C * C, s));
-        SDVAR_TRY(split_planes(fc1_w, b.fc1_wp, 4 * C * C, 4 * C * C, s)); SDVAR_TRY(split_planes(fc2_w, b.fc2_wp, 4 * C * C, 4 * C * C, s));
+        const int Ci = m->C;
+        SDVAR_TRY(split_planes(qkv_w, b.qkv_wp, 3 * Ci, Ci, 3 * C * C, s)); SDVAR_TRY(split_planes(proj_w, b.proj_wp, Ci, Ci, C * C, s));
+        SDVAR_TRY(split_planes(fc1_w, b.fc1_wp, 4 * Ci, Ci, 4 * C * C, s)); SDVAR_TRY(split_planes(fc2_w, b.fc2_wp, Ci, 4 * Ci, 4 * C * C, s));
     }
     b.bound = true;
     return SDVAR_OK;
@@ -240,7 +241,7 @@ int sdvar_model_bind_block(sdvar_model_t* m, int32_t i, const float* ada_w, cons
 int sdvar_model_bind_head(sdvar_model_t* m, const float* nm_w, const float* nm_b, const float* head_w, const float* head_b, void* stream) {
     SDVAR_CHECK_ARG(m && nm_w && nm_b && head_w && head_b, "bind_head: null argument");
     m->nm_w = nm_w; m->nm_b = nm_b; m->head_w = head_w; m->head_b = head_b; m->head_bound = true;
-    if (m->d.gemm_mode == 1) SDVAR_TRY(split_planes(head_w, m->head_wp, (size_t)m->d.vocab * m->C, (size_t)m->d.vocab * m->C, (hipStream_t)stream));
+    if (m->d.gemm_mode == 1) SDVAR_TRY(split_planes(head_w, m->head_wp, m->d.vocab, m->C, (size_t)m->d.vocab * m->C, (hipStream_t)stream));
     return SDVAR_OK;
 }
 
@@ -466,8 +467,8 @@ int sdvar_op_ln_modulate(const float* x, const float* scale, const float* shift,
     SDVAR_CHECK_ARG(out || out_planes, "op_ln_modulate: no output");
     return ln_modulate(x, scale, shift, out, out_planes, (size_t)plane_stride, rows, C, rows_per_img, mod_stride, (hipStream_t)stream);
 }
-int sdvar_op_split_planes(const float* x, uint16_t* planes, uint64_t n, uint64_t plane_stride, void* stream) {
-    return split_planes(x, planes, (size_t)n, (size_t)plane_stride, (hipStream_t)stream);
+int sdvar_op_split_planes(const float* x, uint16_t* planes, int32_t rows, int32_t cols, uint64_t plane_stride, void* stream) {
+    return split_planes(x, planes, rows, cols, (size_t)plane_stride, (hipStream_t)stream);
 }
 int sdvar_op_gemm_bf16x3(const uint16_t* Xp, uint64_t x_plane_stride, const uint16_t* Wp, uint64_t w_plane_stride, const float* bias, float* out, int32_t ldo,
                          uint16_t* out_planes, uint64_t out_plane_stride, int32_t M, int32_t N, int32_t K, int32_t epi, const float* res, int32_t ldres,

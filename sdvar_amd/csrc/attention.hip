@@ -211,8 +211,9 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(AttnArgs a) {
                     uint2 w0, w1;
                     w0.x = (uint32_t)q0[k][0] | ((uint32_t)q0[k][1] << 16); w0.y = (uint32_t)q0[k][2] | ((uint32_t)q0[k][3] << 16);
                     w1.x = (uint32_t)q1[k][0] | ((uint32_t)q1[k][1] << 16); w1.y = (uint32_t)q1[k][2] | ((uint32_t)q1[k][3] << 16);
-                    *reinterpret_cast<uint2*>(a.outp + k * a.ops + obase + 8 * g) = w0;
-                    *reinterpret_cast<uint2*>(a.outp + k * a.ops + obase + 32 + 8 * g) = w1;
+                    const int orow = r * a.l + qi_raw, ocol = h * 64 + 4 * lh + 8 * g;      // K-blocked planes of the (R*l, H*64) matrix
+                    *reinterpret_cast<uint2*>(a.outp + k * a.ops + kb_index(orow, ocol, a.R * a.l)) = w0;
+                    *reinterpret_cast<uint2*>(a.outp + k * a.ops + kb_index(orow, ocol + 32, a.R * a.l)) = w1;
                 }
             } else {
                 *reinterpret_cast<f32x4*>(a.out + obase + 8 * g) = v0;

@@ -70,6 +70,13 @@ __device__ __forceinline__ void split3(float x, uint16_t& p0, uint16_t& p1, uint
     p0 = (uint16_t)(u0 >> 16); p1 = (uint16_t)(u1 >> 16); p2 = (uint16_t)(__float_as_uint(r2) >> 16);
 }
 
+// Planar bf16x3 tensors are K-BLOCKED: element (row, k) of plane p of a (rows x K) matrix lives at
+//     plane_base[p] + ((k / 32) * rows + row) * 32 + (k % 32)
+// i.e. for every block of 32 k the rows are contiguous 64-byte segments, so the (tile rows) x (32 k) slab a GEMM workgroup
+// loads per K-step is ONE contiguous run of full 128-byte lines (a [rows][K] row-major plane would give half-line, 64-byte
+// fragments at stride 2K: twice the L1/TA requests per byte).
+__device__ __forceinline__ size_t kb_index(int row, int k, int rows) { return ((size_t)(k >> 5) * rows + row) * 32 + (k & 31); }
+
 // ---- Philox4x32-10 (must match sdvar_amd/noise.py bit for bit) ----------------------------------------------------
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
                                               uint32_t out[4]) {

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restric
                 for (int k = 0; k < 3; ++k) {
                     uint2 w;
                     w.x = (uint32_t)q[k][0] | ((uint32_t)q[k][1] << 16); w.y = (uint32_t)q[k][2] | ((uint32_t)q[k][3] << 16);
-                    *reinterpret_cast<uint2*>(outp + k * ops + (size_t)row * C + 4 * idx) = w;
+                    *reinterpret_cast<uint2*>(outp + k * ops + kb_index(row, 4 * idx, rows)) = w;
                 }
             } else {
                 po[idx] = o;

@@ -7,7 +7,7 @@
 // 1.2e-6 vs 2.5e-6 for a plain fp32 GEMM - the fp32 accumulation order dominates either way - while the matrix pipe
 // spends 6 x 32 cycles per 16 k instead of 8 x 64: 2.67x the throughput of v_mfma_f32_32x32x2_f32 (gemm.hip).
 //
-// Operands are PLANAR: planes[3][rows][K] bf16.  Weights are split once at bind time; activations are written as planes
+// Operands are PLANAR and K-blocked: planes[3][K/32][rows][32] bf16 (common.h kb_index).  Weights are split once at bind time; activations are written as planes
 // by their producers (ln_modulate, attention, the fc1 GELU epilogue), so the GEMM itself does no conversion work.
 //
 // Tiling: BM x 128 x 32 (BM = 128 / 64 / 32), 4 waves, one LDS stage (rows padded to 80 bytes: conflict-free
@@ -31,7 +31,7 @@ __device__ __forceinline__ float gelu_tanh_p(float x) {
 }
 
 struct GemmPArgs {
-    const uint16_t* X; const uint16_t* W;        // planes [3][M][K], [3][N][K]
+    const uint16_t* X; const uint16_t* W;        // K-blocked planes [3][K/32][M][32], [3][K/32][N][32]
     size_t xps, wps;                             // plane strides in elements
     const float* bias; float* out; uint16_t* outp; size_t ops;
     const float* res; const float* gate;
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmPArgs a) {
             const bool ok = (BM * 4 >= 256 || c < BM * 4) && m < a.M;
 #pragma unroll
             for (int p = 0; p < 3; ++p)
-                rx[p][i] = ok ? *reinterpret_cast<const f32x4*>(a.X + p * a.xps + (size_t)m * a.K + k0 + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+                rx[p][i] = ok ? *reinterpret_cast<const f32x4*>(a.X + p * a.xps + ((size_t)(k0 >> 5) * a.M + m) * 32 + col) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int i = 0; i < WCH; ++i) {
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmPArgs a) {
             const int n = n0 + row;
 #pragma unroll
             for (int p = 0; p < 3; ++p)
-                rw[p][i] = (n < a.N) ? *reinterpret_cast<const f32x4*>(a.W + p * a.wps + (size_t)n * a.K + k0 + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+                rw[p][i] = (n < a.N) ? *reinterpret_cast<const f32x4*>(a.W + p * a.wps + ((size_t)(k0 >> 5) * a.N + n) * 32 + col) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
     auto store_tile = [&]() {
@@ -157,7 +157,133 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmPArgs a) {
                 if (EPI == PEPI_BIAS_GELU_PLANES) {
                     uint16_t p0, p1, p2;
                     split3(gelu_tanh_p(v), p0, p1, p2);
-                    const size_t o = (size_t)m * a.N + n;
+                    const size_t o = kb_index(m, n, a.M);           // the output is the next GEMM's K-blocked operand
+                    a.outp[o] = p0; a.outp[a.ops + o] = p1; a.outp[2 * a.ops + o] = p2;
+                } else {
+                    if (EPI == PEPI_GATED_RES) v = a.res[(size_t)m * a.ldres + n] + v * a.gate[(size_t)(m / a.rows_per_gate) * a.gate_stride + n];
+                    outp[(size_t)m * a.ldo + n] = v;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// v2 main-loop structure for the 128x128 tile: 8 waves (2 x 4, 64x32 outputs each), K-steps of 32 streamed global -> LDS
+// by the LDS-DMA (global_load_lds_dwordx4, no staging registers) into a 3-stage ring, two K-steps in flight, ONE raw
+// s_barrier per K-step and counted vmcnt waits (cdna_hip_programming.md, "Pipelining across barriers").
+//   stage (48 KB) = 6 sub-arrays [128 rows][64 B]: X planes 0..2 then W planes 0..2; rows are NOT padded (one DMA
+//   instruction writes 16 rows x 64 B contiguously); bank conflicts of the fragment reads are avoided by storing the
+//   16-byte chunk c of row r at chunk c ^ ((r >> 2) & 3) - applied on the DMA source address and on the ds_read address.
+//   Every wave issues 6 DMA instructions per K-step (rows 16w .. 16w+15 of each sub-array).
+// Order per K-step t:  vmcnt(6|0) -> s_barrier  (tile t landed for all waves; everyone is done reading tile t-1)
+//                      issue tile t+2 into stage (t+2)%3 (the stage tile t-1 occupied)  ->  MFMAs on stage t%3.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+constexpr int V2_STAGE = 6 * 128 * 32;          // bf16 elements per stage (48 KB)
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_bf16x3_v2_kernel(GemmPArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t psm[];
+    constexpr int BM = 128;
+    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + PBN - 1) / PBN, ntile = tiles_m * tiles_n;
+    const int ks = blockIdx.x / ntile;
+    const int lid = xcd_remap(blockIdx.x - ks * ntile, ntile);
+    const int G = 8, per_group = tiles_m * G;
+    const int g = lid / per_group, rem = lid - g * per_group;
+    const int gw = min(G, tiles_n - g * G);
+    const int tm = rem / gw, tn = g * G + rem % gw;
+    const int m0 = tm * BM, n0 = tn * PBN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3, li = lane & 31, lh = lane >> 5;
+
+    // DMA source pointers of this lane: row 16*wave + lane/4 of each sub-array, logical chunk (lane%4) ^ ((row>>2)&3)
+    const int drow = 16 * wave + (lane >> 2);
+    const int dchunk = (lane & 3) ^ ((drow >> 2) & 3);
+    const int xrow = min(m0 + drow, a.M - 1), wrow = min(n0 + drow, a.N - 1);     // clamped: rows past the edge are never stored
+    const int kt0 = ks * a.k_per_split;
+    const int nk = min(a.K / PBK - kt0, a.k_per_split);
+    const uint16_t* srcx = a.X + ((size_t)kt0 * a.M + xrow) * 32 + 8 * dchunk;      // K-blocked: K-step t is the slab [t][rows][32]
+    const uint16_t* srcw = a.W + ((size_t)kt0 * a.N + wrow) * 32 + 8 * dchunk;
+    auto issue = [&](int t) {             // K-step t (relative) -> stage t % 3
+        uint16_t* st = psm + (t % 3) * V2_STAGE + wave * 512;       // + sub-array q * 4096 elements
+        const uint16_t* px = srcx + (size_t)t * a.M * 32;
+        const uint16_t* pw = srcw + (size_t)t * a.N * 32;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(px + p * a.xps), (lds_ptr_t)(st + p * 4096), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pw + p * a.wps), (lds_ptr_t)(st + (3 + p) * 4096), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    // fragment read offsets (elements) inside a sub-array: row * 32 + 8 * ((2s + lh) ^ ((li >> 2) & 3))
+    const int sw = (li >> 2) & 3;
+    const int offa0 = (wm * 64 + li) * 32, offb = (wn * 32 + li) * 32;
+    const int ch0 = 8 * ((0 + lh) ^ sw), ch1 = 8 * ((2 + lh) ^ sw);
+
+    issue(0);
+    if (nk > 1) issue(1);
+    for (int t = 0; t < nk; ++t) {
+        if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 2 < nk) issue(t + 2);
+        // LDS byte addresses of this lane's fragments in stage t % 3 (the two k16-steps differ only in the swizzled chunk)
+        const uint32_t sb = (uint32_t)(uintptr_t)(lds_ptr_t)(psm + (t % 3) * V2_STAGE);
+        const uint32_t aa0 = sb + 2 * (offa0 + ch0), aa1 = sb + 2 * (offa0 + ch1), ab0 = sb + 2 * (offb + ch0), ab1 = sb + 2 * (offb + ch1);
+        // Hand-placed LDS reads and waits (the compiler's waitcnt pass falls back to lgkmcnt(0) with 18 reads in flight):
+        // step-0 fragments, then step-1 fragments, wait for step 0 only, 12 MFMAs, wait for the rest, 12 MFMAs.  Both
+        // waves of a SIMD belong to this workgroup and pass the barrier together, so what is not hidden inside the wave
+        // is not hidden at all.
+        bf16x8 fa[2][3][2], fb[2][3];
+#define SDVAR_LDS_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr) : "memory")
+        SDVAR_LDS_RD(fa[0][0][0], aa0, 0);     SDVAR_LDS_RD(fb[0][2], ab0, 40960);  SDVAR_LDS_RD(fa[0][1][0], aa0, 8192);
+        SDVAR_LDS_RD(fb[0][1], ab0, 32768);    SDVAR_LDS_RD(fa[0][2][0], aa0, 16384); SDVAR_LDS_RD(fb[0][0], ab0, 24576);
+        SDVAR_LDS_RD(fa[0][0][1], aa0, 2048);  SDVAR_LDS_RD(fa[0][1][1], aa0, 10240); SDVAR_LDS_RD(fa[0][2][1], aa0, 18432);
+        SDVAR_LDS_RD(fa[1][0][0], aa1, 0);     SDVAR_LDS_RD(fb[1][2], ab1, 40960);  SDVAR_LDS_RD(fa[1][1][0], aa1, 8192);
+        SDVAR_LDS_RD(fb[1][1], ab1, 32768);    SDVAR_LDS_RD(fa[1][2][0], aa1, 16384); SDVAR_LDS_RD(fb[1][0], ab1, 24576);
+        SDVAR_LDS_RD(fa[1][0][1], aa1, 2048);  SDVAR_LDS_RD(fa[1][1][1], aa1, 10240); SDVAR_LDS_RD(fa[1][2][1], aa1, 18432);
+#undef SDVAR_LDS_RD
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (s == 0) asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);      // keep the MFMAs behind the wait (rule 18 of the CDNA guide)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][0][i], fb[s][2], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][1][i], fb[s][1], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][2][i], fb[s][0], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][0][i], fb[s][1], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][1][i], fb[s][0], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][0][i], fb[s][0], acc[i], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    const int n = n0 + wn * 32 + li;
+    if (n < a.N) {
+        const float bv = (EPI != PEPI_PARTIAL && a.bias) ? a.bias[n] : 0.f;
+        float* outp = (EPI == PEPI_PARTIAL) ? a.out + (size_t)ks * a.M * a.ldo : a.out;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= a.M) continue;
+                float v = acc[i][r] + bv;
+                if (EPI == PEPI_BIAS_GELU_PLANES) {
+                    uint16_t p0, p1, p2;
+                    split3(gelu_tanh_p(v), p0, p1, p2);
+                    const size_t o = kb_index(m, n, a.M);           // the output is the next GEMM's K-blocked operand
                     a.outp[o] = p0; a.outp[a.ops + o] = p1; a.outp[2 * a.ops + o] = p2;
                 } else {
                     if (EPI == PEPI_GATED_RES) v = a.res[(size_t)m * a.ldres + n] + v * a.gate[(size_t)(m / a.rows_per_gate) * a.gate_stride + n];
@@ -195,32 +321,35 @@ __global__ __launch_bounds__(256) void splitk_reduce_p_kernel(const float* __res
             for (int p = 0; p < 3; ++p) {
                 uint2 w;
                 w.x = (uint32_t)pl[p][0] | ((uint32_t)pl[p][1] << 16); w.y = (uint32_t)pl[p][2] | ((uint32_t)pl[p][3] << 16);
-                *reinterpret_cast<uint2*>(outp + p * ops + (size_t)m * N + n) = w;
+                *reinterpret_cast<uint2*>(outp + p * ops + kb_index(m, n, M)) = w;
             }
         }
     }
 }
 
-// fp32 (rows, cols) -> planes [3][rows][cols] bf16 (weights at bind time, and any activation without a fused producer)
-__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, uint16_t* __restrict__ p, size_t n, size_t ps) {
-    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * blockDim.x * 4) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(x + i);
+// fp32 (rows, cols) row-major -> K-blocked planes [3][cols/32][rows][32] bf16 (weights at bind time, tests)
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, uint16_t* __restrict__ p, int rows, int cols, size_t ps) {
+    const size_t n4 = (size_t)rows * cols / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i / (cols / 4)), k = (int)(i % (cols / 4)) * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)row * cols + k);
         uint16_t q[3][4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) split3(v[e], q[0][e], q[1][e], q[2][e]);
+        const size_t o = kb_index(row, k, rows);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
+        for (int j = 0; j < 3; ++j) {
             uint2 w;
-            w.x = (uint32_t)q[k][0] | ((uint32_t)q[k][1] << 16); w.y = (uint32_t)q[k][2] | ((uint32_t)q[k][3] << 16);
-            *reinterpret_cast<uint2*>(p + k * ps + i) = w;
+            w.x = (uint32_t)q[j][0] | ((uint32_t)q[j][1] << 16); w.y = (uint32_t)q[j][2] | ((uint32_t)q[j][3] << 16);
+            *reinterpret_cast<uint2*>(p + j * ps + o) = w;
         }
     }
 }
 
-int split_planes(const float* x, uint16_t* planes, size_t n, size_t plane_stride, hipStream_t stream) {
-    SDVAR_CHECK_ARG(x && planes && n % 4 == 0 && plane_stride % 4 == 0, "split_planes: need a multiple of 4 elements");
-    const size_t blocks = (n / 4 + 255) / 256;
-    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream, x, planes, n, plane_stride);
+int split_planes(const float* x, uint16_t* planes, int rows, int cols, size_t plane_stride, hipStream_t stream) {
+    SDVAR_CHECK_ARG(x && planes && rows > 0 && cols > 0 && cols % 32 == 0 && plane_stride % 8 == 0, "split_planes: need cols %% 32 == 0 (rows=%d cols=%d)", rows, cols);
+    const size_t blocks = ((size_t)rows * cols / 4 + 255) / 256;
+    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream, x, planes, rows, cols, plane_stride);
     SDVAR_LAUNCH_CHECK();
     return SDVAR_OK;
 }
@@ -236,27 +365,43 @@ static void choose_cfg_p(int M, int N, int K, size_t ws_floats, int* bm_out, int
     double best = 1e30; int bbm = 128, bs = 1;
     const int bms[3] = {128, 64, 32};
     // constants fitted to tools/gemm_bench.py --mode bf16x3 --sweep --dump (d12 / d16 shapes, single stages and gamma = 2
-    // chunks): geometric-mean regret 2.8 % against the best swept configuration
-    const int resident[3] = {2, 3, 3};
-    const double lat[4] = {0.0, 2.0, 1.2, 1.1};
+    // chunks; 128-row tiles run the LDS-DMA kernel): geometric-mean regret 2.1 % against the best swept configuration
+    const int resident[3] = {2, 2, 4};
+    const double lat[5] = {0.0, 1.5, 1.4, 1.05, 1.0};
     for (int bi = 0; bi < 3; ++bi) {
         const int bm = bms[bi], res = resident[bi];
         const int tiles = ((M + bm - 1) / bm) * tiles_n;
-        const double ktile = 384.0 * (bm / 32) * (bm == 32 ? 1.3 : (bm == 64 ? 1.2 : 1.0));   // 6 MFMAs x 32 cycles x 2 k16-steps per 32x32 sub-tile
+        const double ktile = 384.0 * (bm / 32) * (bm == 128 ? 1.0 : 1.2);   // 6 MFMAs x 32 cycles x 2 k16-steps per 32x32 sub-tile
         for (int split = 1; split <= 32 && split <= nkt / 2; ++split) {
             if (split > 1 && ((size_t)split * M * N > ws_floats || N % 4)) break;
             const int kps = (nkt + split - 1) / split;
             if ((nkt + kps - 1) / kps != split) continue;
             const long blocks = (long)tiles * split;
             const long per_cu = (blocks + 255) / 256;
-            const double T = kps * (ktile + 260.0) + 8000.0 + 20.0 * bm;    // + barriers / LDS refill per K-step, prologue + epilogue
+            const double T = kps * (ktile + 600.0) + 8000.0 + 80.0 * bm;    // + per-K-step sync/refill, prologue + epilogue
             const long full = per_cu / res, rem = per_cu % res;
             double cyc = full * res * T * lat[res] + (rem ? rem * T * lat[rem] : 0.0);
-            if (split > 1) cyc += 2000.0 + (double)(split + 1) * M * N * 4.0 / 3000.0;
+            if (split > 1) cyc += 4000.0 + (double)(split + 1) * M * N * 4.0 / 5000.0;
             if (cyc < best) { best = cyc; bbm = bm; bs = split; }
         }
     }
     *bm_out = bbm; *split_out = bs;
+}
+
+static bool g_use_v2 = true;
+void debug_set_gemm_v2(int on) { g_use_v2 = on != 0; }
+
+template <int EPI>
+static int launch_v2_kernel(const GemmPArgs& a, int grid, hipStream_t stream) {
+    const size_t lds = 3 * (size_t)V2_STAGE * sizeof(uint16_t);      // 144 KB
+    static bool attr_set = false;
+    if (!attr_set) {
+        SDVAR_HIP(hipFuncSetAttribute((const void*)gemm_bf16x3_v2_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_bf16x3_v2_kernel<EPI>), dim3(grid), dim3(512), lds, stream, a);
+    SDVAR_LAUNCH_CHECK();
+    return SDVAR_OK;
 }
 
 template <int BM, int WAVES_M, int WAVES_N>
@@ -264,6 +409,7 @@ static int launch_p(GemmPArgs a, int epi, int split, hipStream_t stream) {
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + PBN - 1) / PBN);
     const size_t lds = 3 * (size_t)(BM + PBN) * PROW * sizeof(uint16_t);
     dim3 block(256);
+    const bool v2 = (BM == 128) && g_use_v2;
     const int nkt = a.K / PBK;
     if (split > 1) {
         size_t wsf = 0;
@@ -271,8 +417,8 @@ static int launch_p(GemmPArgs a, int epi, int split, hipStream_t stream) {
         if (!ws) return SDVAR_ERR_HIP;
         GemmPArgs p = a;
         p.out = ws; p.ldo = a.N; p.split = split; p.k_per_split = (nkt + split - 1) / split;
-        hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, WAVES_M, WAVES_N, PEPI_PARTIAL>), dim3(tiles * split), block, lds, stream, p);
-        SDVAR_LAUNCH_CHECK();
+        if (v2) { int rc = launch_v2_kernel<PEPI_PARTIAL>(p, tiles * split, stream); if (rc) return rc; }
+        else { hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, WAVES_M, WAVES_N, PEPI_PARTIAL>), dim3(tiles * split), block, lds, stream, p); SDVAR_LAUNCH_CHECK(); }
         const size_t total = (size_t)a.M * (a.N / 4);
         const int rgrid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
         switch (epi) {
@@ -284,6 +430,13 @@ static int launch_p(GemmPArgs a, int epi, int split, hipStream_t stream) {
         return SDVAR_OK;
     }
     a.split = 1; a.k_per_split = nkt;
+    if (v2) {
+        switch (epi) {
+            case PEPI_BIAS: return launch_v2_kernel<PEPI_BIAS>(a, tiles, stream);
+            case PEPI_BIAS_GELU_PLANES: return launch_v2_kernel<PEPI_BIAS_GELU_PLANES>(a, tiles, stream);
+            default: return launch_v2_kernel<PEPI_GATED_RES>(a, tiles, stream);
+        }
+    }
     switch (epi) {
         case PEPI_BIAS: hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, WAVES_M, WAVES_N, PEPI_BIAS>), dim3(tiles), block, lds, stream, a); break;
         case PEPI_BIAS_GELU_PLANES: hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, WAVES_M, WAVES_N, PEPI_BIAS_GELU_PLANES>), dim3(tiles), block, lds, stream, a); break;

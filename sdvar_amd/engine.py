@@ -64,7 +64,7 @@ _SIGNATURES = {
     "sdvar_verify_accept": (_I, [_P, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_D), _P, _I, _D, _P, _P, _P]),
     "sdvar_op_gemm": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P]),
     "sdvar_op_ln_modulate": (_I, [_P, _P, _P, _P, _P, _U64, _I, _I, _I, _I, _P]),
-    "sdvar_op_split_planes": (_I, [_P, _P, _U64, _U64, _P]),
+    "sdvar_op_split_planes": (_I, [_P, _P, _I, _I, _U64, _P]),
     "sdvar_op_gemm_bf16x3": (_I, [_P, _U64, _P, _U64, _P, _P, _I, _P, _U64, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P]),
     "sdvar_op_qk_norm_append": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "sdvar_op_attention": (_I, [_P, _P, _P, _I, _P, _P, _U64, _I, _I, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), _P]),

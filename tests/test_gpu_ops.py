@@ -290,16 +290,19 @@ def test_fp16_kv_cache_append_and_attention(dev):
 
 # ------------------------------------------------------------------------------------------------ bf16x3 split-operand path
 def _planes(t, dev):
-    """fp32 tensor -> device planes (3, *shape) int16 through the library's splitter."""
+    """fp32 (rows, K) -> device K-blocked planes (3, K/32, rows, 32) int16 through the library's splitter."""
     lib = E.load_library()
     x = t.to(dev).contiguous()
-    p = torch.empty((3,) + tuple(x.shape), dtype=torch.int16, device=dev)
-    E._check(lib.sdvar_op_split_planes(_p(x), _p(p), x.numel(), x.numel(), _st()))
+    rows, K = x.shape
+    p = torch.empty(3, K // 32, rows, 32, dtype=torch.int16, device=dev)
+    E._check(lib.sdvar_op_split_planes(_p(x), _p(p), rows, K, rows * K, _st()))
     return p
 
 
 def _unplanes(p):
-    return sum((p[k].to(torch.int32) << 16).view(torch.float32).double() for k in range(3))
+    """K-blocked planes (3, K/32, rows, 32) -> fp64 (rows, K)."""
+    v = sum((p[k].to(torch.int32) << 16).view(torch.float32).double() for k in range(3))
+    return v.permute(1, 0, 2).reshape(v.shape[1], -1)
 
 
 def test_split_planes_is_exact(dev):
@@ -321,7 +324,7 @@ def test_gemm_bf16x3_epilogues(dev, M, N, K, epi):
     R = (M + rows_per_gate - 1) // rows_per_gate
     res, gate = rnd(4, (M, N)).to(dev), rnd(5, (R, 2 * N)).to(dev)
     out = res.clone() if epi == 2 else torch.empty(M, N, device=dev)
-    outp = torch.empty(3, M, N, dtype=torch.int16, device=dev) if epi == 1 else None
+    outp = torch.empty(3, N // 32, M, 32, dtype=torch.int16, device=dev) if epi == 1 else None
     E._check(lib.sdvar_op_gemm_bf16x3(_p(Xp), M * K, _p(Wp), N * K, _p(b), _p(out), N, _p(outp), M * N, M, N, K, epi, _p(out) if epi == 2 else None, N,
                                       _p(gate) if epi == 2 else None, rows_per_gate, 2 * N, _st()))
     ref = X.double() @ W.double().t() + b.cpu().double()
@@ -340,14 +343,41 @@ def test_ln_and_attention_plane_outputs_equal_fp32_outputs(dev):
     lib = E.load_library()
     rows, Cw = 41, 384
     x = rnd(1, (rows, Cw), 2.0).to(dev); mod = rnd(2, (1, 6 * Cw)).to(dev)
-    o32 = torch.empty_like(x); op = torch.empty(3, rows, Cw, dtype=torch.int16, device=dev)
+    o32 = torch.empty_like(x); op = torch.empty(3, Cw // 32, rows, 32, dtype=torch.int16, device=dev)
     E._check(lib.sdvar_op_ln_modulate(_p(x), C_void(mod, 2 * Cw), C_void(mod, 4 * Cw), _p(o32), None, 0, rows, Cw, rows, 6 * Cw, _st()))
     E._check(lib.sdvar_op_ln_modulate(_p(x), C_void(mod, 2 * Cw), C_void(mod, 4 * Cw), None, _p(op), rows * Cw, rows, Cw, rows, 6 * Cw, _st()))
     assert torch.equal(_unplanes(op).float(), o32)
     R, H, l, K = 2, 3, 100, 255
     q = (F.normalize(rnd(1, (R, H, l, 64)), dim=-1) * 4).to(dev); kc = F.normalize(rnd(2, (R, H, K, 64)), dim=-1).to(dev); vc = rnd(3, (R, H, K, 64)).to(dev)
-    a32 = torch.empty(R, l, H * 64, device=dev); ap = torch.empty(3, R, l, H * 64, dtype=torch.int16, device=dev)
+    a32 = torch.empty(R, l, H * 64, device=dev); ap = torch.empty(3, H * 2, R * l, 32, dtype=torch.int16, device=dev)
     one = (C.c_int32 * 1)
     E._check(lib.sdvar_op_attention(_p(q), _p(kc), _p(vc), 0, _p(a32), None, 0, R, H, l, K, K, 1, one(0), one(K), _st()))
     E._check(lib.sdvar_op_attention(_p(q), _p(kc), _p(vc), 0, None, _p(ap), R * l * H * 64, R, H, l, K, K, 1, one(0), one(K), _st()))
-    assert torch.equal(_unplanes(ap).float(), a32)
+    assert torch.equal(_unplanes(ap).float().view(R, l, H * 64), a32)
+
+
+@pytest.mark.parametrize("M,N,K,split", [(130, 192, 64, 1), (1, 128, 32, 1), (257, 384, 1024, 3), (4096, 256, 1024, 1), (2704, 1024, 4096, 5), (100, 4096, 1024, 2)])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_gemm_bf16x3_v2_forced_128_tile(dev, M, N, K, split, epi):
+    """The LDS-DMA pipelined 128x128 kernel on ragged edges (clamped source rows), short K loops and split-K."""
+    lib = E.load_library()
+    X, W, b = rnd(1, (M, K)), rnd(2, (N, K), 1 / math.sqrt(K)), rnd(3, (N,)).to(dev)
+    Xp, Wp = _planes(X, dev), _planes(W, dev)
+    res, gate = rnd(4, (M, N)).to(dev), rnd(5, (M, 2 * N)).to(dev)
+    out = res.clone() if epi == 2 else torch.full((M, N), float("nan"), device=dev)
+    outp = torch.empty(3, N // 32, M, 32, dtype=torch.int16, device=dev) if epi == 1 else None
+    E._check(lib.sdvar_debug_set_gemm_cfg(128, split))
+    try:
+        E._check(lib.sdvar_op_gemm_bf16x3(_p(Xp), M * K, _p(Wp), N * K, _p(b), _p(out), N, _p(outp), M * N, M, N, K, epi, _p(out) if epi == 2 else None, N,
+                                          _p(gate) if epi == 2 else None, 1, 2 * N, _st()))
+    finally:
+        E._check(lib.sdvar_debug_set_gemm_cfg(0, 0))
+    ref = X.double() @ W.double().t() + b.cpu().double()
+    if epi == 1:
+        ref = F.gelu(ref, approximate="tanh"); got = _unplanes(outp).cpu()
+    elif epi == 2:
+        ref = res.cpu().double() + ref * gate.cpu()[:, :N].double(); got = out.cpu().double()
+    else:
+        got = out.cpu().double()
+    err = (got - ref).abs().max().item()
+    assert err <= 2e-5 * max(1.0, ref.abs().max().item()), err

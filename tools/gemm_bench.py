@@ -39,8 +39,8 @@ def main():
             out = torch.randn(M, N, device=dev); gate = torch.randn(R, 6 * Cw, device=dev)
             if a.mode == "bf16x3":
                 Xp = torch.empty(3, M, K, dtype=torch.int16, device=dev); Wp = torch.empty(3, N, K, dtype=torch.int16, device=dev)
-                E._check(lib.sdvar_op_split_planes(C.c_void_p(X.data_ptr()), C.c_void_p(Xp.data_ptr()), M * K, M * K, st))
-                E._check(lib.sdvar_op_split_planes(C.c_void_p(W.data_ptr()), C.c_void_p(Wp.data_ptr()), N * K, N * K, st))
+                E._check(lib.sdvar_op_split_planes(C.c_void_p(X.data_ptr()), C.c_void_p(Xp.data_ptr()), M, K, M * K, st))
+                E._check(lib.sdvar_op_split_planes(C.c_void_p(W.data_ptr()), C.c_void_p(Wp.data_ptr()), N, K, N * K, st))
                 outp = torch.empty(3, M, N, dtype=torch.int16, device=dev)
             def run():
                 if a.mode == "bf16x3":
