@@ -43,6 +43,7 @@ def host_cores():
 
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # same guide, dense bf16 MFMA; the bf16x3 GEMM spends 6 bf16 products per fp32 product
 PEAK_HBM_GBS = 8000.0             # same guide, HBM3E spec
 
 
@@ -58,6 +59,7 @@ def main():
     ap.add_argument("--mode", default="natural", choices=["natural", "accept_all", "reject_all"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-modes", action="store_true")
+    ap.add_argument("--serial-decode", action="store_true", help="decode on the sampling stream instead of overlapping it with the next batch")
     ap.add_argument("--gemm-mode", default=None, choices=["f32", "bf16x3"], help="default: sdvar_amd.engine.DEFAULT_GEMM_MODE")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark for the VQVAE decoder convs")
     args = ap.parse_args()
@@ -91,11 +93,33 @@ def main():
     lo, _ = D.shard_range(B * world, rank, world)
     labels = ((torch.arange(B) + lo) % 1000).to(dev)
 
+    # The VQVAE decode of batch i runs on a second HIP stream and overlaps the sampling loop of batch i+1 (whose early
+    # stages leave most CUs idle); f_hat is double-buffered and every decode is finished inside the timed region.
+    main_stream = torch.cuda.current_stream()
+    dec_stream = torch.cuda.Stream(device=dev)
+    fh_buf = [torch.zeros(B, 32, 16, 16, device=dev) for _ in range(2)]
+    dec_done = [None, None]
+    state = {"i": 0, "img": None}
+
     def step(mode, seed):
         res = smp.spec_decode(labels, 1.5, args.gamma, 900, 0.96, E.Noise("device", seed, image_offset=lo), thr=thr[mode])
-        img = vae.fhat_to_img(res.f_hat).add_(1).mul_(0.5)          # (B,3,256,256) in [0,1]  (var.py:215)
         st = dict(res.stats); st["images"] = B
-        return img, st
+        if args.serial_decode:
+            state["img"] = vae.fhat_to_img(res.f_hat).add_(1).mul_(0.5)          # (B,3,256,256) in [0,1]  (var.py:215)
+            return state["img"], st
+        j = state["i"] & 1; state["i"] += 1
+        if dec_done[j] is not None:
+            main_stream.wait_event(dec_done[j])                     # the decode that last read this buffer
+        fh_buf[j].copy_(res.f_hat)
+        ready = torch.cuda.Event(); ready.record(main_stream)
+        dec_stream.wait_event(ready)
+        with torch.cuda.stream(dec_stream):
+            state["img"] = vae.fhat_to_img(fh_buf[j]).add_(1).mul_(0.5)
+            dec_done[j] = torch.cuda.Event(); dec_done[j].record(dec_stream)
+        return state["img"], st
+
+    def drain():
+        dec_stream.synchronize()
 
     def timed(mode, steps, warmup):
         for i in range(warmup):
@@ -107,7 +131,7 @@ def main():
             _, st = step(mode, 1000 + i)
             for k in tot: tot[k] += int(st.get(k, 0))
         agg = D.gather_counters(tot, dev)                            # the one collective: counters only
-        torch.cuda.synchronize(); D.barrier()
+        drain(); torch.cuda.synchronize(); D.barrier()
         dt = D.max_over_ranks(time.perf_counter() - t0, dev)
         return dt, agg
 
@@ -137,8 +161,10 @@ def main():
                             target_calls_per_image_batch=a2["target_calls"] / max(1, a2["images"] // B))
 
     # ---- roofline leg: HIP events around every launch of one step (launch stream = torch's current stream)
+    drain(); torch.cuda.synchronize()
     E.prof_enable(True)
     step(args.mode, 4242)
+    drain(); torch.cuda.synchronize()
     prof = E.prof_collect()
     E.prof_enable(False)
     classes = {k: v for k, v in prof.items() if v["launches"]}
@@ -153,13 +179,19 @@ def main():
         c = classes[name]
         sec = c["ms"] * 1e-3
         if name == "gemm":
-            ach = c["flops"] / sec / 1e12
-            return dict(kernel="gemm_f32_nt_kernel", bound="mfma", achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_F32_MFMA_TFLOPS,
-                        traffic=pmc.get("gemm_f32_nt_kernel", {}).get("hbm_bytes_per_launch"), algorithmic_bytes=c["bytes"] / c["launches"],
+            ach = c["flops"] / sec / 1e12            # algorithmic 2*M*N*K per launch / measured duration
+            if tc.gemm_mode == "bf16x3":
+                peak = PEAK_BF16_MFMA_TFLOPS / 6.0   # 6 bf16 MFMA products per algorithmic fp32 product
+                kname, note = "gemm_bf16x3_{v3,v2,}_kernel", "peak = dense bf16 MFMA peak / 6 (split-operand products per fp32 product)"
+            else:
+                peak, kname, note = PEAK_F32_MFMA_TFLOPS, "gemm_f32_nt_kernel", "peak = fp32-in MFMA"
+            return dict(kernel=kname, bound="mfma", achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak, note=note,
+                        vs_fp32_mfma_peak=ach / PEAK_F32_MFMA_TFLOPS,
+                        traffic=pmc.get("gemm", {}).get("hbm_bytes_per_launch"), algorithmic_bytes=c["bytes"] / c["launches"],
                         launches=c["launches"], avg_us=c["ms"] * 1e3 / c["launches"])
         ach = c["bytes"] / sec / 1e9
         return dict(kernel=name, bound="hbm", achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS,
-                    traffic=pmc.get(name + "_f32_kernel", {}).get("hbm_bytes_per_launch"), algorithmic_bytes=c["bytes"] / c["launches"],
+                    traffic=pmc.get(name, {}).get("hbm_bytes_per_launch"), algorithmic_bytes=c["bytes"] / c["launches"],
                     launches=c["launches"], avg_us=c["ms"] * 1e3 / c["launches"], tflops=c["flops"] / sec / 1e12)
     roofline = roof(dom)
     roofline_attn = roof("attention") if "attention" in classes else None
@@ -170,9 +202,9 @@ def main():
         "metric": "images/s (+ mean accepted tokens/step), VAR-d16 256^2 B=8 per GPU, d12 draft + d16 verify",
         "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic (random-init weights, labels arange(B)%1000, device Philox noise)",
+        "dtype": "f32" if tc.gemm_mode == "f32" else "f32 (GEMM operands split exactly into 3 bf16 planes, 6 bf16 MFMA products, fp32 accumulate)", "data": "synthetic (random-init weights, labels arange(B)%1000, device Philox noise)",
         "config": {"workload": f"VAR-d{args.depth_target} 256^2 B={B}/GPU, d{args.depth_draft} draft + d{args.depth_target} verify, gamma={args.gamma}, "
-                               f"cfg=1.5 top_k=900 top_p=0.96, acceptance={args.mode}, incl. VQVAE decode", "parallelism": f"{world} independent batch shards"},
+                               f"cfg=1.5 top_k=900 top_p=0.96, acceptance={args.mode}, incl. VQVAE decode ({'serial' if args.serial_decode else 'overlapped with the next batch on a 2nd stream'})", "parallelism": f"{world} independent batch shards"},
         "mean_accepted_tokens_per_step": agg["mean_accepted_tokens_per_step"],
         "target_calls": agg["target_calls"], "draft_stage_calls": agg["draft_stage_calls"], "forced_accepts": agg["forced_accepts"],
         "images_per_s_no_decode": B * world * nd_steps / dt_nd,

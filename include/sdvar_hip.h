@@ -124,6 +124,9 @@ int sdvar_op_noise_fill(float* q, int32_t B, int32_t l, int32_t V, uint64_t seed
 
 /* tuning aid (tools/gemm_bench.py --sweep): force the GEMM row tile (32/64/128) and K-slice count; 0 = automatic */
 int sdvar_debug_set_gemm_cfg(int32_t bm, int32_t split);
+/* diagnostic: per-workgroup s_memtime stamps (4 x u64 per workgroup: entry, main loop start, main loop end, exit) of the
+ * LDS-DMA bf16x3 GEMM kernel; NULL disables */
+int sdvar_debug_set_gemm_stamps(uint64_t* stamps);
 
 /* ---- per-kernel-class timing with HIP events on the launch stream (bench.py roofline leg) ----------------------------- */
 #define SDVAR_PROF_CLASSES 8   /* 0 gemm, 1 attention, 2 ln_modulate, 3 qk_norm_append, 4 sampler, 5 verify, 6 quant, 7 embed/misc */

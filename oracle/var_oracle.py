@@ -168,7 +168,7 @@ def cfg_combine(logits_2B: Tensor, B: int, t: float) -> Tensor:               # 
     return (1 + t) * logits_2B[:B] - t * logits_2B[B:]
 
 
-def sample_topk_topp(logits: Tensor, top_k: int, top_p: float, q: Tensor) -> Tuple[Tensor, Tensor]:
+def sample_topk_topp(logits: Tensor, top_k: int, top_p: float, q: Tensor, margin_out: Optional[list] = None) -> Tuple[Tensor, Tensor]:
     """helpers.py:6-19 with the multinomial replaced by its exact equivalent argmax(p/q).
     Returns (ids (B,l) int64, masked logits)."""
     B, l, V = logits.shape
@@ -182,7 +182,11 @@ def sample_topk_topp(logits: Tensor, top_k: int, top_p: float, q: Tensor) -> Tup
         rm[..., -1:] = False
         logits.masked_fill_(rm.scatter(idx.ndim - 1, idx, rm), -torch.inf)
     p = logits.softmax(dim=-1).view(-1, V)
-    ids = torch.argmax(p / q.view(-1, V), dim=-1).view(B, l)
+    ratio = p / q.view(-1, V)
+    ids = torch.argmax(ratio, dim=-1).view(B, l)
+    if margin_out is not None:      # smallest relative gap between the winner and the runner-up: how close a draw was to a tie
+        top2 = ratio.topk(2, dim=-1)[0]
+        margin_out.append(float(((top2[:, 0] - top2[:, 1]) / top2[:, 0]).min()))
     return ids, logits
 
 
@@ -210,6 +214,7 @@ class ARTrace:
     x_in: List[Tensor] = field(default_factory=list)         # per stage (2B, pn^2, C)
     f_hat: Optional[Tensor] = None
     stats: Dict[str, object] = field(default_factory=dict)
+    margins: List[float] = field(default_factory=list)      # per sampler call: min relative top-2 gap of p/q (tie detector)
 
 
 def plain_ar(model: OracleVAR, quant: OracleQuant, label_B: Tensor, cfg: float, top_k: int, top_p: float,
@@ -225,7 +230,7 @@ def plain_ar(model: OracleVAR, quant: OracleQuant, label_B: Tensor, cfg: float, 
         logits = model.forward(x, cond, si, 1)
         t = cfg * (si / (S - 1))
         cl = cfg_combine(logits, B, t)
-        ids, _ = sample_topk_topp(cl, top_k, top_p, noise(si, B, pn * pn, model.V))
+        ids, _ = sample_topk_topp(cl, top_k, top_p, noise(si, B, pn * pn, model.V), tr.margins)
         if keep:
             tr.logits.append(logits); tr.cfg_logits.append(cl); tr.x_in.append(x)
         tr.ids.append(ids)
@@ -264,7 +269,7 @@ def spec_decode(draft: OracleVAR, target: OracleVAR, quant: OracleQuant, label_B
             lg = draft.forward(dx_r[j], d_cond, s, 1)
             st["draft_stage_calls"] += 1
             cl = cfg_combine(lg, B, cfg * (s / (S - 1)))
-            ids, _ = sample_topk_topp(cl, top_k, top_p, noise(draw, B, pns[s] ** 2, draft.V)); draw += 1
+            ids, _ = sample_topk_topp(cl, top_k, top_p, noise(draw, B, pns[s] ** 2, draft.V), tr.margins); draw += 1
             ids_r.append(ids)
             f, nxt = quant.next_input(s, f, quant.embed_ids(ids, pns[s]))
             fh_r.append(f)

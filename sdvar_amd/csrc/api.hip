@@ -25,6 +25,7 @@ int gemm_bf16x3_nt(const uint16_t* X, size_t xps, const uint16_t* W, size_t wps,
                    int M, int N, int K, int epi, const float* res, int ldres, const float* gate, int rows_per_gate, int gate_stride, hipStream_t stream);
 int split_planes(const float* x, uint16_t* planes, int rows, int cols, size_t plane_stride, hipStream_t stream);
 void debug_set_gemm_cfg_p(int bm, int split);
+void debug_set_gemm_stamps(unsigned long long* p);
 int cfg_sample(const float* logits, int B, int l, int V, float one_plus_t, float t, int top_k, int use_top_p, float top_p_thr, const float* q, uint64_t seed,
                uint32_t draw, uint32_t image_offset, long long* ids, int ids_stride, float* dbg_masked, hipStream_t stream);
 int noise_fill(float* q, int B, int l, int V, uint64_t seed, uint32_t draw, uint32_t image_offset, hipStream_t stream);
@@ -494,12 +495,14 @@ int sdvar_op_noise_fill(float* q, int32_t B, int32_t l, int32_t V, uint64_t seed
 }
 
 int sdvar_debug_set_gemm_cfg(int32_t bm, int32_t split) {
-    SDVAR_CHECK_ARG(bm == 0 || bm == 32 || bm == 64 || bm == 128, "debug_set_gemm_cfg: bm %d", bm);
+    SDVAR_CHECK_ARG(bm == 0 || bm == 32 || bm == 64 || bm == 128 || bm == 256, "debug_set_gemm_cfg: bm %d", bm);
     SDVAR_CHECK_ARG(split >= 0 && split <= 64, "debug_set_gemm_cfg: split %d", split);
     debug_set_gemm_cfg(bm, split);
     debug_set_gemm_cfg_p(bm, split);
     return SDVAR_OK;
 }
+
+int sdvar_debug_set_gemm_stamps(uint64_t* stamps) { debug_set_gemm_stamps((unsigned long long*)stamps); return SDVAR_OK; }
 
 // ---------------------------------------------------------------------------------------------------- profiling
 int sdvar_prof_enable(int32_t on) {

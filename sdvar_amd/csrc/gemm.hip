@@ -274,7 +274,7 @@ int gemm_f32_nt(const float* X, int ldx, const float* W, const float* bias, floa
     GemmArgs a{X, W, bias, out, res, gate, M, N, K, ldx, ldo, ldres, rows_per_gate > 0 ? rows_per_gate : 1, gate_stride, 1, K / BK};
     int bm, split;
     choose_cfg(M, N, K, &bm, &split);
-    if (g_force_bm) bm = g_force_bm;
+    if (g_force_bm && g_force_bm <= 128) bm = g_force_bm;
     if (g_force_split) {
         split = g_force_split;
         const int nkt = K / BK;

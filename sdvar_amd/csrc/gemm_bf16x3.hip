@@ -14,6 +14,8 @@
 // ds_read_b128 of the 8-k fragments) refilled from registers that prefetch the next K-step while the MFMAs run;
 // tiles are walked in 8-wide column groups inside each XCD's block range so that co-resident workgroups share both
 // operand panels in the per-XCD L2.  Split-K and the epilogues are those of gemm.hip.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace sdvar {
@@ -36,6 +38,8 @@ struct GemmPArgs {
     const float* bias; float* out; uint16_t* outp; size_t ops;
     const float* res; const float* gate;
     int M, N, K, ldo, ldres, rows_per_gate, gate_stride, split, k_per_split;
+    unsigned long long* dbg_stamps;   // diagnostic builds only: per-workgroup s_memtime at entry / loop start / loop end / exit
+    int dbg_same_tile;       // timing experiment only: every workgroup streams tile (0,0) (100 % L2 hits, results wrong)
 };
 
 template <int BM, int WAVES_M, int WAVES_N, int EPI>
@@ -201,7 +205,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_v2_kernel(GemmPArgs a) {
     // DMA source pointers of this lane: row 16*wave + lane/4 of each sub-array, logical chunk (lane%4) ^ ((row>>2)&3)
     const int drow = 16 * wave + (lane >> 2);
     const int dchunk = (lane & 3) ^ ((drow >> 2) & 3);
-    const int xrow = min(m0 + drow, a.M - 1), wrow = min(n0 + drow, a.N - 1);     // clamped: rows past the edge are never stored
+    const int xrow = a.dbg_same_tile ? drow : min(m0 + drow, a.M - 1), wrow = a.dbg_same_tile ? drow : min(n0 + drow, a.N - 1);   // clamped: rows past the edge are never stored
     const int kt0 = ks * a.k_per_split;
     const int nk = min(a.K / PBK - kt0, a.k_per_split);
     const uint16_t* srcx = a.X + ((size_t)kt0 * a.M + xrow) * 32 + 8 * dchunk;      // K-blocked: K-step t is the slab [t][rows][32]
@@ -228,13 +232,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_v2_kernel(GemmPArgs a) {
     const int offa0 = (wm * 64 + li) * 32, offb = (wn * 32 + li) * 32;
     const int ch0 = 8 * ((0 + lh) ^ sw), ch1 = 8 * ((2 + lh) ^ sw);
 
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+    if (a.dbg_stamps) ts0 = __builtin_amdgcn_s_memtime();
     issue(0);
     if (nk > 1) issue(1);
     for (int t = 0; t < nk; ++t) {
+        if (a.dbg_stamps && t == 1) ts1 = __builtin_amdgcn_s_memtime();
         if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (t + 2 < nk) issue(t + 2);
+        if (t + 2 < nk && a.dbg_same_tile != 2) issue(t + 2);      // (== 2: timing experiment without the DMA stream)
         // LDS byte addresses of this lane's fragments in stage t % 3 (the two k16-steps differ only in the swizzled chunk)
         const uint32_t sb = (uint32_t)(uintptr_t)(lds_ptr_t)(psm + (t % 3) * V2_STAGE);
         const uint32_t aa0 = sb + 2 * (offa0 + ch0), aa1 = sb + 2 * (offa0 + ch1), ab0 = sb + 2 * (offb + ch0), ab1 = sb + 2 * (offb + ch1);
@@ -269,6 +276,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_v2_kernel(GemmPArgs a) {
         }
     }
 
+    if (a.dbg_stamps) ts2 = __builtin_amdgcn_s_memtime();
     const int n = n0 + wn * 32 + li;
     if (n < a.N) {
         const float bv = (EPI != PEPI_PARTIAL && a.bias) ? a.bias[n] : 0.f;
@@ -284,6 +292,132 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_v2_kernel(GemmPArgs a) {
                     uint16_t p0, p1, p2;
                     split3(gelu_tanh_p(v), p0, p1, p2);
                     const size_t o = kb_index(m, n, a.M);           // the output is the next GEMM's K-blocked operand
+                    a.outp[o] = p0; a.outp[a.ops + o] = p1; a.outp[2 * a.ops + o] = p2;
+                } else {
+                    if (EPI == PEPI_GATED_RES) v = a.res[(size_t)m * a.ldres + n] + v * a.gate[(size_t)(m / a.rows_per_gate) * a.gate_stride + n];
+                    outp[(size_t)m * a.ldo + n] = v;
+                }
+            }
+        }
+    }
+    if (a.dbg_stamps && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long* o = a.dbg_stamps + 4 * (size_t)blockIdx.x;
+        o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = __builtin_amdgcn_s_memtime();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// v3: 256 x 128 workgroup tile, 8 waves (4 x 2) of 64 x 64 outputs, same LDS-DMA scheme with a 2-stage ring (72 KB per
+// stage).  Measured on v2 (in-kernel stamps, tools/micro/gemm_stamps.py): 2776 cycles per K-step against 1536 of MFMA
+// work, because the LDS array serves 144 KB of fragment reads plus 48 KB of DMA writes per K-step.  64x64 wave tiles
+// halve the fragment reads per MFMA and the taller workgroup tile cuts the DMA bytes per flop by a quarter.
+constexpr int V3_STAGE = 3 * (256 + 128) * 32;      // bf16 elements per stage: X planes [3][256][32] then W planes [3][128][32]
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_bf16x3_v3_kernel(GemmPArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t psm[];
+    constexpr int BM = 256;
+    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + PBN - 1) / PBN, ntile = tiles_m * tiles_n;
+    const int ks = blockIdx.x / ntile;
+    const int lid = xcd_remap(blockIdx.x - ks * ntile, ntile);
+    const int G = 8, per_group = tiles_m * G;
+    const int g = lid / per_group, rem = lid - g * per_group;
+    const int gw = min(G, tiles_n - g * G);
+    const int tm = rem / gw, tn = g * G + rem % gw;
+    const int m0 = tm * BM, n0 = tn * PBN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+
+    // DMA: wave w fills X rows [32w, 32w+32) (two 16-row groups) and W rows [16w, 16w+16) of every plane: 9 instructions
+    const int r16 = lane >> 2;
+    const int xr0 = 32 * wave + r16, xr1 = xr0 + 16, wr = 16 * wave + r16;
+    const int cx0 = (lane & 3) ^ ((xr0 >> 2) & 3), cx1 = (lane & 3) ^ ((xr1 >> 2) & 3), cw = (lane & 3) ^ ((wr >> 2) & 3);
+    const int kt0 = ks * a.k_per_split;
+    const int nk = min(a.K / PBK - kt0, a.k_per_split);
+    const uint16_t* sx0 = a.X + ((size_t)kt0 * a.M + min(m0 + xr0, a.M - 1)) * 32 + 8 * cx0;
+    const uint16_t* sx1 = a.X + ((size_t)kt0 * a.M + min(m0 + xr1, a.M - 1)) * 32 + 8 * cx1;
+    const uint16_t* sw0 = a.W + ((size_t)kt0 * a.N + min(n0 + wr, a.N - 1)) * 32 + 8 * cw;
+    auto issue = [&](int t) {
+        uint16_t* st = psm + (t & 1) * V3_STAGE;
+        const size_t ox = (size_t)t * a.M * 32, ow = (size_t)t * a.N * 32;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(sx0 + ox + p * a.xps), (lds_ptr_t)(st + p * 8192 + wave * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(sx1 + ox + p * a.xps), (lds_ptr_t)(st + p * 8192 + wave * 1024 + 512), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(sw0 + ow + p * a.wps), (lds_ptr_t)(st + 3 * 8192 + p * 4096 + wave * 512), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int sw = (li >> 2) & 3;
+    const int offa = (wm * 64 + li) * 32, offb = 3 * 8192 + (wn * 64 + li) * 32;     // element offsets inside a stage
+    const int ch0 = 8 * ((0 + lh) ^ sw), ch1 = 8 * ((2 + lh) ^ sw);
+
+    issue(0);
+    for (int t = 0; t < nk; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 1 < nk) issue(t + 1);
+        const uint32_t sb = (uint32_t)(uintptr_t)(lds_ptr_t)(psm + (t & 1) * V3_STAGE);
+        const uint32_t aa0 = sb + 2 * (offa + ch0), aa1 = sb + 2 * (offa + ch1), ab0 = sb + 2 * (offb + ch0), ab1 = sb + 2 * (offb + ch1);
+        bf16x8 fa[2][3][2], fb[2][3][2];
+#define SDVAR_LDS_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr) : "memory")
+        // X plane p at +16384 p bytes, second 32-row tile at +2048; W plane p at +8192 p bytes, second tile at +2048
+        SDVAR_LDS_RD(fa[0][0][0], aa0, 0);     SDVAR_LDS_RD(fb[0][2][0], ab0, 16384); SDVAR_LDS_RD(fa[0][1][0], aa0, 16384);
+        SDVAR_LDS_RD(fb[0][1][0], ab0, 8192);  SDVAR_LDS_RD(fa[0][2][0], aa0, 32768); SDVAR_LDS_RD(fb[0][0][0], ab0, 0);
+        SDVAR_LDS_RD(fb[0][2][1], ab0, 18432); SDVAR_LDS_RD(fb[0][1][1], ab0, 10240); SDVAR_LDS_RD(fb[0][0][1], ab0, 2048);
+        SDVAR_LDS_RD(fa[0][0][1], aa0, 2048);  SDVAR_LDS_RD(fa[0][1][1], aa0, 18432); SDVAR_LDS_RD(fa[0][2][1], aa0, 34816);
+        SDVAR_LDS_RD(fa[1][0][0], aa1, 0);     SDVAR_LDS_RD(fb[1][2][0], ab1, 16384); SDVAR_LDS_RD(fa[1][1][0], aa1, 16384);
+        SDVAR_LDS_RD(fb[1][1][0], ab1, 8192);  SDVAR_LDS_RD(fa[1][2][0], aa1, 32768); SDVAR_LDS_RD(fb[1][0][0], ab1, 0);
+        SDVAR_LDS_RD(fb[1][2][1], ab1, 18432); SDVAR_LDS_RD(fb[1][1][1], ab1, 10240); SDVAR_LDS_RD(fb[1][0][1], ab1, 2048);
+        SDVAR_LDS_RD(fa[1][0][1], aa1, 2048);  SDVAR_LDS_RD(fa[1][1][1], aa1, 18432); SDVAR_LDS_RD(fa[1][2][1], aa1, 34816);
+#undef SDVAR_LDS_RD
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (s == 0) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][0][i], fb[s][2][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][1][i], fb[s][1][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][2][i], fb[s][0][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][0][i], fb[s][1][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][1][i], fb[s][0][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][0][i], fb[s][0][j], acc[i][j], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + li;
+        if (n >= a.N) continue;
+        const float bv = (EPI != PEPI_PARTIAL && a.bias) ? a.bias[n] : 0.f;
+        float* outp = (EPI == PEPI_PARTIAL) ? a.out + (size_t)ks * a.M * a.ldo : a.out;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= a.M) continue;
+                float v = acc[i][j][r] + bv;
+                if (EPI == PEPI_BIAS_GELU_PLANES) {
+                    uint16_t p0, p1, p2;
+                    split3(gelu_tanh_p(v), p0, p1, p2);
+                    const size_t o = kb_index(m, n, a.M);
                     a.outp[o] = p0; a.outp[a.ops + o] = p1; a.outp[2 * a.ops + o] = p2;
                 } else {
                     if (EPI == PEPI_GATED_RES) v = a.res[(size_t)m * a.ldres + n] + v * a.gate[(size_t)(m / a.rows_per_gate) * a.gate_stride + n];
@@ -356,6 +490,26 @@ int split_planes(const float* x, uint16_t* planes, int rows, int cols, size_t pl
 
 float* splitk_workspace(size_t* floats);     // gemm.hip: the shared slab workspace
 
+// cost-model constants (see choose_cfg_p; tools/fit_gemm_model.py on profiles/r01_e_gemm_sweep_bf16x3.jsonl: geometric-mean
+// regret 1.8 %, worst case 21 %, over the d12 / d16 shapes incl. gamma = 2 chunks)
+#define CM_R256 1
+#define CM_R128 1
+#define CM_R64 3
+#define CM_R32 3
+#define CM_P256 1.1
+#define CM_P64 1.3
+#define CM_P32 1.3
+#define CM_L1 1.2
+#define CM_L2 1.0
+#define CM_L3 1.0
+#define CM_KOVER 260.0
+#define CM_FIX 1500.0
+#define CM_FIXBM 20.0
+#define CM_RED0 2000.0
+#define CM_REDBW 5000.0
+
+static unsigned long long* g_dbg_stamps = nullptr;
+void debug_set_gemm_stamps(unsigned long long* p) { g_dbg_stamps = p; }
 static int g_force_bm_p = 0, g_force_split_p = 0;
 void debug_set_gemm_cfg_p(int bm, int split) { g_force_bm_p = bm; g_force_split_p = split; }
 
@@ -363,25 +517,27 @@ void debug_set_gemm_cfg_p(int bm, int split) { g_force_bm_p = bm; g_force_split_
 static void choose_cfg_p(int M, int N, int K, size_t ws_floats, int* bm_out, int* split_out) {
     const int nkt = K / PBK, tiles_n = (N + PBN - 1) / PBN;
     double best = 1e30; int bbm = 128, bs = 1;
-    const int bms[3] = {128, 64, 32};
-    // constants fitted to tools/gemm_bench.py --mode bf16x3 --sweep --dump (d12 / d16 shapes, single stages and gamma = 2
-    // chunks; 128-row tiles run the LDS-DMA kernel): geometric-mean regret 2.1 % against the best swept configuration
-    const int resident[3] = {2, 2, 4};
-    const double lat[5] = {0.0, 1.5, 1.4, 1.05, 1.0};
-    for (int bi = 0; bi < 3; ++bi) {
+    // per row-tile constants fitted to tools/gemm_bench.py --mode bf16x3 --sweep --dump (tools/fit_gemm_model.py):
+    //   resident workgroups per CU, K-step cost factor over the MFMA time, slowdown when 1 / 2 / 3 workgroups share a CU
+    const int bms[4] = {256, 128, 64, 32};
+    const int resident[4] = {CM_R256, CM_R128, CM_R64, CM_R32};
+    const double kfac[4] = {CM_P256, 1.0, CM_P64, CM_P32};
+    const double lat[5] = {0.0, CM_L1, CM_L2, CM_L3, 1.0};
+    for (int bi = 0; bi < 4; ++bi) {
         const int bm = bms[bi], res = resident[bi];
         const int tiles = ((M + bm - 1) / bm) * tiles_n;
-        const double ktile = 384.0 * (bm / 32) * (bm == 128 ? 1.0 : 1.2);   // 6 MFMAs x 32 cycles x 2 k16-steps per 32x32 sub-tile
+        const double ktile = 384.0 * (bm / 32) * kfac[bi];              // 6 MFMAs x 32 cycles x 2 k16-steps per 32x32 sub-tile
         for (int split = 1; split <= 32 && split <= nkt / 2; ++split) {
             if (split > 1 && ((size_t)split * M * N > ws_floats || N % 4)) break;
             const int kps = (nkt + split - 1) / split;
             if ((nkt + kps - 1) / kps != split) continue;
             const long blocks = (long)tiles * split;
             const long per_cu = (blocks + 255) / 256;
-            const double T = kps * (ktile + 600.0) + 8000.0 + 80.0 * bm;    // + per-K-step sync/refill, prologue + epilogue
+            const double T = kps * (ktile + CM_KOVER) + CM_FIX + CM_FIXBM * bm;    // + per-K-step sync/refill, prologue + epilogue
             const long full = per_cu / res, rem = per_cu % res;
-            double cyc = full * res * T * lat[res] + (rem ? rem * T * lat[rem] : 0.0);
-            if (split > 1) cyc += 4000.0 + (double)(split + 1) * M * N * 4.0 / 5000.0;
+            const double l_full = (bm == 256) ? 1.0 : lat[res < 4 ? res : 4], l_rem = (bm == 256) ? 1.0 : lat[rem < 4 ? rem : 4];
+            double cyc = full * res * T * l_full + (rem ? rem * T * l_rem : 0.0);
+            if (split > 1) cyc += CM_RED0 + (double)(split + 1) * M * N * 4.0 / CM_REDBW;
             if (cyc < best) { best = cyc; bbm = bm; bs = split; }
         }
     }
@@ -402,6 +558,53 @@ static int launch_v2_kernel(const GemmPArgs& a, int grid, hipStream_t stream) {
     hipLaunchKernelGGL((gemm_bf16x3_v2_kernel<EPI>), dim3(grid), dim3(512), lds, stream, a);
     SDVAR_LAUNCH_CHECK();
     return SDVAR_OK;
+}
+
+template <int EPI>
+static int launch_v3_kernel(const GemmPArgs& a, int grid, hipStream_t stream) {
+    const size_t lds = 2 * (size_t)V3_STAGE * sizeof(uint16_t);      // 144 KB
+    static bool attr_set = false;
+    if (!attr_set) {
+        SDVAR_HIP(hipFuncSetAttribute((const void*)gemm_bf16x3_v3_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_bf16x3_v3_kernel<EPI>), dim3(grid), dim3(512), lds, stream, a);
+    SDVAR_LAUNCH_CHECK();
+    return SDVAR_OK;
+}
+
+static int launch_reduce_p(const GemmPArgs& a, const float* ws, int split, int epi, hipStream_t stream) {
+    const size_t total = (size_t)a.M * (a.N / 4);
+    const int rgrid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    dim3 block(256);
+    switch (epi) {
+        case PEPI_BIAS: hipLaunchKernelGGL(splitk_reduce_p_kernel<PEPI_BIAS>, dim3(rgrid), block, 0, stream, ws, split, a.bias, a.out, a.outp, a.ops, a.res, a.gate, a.M, a.N, a.ldo, a.ldres, a.rows_per_gate, a.gate_stride); break;
+        case PEPI_BIAS_GELU_PLANES: hipLaunchKernelGGL(splitk_reduce_p_kernel<PEPI_BIAS_GELU_PLANES>, dim3(rgrid), block, 0, stream, ws, split, a.bias, a.out, a.outp, a.ops, a.res, a.gate, a.M, a.N, a.ldo, a.ldres, a.rows_per_gate, a.gate_stride); break;
+        default: hipLaunchKernelGGL(splitk_reduce_p_kernel<PEPI_GATED_RES>, dim3(rgrid), block, 0, stream, ws, split, a.bias, a.out, a.outp, a.ops, a.res, a.gate, a.M, a.N, a.ldo, a.ldres, a.rows_per_gate, a.gate_stride); break;
+    }
+    SDVAR_LAUNCH_CHECK();
+    return SDVAR_OK;
+}
+
+static int launch_v3(GemmPArgs a, int epi, int split, hipStream_t stream) {
+    const int tiles = ((a.M + 255) / 256) * ((a.N + PBN - 1) / PBN);
+    const int nkt = a.K / PBK;
+    if (split > 1) {
+        size_t wsf = 0;
+        float* ws = splitk_workspace(&wsf);
+        if (!ws) return SDVAR_ERR_HIP;
+        GemmPArgs p = a;
+        p.out = ws; p.ldo = a.N; p.split = split; p.k_per_split = (nkt + split - 1) / split;
+        int rc = launch_v3_kernel<PEPI_PARTIAL>(p, tiles * split, stream);
+        if (rc) return rc;
+        return launch_reduce_p(a, ws, split, epi, stream);
+    }
+    a.split = 1; a.k_per_split = nkt;
+    switch (epi) {
+        case PEPI_BIAS: return launch_v3_kernel<PEPI_BIAS>(a, tiles, stream);
+        case PEPI_BIAS_GELU_PLANES: return launch_v3_kernel<PEPI_BIAS_GELU_PLANES>(a, tiles, stream);
+        default: return launch_v3_kernel<PEPI_GATED_RES>(a, tiles, stream);
+    }
 }
 
 template <int BM, int WAVES_M, int WAVES_N>
@@ -456,7 +659,8 @@ int gemm_bf16x3_nt(const uint16_t* X, size_t xps, const uint16_t* W, size_t wps,
     SDVAR_CHECK_ARG(epi == PEPI_BIAS_GELU_PLANES ? (outp != nullptr && N % 4 == 0) : (out != nullptr && ldo >= N), "gemm_bf16x3: missing output");
     SDVAR_CHECK_ARG(((uintptr_t)X % 16) == 0 && ((uintptr_t)W % 16) == 0 && xps % 8 == 0 && wps % 8 == 0, "gemm_bf16x3: planes must be 16-byte aligned");
     if (epi == PEPI_GATED_RES) SDVAR_CHECK_ARG(res && gate && rows_per_gate > 0 && ldres >= N, "gemm_bf16x3: gated-residual epilogue needs res/gate");
-    GemmPArgs a{X, W, xps, wps, bias, out, outp, ops, res, gate, M, N, K, ldo, ldres, rows_per_gate > 0 ? rows_per_gate : 1, gate_stride, 1, K / PBK};
+    GemmPArgs a{X, W, xps, wps, bias, out, outp, ops, res, gate, M, N, K, ldo, ldres, rows_per_gate > 0 ? rows_per_gate : 1, gate_stride, 1, K / PBK,
+                g_dbg_stamps, getenv("SDVAR_DEBUG_SAME_TILE") ? atoi(getenv("SDVAR_DEBUG_SAME_TILE")) : 0};
     size_t wsf = 0;
     (void)splitk_workspace(&wsf);
     int bm, split;
@@ -470,6 +674,7 @@ int gemm_bf16x3_nt(const uint16_t* X, size_t xps, const uint16_t* W, size_t wps,
         const int kps = (nkt + split - 1) / split;
         split = (nkt + kps - 1) / kps;
     }
+    if (bm == 256) return launch_v3(a, epi, split, stream);
     if (bm == 32) return launch_p<32, 1, 4>(a, epi, split, stream);
     if (bm == 64) return launch_p<64, 2, 2>(a, epi, split, stream);
     return launch_p<128, 2, 2>(a, epi, split, stream);

@@ -112,6 +112,21 @@ def check_multinomial_equivalence():
     assert torch.equal(a, b), "F6 does not hold on this host"
 
 
+MIN_MARGIN = 1e-3     # fixtures avoid near-ties: a token whose top-2 draw ratios differ by less than this could flip under the
+                      # ~1e-5 logit noise of ANY fp32 evaluation order (the CPU's included), making "bit-exact ids" ill-posed
+
+
+def pick_seed(run, start=0, tries=60):
+    """First seed whose run keeps every sampled token at least MIN_MARGIN away from a tie."""
+    best = (0.0, start)
+    for seed in range(start, start + tries):
+        m = run(seed)
+        if m >= MIN_MARGIN:
+            return seed, m
+        best = max(best, (m, seed))
+    raise RuntimeError(f"no seed with margin >= {MIN_MARGIN}: best {best}")
+
+
 def plain_ar_fixture(name, depth, patch_nums, B, labels, cfg, top_k, top_p, g_seed, mode, wseed, store_logits_rows=2):
     t0 = time.time()
     vae, var, sd_var, sd_vae = build_ref(depth, patch_nums, mode, wseed)
@@ -119,6 +134,9 @@ def plain_ar_fixture(name, depth, patch_nums, B, labels, cfg, top_k, top_p, g_se
     V = 4096
     model = orc.OracleVAR(sd_var, depth, patch_nums)
     quant = orc.OracleQuant(sd_vae, patch_nums)
+    g_seed, m0 = pick_seed(lambda sd_: min(orc.plain_ar(model, quant, label_B, cfg, top_k, top_p, orc.array_noise(
+        lambda d, B_, l, V_: exponential_noise(sd_, d, B_, l, V_)), keep=False).margins), start=g_seed)
+    print(f"[golden] {name}: seed {g_seed} (min margin {m0:.2e})")
     out = dict(depth=depth, patch_nums=np.array(patch_nums), B=B, labels=np.array(labels), cfg=cfg, top_k=top_k, top_p=top_p,
                g_seed=g_seed, mode=mode, wseed=wseed,
                w_digest=digest(sd_var["head.weight"]), vae_digest=digest(sd_vae["quantize.embedding.weight"]))
@@ -241,8 +259,22 @@ def sd_fixture():
     draft.eval(); target.eval()
     od, ot, oq = orc.OracleVAR(sd_d, dd, pns), orc.OracleVAR(sd_t, dt, pns), orc.OracleQuant(sd_v, pns)
     labels = torch.tensor([3, 977])
-    out = dict(dd=dd, dt=dt, B=B, labels=labels.numpy())
     V = 4096
+
+    def all_margins(seed):
+        nf = orc.array_noise(lambda d, B_, l, V_: exponential_noise(seed, d, B_, l, V_))
+        m = min(orc.plain_ar(od, oq, labels, 1.5, 900, 0.96, nf, keep=False).margins + orc.plain_ar(ot, oq, labels, 1.5, 900, 0.96, nf, keep=False).margins)
+        if m < MIN_MARGIN:
+            return m
+        for thr in (0.5, 0.0, 2.0):
+            for gamma in (1, 2, 3):
+                m = min(m, min(orc.spec_decode(od, ot, oq, labels, 1.5, gamma, 900, 0.96, nf, thr=thr).margins))
+                if m < MIN_MARGIN:
+                    return m
+        return m
+    SEED, m0 = pick_seed(all_margins)
+    print(f"[golden] sd_components: seed {SEED} (min margin over 11 runs {m0:.2e})")
+    out = dict(dd=dd, dt=dt, B=B, labels=labels.numpy(), seed=SEED, min_margin=m0)
 
     # -- basic_token_matching (var.py:1160-1227) known answers vs oracle accept_scan
     class St: pass
@@ -269,12 +301,12 @@ def sd_fixture():
 
     # -- draft_generate_batch round 1 (var.py:949-1024) for gamma 1..3 under the portable noise
     for gamma in (1, 2, 3):
-        state = sd._initialize_inference_state(B, labels, 0, 1.5, gamma)
+        state = sd._initialize_inference_state(B, labels, SEED, 1.5, gamma)
         state.top_k, state.top_p = 900, 0.96
-        with PortableMultinomial(0, B, V):
+        with PortableMultinomial(SEED, B, V):
             toks = sd.draft_generate_batch(state, B)
         for blk in draft.blocks: blk.attn.kv_caching(False)
-        nfn = orc.array_noise(lambda d, B_, l, V_: exponential_noise(0, d, B_, l, V_))
+        nfn = orc.array_noise(lambda d, B_, l, V_: exponential_noise(SEED, d, B_, l, V_))
         # oracle: the first `gamma` stages of a plain draft AR are the same computation
         tr = orc.plain_ar(od, oq, labels, 1.5, 900, 0.96, nfn, keep=False)
         for j in range(gamma):
@@ -309,8 +341,8 @@ def sd_fixture():
         out[f"chunk_{s0}_{n}_row"] = lg_chunk[0, -1].numpy()
     # -- I6: sd_test3 hand-off (var.py:604-865) entry_num 0 / S equals plain target / draft AR
     for entry, who, omodel in ((0, "target", ot), (10, "draft", od)):
-        with Recorder() as rec, PortableMultinomial(0, B, V):
-            sd.sdvar_autoregressive_infer_cfg_sd_test3(B=B, label_B=labels, g_seed=0, cfg=1.5, top_k=900, top_p=0.96, entry_num=entry, sd_mask=0)
+        with Recorder() as rec, PortableMultinomial(SEED, B, V):
+            sd.sdvar_autoregressive_infer_cfg_sd_test3(B=B, label_B=labels, g_seed=SEED, cfg=1.5, top_k=900, top_p=0.96, entry_num=entry, sd_mask=0)
         tr2 = orc.plain_ar(omodel, oq, labels, 1.5, 900, 0.96, nfn, keep=False)
         for s in range(10):
             assert torch.equal(rec.ids[s], tr2.ids[s]), ("sd_test3", entry, s)

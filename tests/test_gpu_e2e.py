@@ -92,7 +92,7 @@ def test_chunk_verify_logits_vs_reference_fixture(dev, pair):
     smp, (od, ot, oq) = pair
     g = golden("sd_components")
     labels = torch.from_numpy(g["labels"]).long()
-    tr = orc.plain_ar(ot, oq, labels, 1.5, 900, 0.96, _noise_o(0), keep=True)
+    tr = orc.plain_ar(ot, oq, labels, 1.5, 900, 0.96, _noise_o(int(g["seed"])), keep=True)
     t, lad, B, V = smp.t, smp.lad, 2, 4096
     for (s0, n) in ((3, 2), (5, 3), (0, 2), (8, 2)):
         t.begin(labels.to(dev))
@@ -115,13 +115,14 @@ def test_spec_decode_vs_oracle(dev, pair, mode, thr, gamma):
     smp, (od, ot, oq) = pair
     g = golden("sd_components")
     labels = torch.from_numpy(g["labels"]).long()
-    res = smp.spec_decode(labels.to(dev), 1.5, gamma, 900, 0.96, E.Noise("host", 0), thr=thr)
+    SEED = int(g["seed"])
+    res = smp.spec_decode(labels.to(dev), 1.5, gamma, 900, 0.96, E.Noise("host", SEED), thr=thr)
     want_ids = g[f"spec_{mode}_g{gamma}_ids"].astype(np.int64)
     ids = res.ids.cpu().numpy()
     assert np.array_equal(ids, want_ids), _flip_report(ids, want_ids, smp.lad)
     st = res.stats
     assert [st["target_calls"], st["draft_stage_calls"], st["forced_accepts"], st["accepted_tokens"]] == list(g[f"spec_{mode}_g{gamma}_stats"])
-    tr = orc.spec_decode(od, ot, oq, labels, 1.5, gamma, 900, 0.96, _noise_o(0), thr=thr)
+    tr = orc.spec_decode(od, ot, oq, labels, 1.5, gamma, 900, 0.96, _noise_o(SEED), thr=thr)
     assert (res.f_hat.cpu() - tr.f_hat).abs().max().item() <= 1e-4
     assert [r["n_accept"] for r in st["rounds"]] == [r["n_accept"] for r in tr.stats["rounds"]]
     assert [r["matched"] for r in st["rounds"]] == [r["matched"] for r in tr.stats["rounds"]]

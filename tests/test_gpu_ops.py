@@ -356,17 +356,18 @@ def test_ln_and_attention_plane_outputs_equal_fp32_outputs(dev):
     assert torch.equal(_unplanes(ap).float().view(R, l, H * 64), a32)
 
 
+@pytest.mark.parametrize("bm", [128, 256])
 @pytest.mark.parametrize("M,N,K,split", [(130, 192, 64, 1), (1, 128, 32, 1), (257, 384, 1024, 3), (4096, 256, 1024, 1), (2704, 1024, 4096, 5), (100, 4096, 1024, 2)])
 @pytest.mark.parametrize("epi", [0, 1, 2])
-def test_gemm_bf16x3_v2_forced_128_tile(dev, M, N, K, split, epi):
-    """The LDS-DMA pipelined 128x128 kernel on ragged edges (clamped source rows), short K loops and split-K."""
+def test_gemm_bf16x3_lds_dma_kernels_forced_tile(dev, M, N, K, split, epi, bm):
+    """The LDS-DMA pipelined 128x128 / 256x128 kernels on ragged edges (clamped source rows), short K loops and split-K."""
     lib = E.load_library()
     X, W, b = rnd(1, (M, K)), rnd(2, (N, K), 1 / math.sqrt(K)), rnd(3, (N,)).to(dev)
     Xp, Wp = _planes(X, dev), _planes(W, dev)
     res, gate = rnd(4, (M, N)).to(dev), rnd(5, (M, 2 * N)).to(dev)
     out = res.clone() if epi == 2 else torch.full((M, N), float("nan"), device=dev)
     outp = torch.empty(3, N // 32, M, 32, dtype=torch.int16, device=dev) if epi == 1 else None
-    E._check(lib.sdvar_debug_set_gemm_cfg(128, split))
+    E._check(lib.sdvar_debug_set_gemm_cfg(bm, split))
     try:
         E._check(lib.sdvar_op_gemm_bf16x3(_p(Xp), M * K, _p(Wp), N * K, _p(b), _p(out), N, _p(outp), M * N, M, N, K, epi, _p(out) if epi == 2 else None, N,
                                           _p(gate) if epi == 2 else None, 1, 2 * N, _st()))

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Fit the constants of gemm_bf16x3.hip::choose_cfg_p to a sweep dump (tools/gemm_bench.py --mode bf16x3 --sweep --dump F).
+Random search minimising the geometric-mean regret (time of the model's pick / time of the best swept configuration)."""
+import json, math, random, sys
+rows = [json.loads(l) for l in open(sys.argv[1])]
+
+def model(M, N, K, bm, split, c):
+    nkt, tiles_n = K // 32, (N + 127) // 128
+    res = {256: 1, 128: c['r128'], 64: c['r64'], 32: c['r32']}[bm]
+    tiles = ((M + bm - 1) // bm) * tiles_n
+    ktile = 384.0 * (bm // 32) * {256: c['p256'], 128: 1.0, 64: c['p64'], 32: c['p32']}[bm]
+    kps = (nkt + split - 1) // split
+    per_cu = (tiles * split + 255) // 256
+    T = kps * (ktile + c['kover']) + c['fix'] + c['fixbm'] * bm
+    lat = [0, c['l1'], c['l2'], c['l3'], 1.0]
+    full, rem = per_cu // res, per_cu % res
+    lf = 1.0 if bm == 256 else lat[min(res, 4)]
+    lr = 1.0 if bm == 256 else lat[min(rem, 4)]
+    cyc = full * res * T * lf + (rem * T * lr if rem else 0)
+    if split > 1:
+        cyc += c['red0'] + (split + 1) * M * N * 4.0 / c['redbw']
+    return cyc
+
+def regret(c, verbose=False):
+    tot, worst = 0.0, 0.0
+    for r in rows:
+        cands = r['cands']
+        best = min(t for t, _, _ in cands)
+        pick = min(cands, key=lambda x: model(r['M'], r['N'], r['K'], x[1], x[2], c))
+        reg = pick[0] / best
+        tot += math.log(reg); worst = max(worst, reg)
+        if verbose and reg > 1.08:
+            print(r['op'], r['M'], r['N'], r['K'], 'pick', pick, 'best', min(cands))
+    return math.exp(tot / len(rows)), worst
+
+base = dict(r128=2, r64=2, r32=4, p256=1.0, p64=1.2, p32=1.2, kover=600, fix=8000, fixbm=80, l1=1.5, l2=1.4, l3=1.05, red0=4000, redbw=5000)
+space = dict(p256=[0.8, 0.85, 0.9, 0.95, 1.0, 1.1], p64=[1.0, 1.1, 1.2, 1.3], p32=[1.1, 1.2, 1.3, 1.5], kover=[100, 260, 400, 600, 900, 1200],
+             fix=[1500, 3000, 5000, 8000, 12000], fixbm=[0, 20, 40, 80], l1=[1.0, 1.2, 1.5, 2.0], l2=[1.0, 1.1, 1.2, 1.4], l3=[1.0, 1.05, 1.1],
+             red0=[2000, 4000, 6000, 10000], redbw=[1800, 3000, 5000, 8000], r128=[1, 2], r64=[2, 3], r32=[3, 4])
+random.seed(0)
+best = (regret(base)[0], base)
+print('start', regret(base))
+for it in range(12000):
+    c = dict(best[1])
+    for k in random.sample(list(space), 3):
+        c[k] = random.choice(space[k])
+    g, w = regret(c)
+    if g < best[0] - 1e-6:
+        best = (g, c)
+print(best, regret(best[1]))
+regret(best[1], True)

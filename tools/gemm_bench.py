@@ -60,7 +60,7 @@ def main():
             us = timeit()
             if a.sweep:
                 res = []
-                for bm in (32, 64, 128):
+                for bm in ((32, 64, 128, 256) if a.mode == "bf16x3" else (32, 64, 128)):
                     for split in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 24, 32):
                         if split > K // 64: continue
                         E._check(lib.sdvar_debug_set_gemm_cfg(bm, split))
