@@ -62,6 +62,9 @@ int sdvar_model_bind_head(sdvar_model_t* m, const float* nm_w, const float* nm_b
  * of every block and of the head hoisted out of the stage loop (basic_var.py:156, :173 - cond never changes), KV
  * length cursor reset (basic_var.py:87).  labels: (B) int64. */
 int sdvar_model_begin(sdvar_model_t* m, int32_t B, const int64_t* labels, void* stream);
+/* the tensors SDVAR.init_param returns (var.py:580-601), copied out of the model object: cond (2B,C), lvl_pos (L,C),
+ * first-token map (2B,C); any pointer may be NULL */
+int sdvar_model_export_prologue(sdvar_model_t* m, float* cond, float* lvl_pos, float* first, void* stream);
 /* copy the first-token map (R,1,C) into a chunk input x (R, ltot, C) at token 0 */
 int sdvar_model_place_first(sdvar_model_t* m, float* x, int32_t ltot, void* stream);
 /* KV-cache cursor: number of valid keys; set_len(n) with n <= current is the rollback after a rejected round. */

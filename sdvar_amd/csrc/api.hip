@@ -285,6 +285,16 @@ int sdvar_model_place_first(sdvar_model_t* m, float* x, int32_t ltot, void* stre
     return SDVAR_OK;
 }
 
+int sdvar_model_export_prologue(sdvar_model_t* m, float* cond, float* lvl_pos, float* first, void* stream) {
+    SDVAR_CHECK_ARG(m && m->begun, "export_prologue: model not begun");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t rc = (size_t)2 * m->B * m->C * sizeof(float);
+    if (cond) SDVAR_HIP(hipMemcpyAsync(cond, m->cond, rc, hipMemcpyDeviceToDevice, s));
+    if (first) SDVAR_HIP(hipMemcpyAsync(first, m->x0, rc, hipMemcpyDeviceToDevice, s));
+    if (lvl_pos) SDVAR_HIP(hipMemcpyAsync(lvl_pos, m->lvl_pos, (size_t)m->L * m->C * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return SDVAR_OK;
+}
+
 int sdvar_kv_len(const sdvar_model_t* m) { return m ? m->kv_len : -1; }
 
 int sdvar_kv_set_len(sdvar_model_t* m, int32_t len) {

@@ -51,6 +51,7 @@ _SIGNATURES = {
     "sdvar_model_bind_block": (_I, [_P, _I] + [_P] * 13),
     "sdvar_model_bind_head": (_I, [_P] * 6),
     "sdvar_model_begin": (_I, [_P, _I, _P, _P]),
+    "sdvar_model_export_prologue": (_I, [_P, _P, _P, _P, _P]),
     "sdvar_model_place_first": (_I, [_P, _P, _I, _P]),
     "sdvar_kv_len": (_I, [_P]),
     "sdvar_kv_set_len": (_I, [_P, _I]),
@@ -165,6 +166,13 @@ class ModelCtx:
         assert labels.dtype == torch.int64 and labels.is_cuda
         self.B = labels.shape[0]
         _check(self.lib.sdvar_model_begin(self.h, self.B, _ptr(labels), _stream()))
+
+    def export_prologue(self):
+        """(cond (2B,C), lvl_pos (1,L,C), first_token_map (2B,1,C)) of the current call, as SDVAR.init_param returns them."""
+        f = dict(device=self.device, dtype=torch.float32)
+        cond, lvl, first = torch.empty(2 * self.B, self.Cw, **f), torch.empty(1, self.lad.L, self.Cw, **f), torch.empty(2 * self.B, 1, self.Cw, **f)
+        _check(self.lib.sdvar_model_export_prologue(self.h, _ptr(cond), _ptr(lvl), _ptr(first), _stream()))
+        return cond, lvl, first
 
     def place_first(self, x: torch.Tensor, ltot: int):
         _check(self.lib.sdvar_model_place_first(self.h, _ptr(x), ltot, _stream()))
@@ -342,72 +350,151 @@ class Sampler:
         res.stats = dict(target_calls=S, draft_stage_calls=0, forced_accepts=0, accepted_tokens=0)
         return res
 
-    # ---- speculative draft -> verify loop
+    # ---- speculative draft -> verify loop, as the reference's four steps
+    def spec_begin(self, labels: torch.Tensor, cfg: float, gamma: int, top_k: int, top_p: float, noise: Noise, thr: float = 0.5) -> "SpecState":
+        """SDVAR._initialize_inference_state (var.py:871-947): both prologues, empty caches, counters."""
+        assert self.d is not None, "the speculative loop needs a draft model"
+        assert 1 <= gamma <= self.t.max_chunk, f"gamma {gamma} exceeds the engine's max_chunk {self.t.max_chunk}"
+        with torch.cuda.device(self.dev):
+            self.d.begin(labels); self.t.begin(labels)
+            self.f_acc[:labels.shape[0]].zero_()
+        return SpecState(sampler=self, labels=labels, B=labels.shape[0], cfg=cfg, gamma=gamma, top_k=top_k, top_p=top_p, noise=noise, thr=thr,
+                         total_stages=self.lad.S, patch_nums=self.lad.patch_nums)
+
+    def spec_draft(self, st: "SpecState") -> int:
+        """SDVAR.draft_generate_batch (var.py:949-1024): g = min(gamma, S - cur) draft stages (forward, CFG, sample, quant,
+        next-stage inputs for BOTH models).  Token ids land in self.ids, f_hat snapshots in self.f_snap."""
+        d, t, qz, lad = self.d, self.t, self.q, self.lad
+        B, V, S, L, lens, cur = st.B, t.V, lad.S, lad.L, lad.lens, st.current_stage
+        g = min(st.gamma, S - cur)
+        if g <= 0:
+            return 0
+        st.g, st.glen = g, lens[cur:cur + g]
+        lsum = sum(st.glen)
+        offs = [sum(st.glen[:j]) for j in range(g)]
+        f_acc, f_work = self.f_acc[:B], self.f_work[:B]
+        with torch.cuda.device(self.dev):
+            if cur == 0:
+                d.place_first(self.x_d, lens[0]); t.place_first(self.x_t, lsum)
+            else:
+                d.embed_next(self.nxt_cur, cur, self.x_d, lens[cur], 0); t.embed_next(self.nxt_cur, cur, self.x_t, lsum, 0)
+            f_work.copy_(f_acc)
+            for j in range(g):
+                s = cur + j
+                d.forward(self.x_d, s, 1, self.logits_d)
+                st.stats["draft_stage_calls"] += 1
+                q = st.noise.tensor(st.draw, B, lens[s], V, self.dev)
+                cfg_sample(self.logits_d, B, lens[s], V, lad.cfg_t(st.cfg, s), st.top_k, st.top_p, q, st.noise.seed, st.draw, st.noise.image_offset,
+                           self.ids, lad.begin(s), L)
+                st.draw += 1
+                last = s == S - 1
+                qz.next(s, self.ids[:, lad.begin(s):], L, f_work, None if last else self.nxt[j], B)
+                self.f_snap[j][:B].copy_(f_work)
+                if j + 1 < g:
+                    d.embed_next(self.nxt[j], s + 1, self.x_d, lens[s + 1], 0)
+                    t.embed_next(self.nxt[j], s + 1, self.x_t, lsum, offs[j + 1])
+        st.drafted = True
+        return g
+
+    def spec_verify_forward(self, st: "SpecState") -> torch.Tensor:
+        """SDVAR.target_verify_batch (var.py:1026-1070): ONE target forward over the drafted stages under the block-causal
+        rows; returns the raw logits view (2B, lsum, V)."""
+        assert st.drafted, "draft_generate_batch must run before target_verify_batch"
+        lsum = sum(st.glen)
+        with torch.cuda.device(self.dev):
+            self.t.forward(self.x_t, st.current_stage, st.g, self.logits_t)
+        st.stats["target_calls"] += 1
+        st.target_calls += 1
+        st.verified = True
+        return self.logits_t[:2 * st.B * lsum * self.t.V].view(2 * st.B, lsum, self.t.V)
+
+    def spec_accept(self, st: "SpecState"):
+        """SDVAR.basic_token_matching (var.py:1160-1227) on the verified chunk: (n_accept, matched per stage)."""
+        assert st.verified
+        lad, cur, g = self.lad, st.current_stage, st.g
+        with torch.cuda.device(self.dev):
+            verify_accept(self.logits_t, st.B, st.glen, self.t.V, [lad.cfg_t(st.cfg, cur + j) for j in range(g)], self.ids, lad.begin(cur), lad.L, st.thr, self.counts)
+            self.counts_host.copy_(self.counts, non_blocking=False)            # the one host sync of the round
+        c = self.counts_host.tolist()
+        return c[16], c[:g]
+
+    def spec_commit(self, st: "SpecState", n_acc: int, forced: bool = False):
+        """SDVAR.update_state_with_accepted_tokens (var.py:1245-1282) + `current_stage += n` (var.py:1349-1350), and the
+        rollback of both KV caches to the accepted prefix (absent in the reference)."""
+        lad, B, cur = self.lad, st.B, st.current_stage
+        with torch.cuda.device(self.dev):
+            if n_acc > 0:
+                self.f_acc[:B].copy_(self.f_snap[n_acc - 1][:B])
+                if not forced:
+                    st.stats["accepted_tokens"] += sum(st.glen[:n_acc])
+                if cur + n_acc < lad.S:
+                    self.nxt_cur.copy_(self.nxt[n_acc - 1])
+                st.current_stage = cur = cur + n_acc
+                st.accept_count += n_acc
+            keep = lad.begin(cur) if cur < lad.S else lad.L
+            self.d.kv_set_len(keep); self.t.kv_set_len(keep)
+        st.drafted = st.verified = False
+
+    def spec_end(self, st: "SpecState"):
+        with torch.cuda.device(self.dev):
+            self.d.kv_set_len(0); self.t.kv_set_len(0)
+        st.stats["gamma_final"] = st.gamma
+
     def spec_decode(self, labels: torch.Tensor, cfg: float, gamma: int, top_k: int, top_p: float, noise: Noise, thr: float = 0.5,
                     trace: bool = False) -> SampleResult:
-        assert self.d is not None, "spec_decode needs a draft model"
-        d, t, qz, lad = self.d, self.t, self.q, self.lad
-        assert 1 <= gamma <= t.max_chunk, f"gamma {gamma} exceeds the engine's max_chunk {t.max_chunk}"
-        B, V, S, L, lens = labels.shape[0], t.V, lad.S, lad.L, lad.lens
-        st = dict(target_calls=0, draft_stage_calls=0, forced_accepts=0, accepted_tokens=0, rounds=[], gamma_final=gamma)
-        res = SampleResult(ids=self.ids[:B], f_hat=self.f_acc[:B], stats=st)
-        with torch.cuda.device(self.dev):
-            d.begin(labels); t.begin(labels)
-            f_acc, f_work = self.f_acc[:B], self.f_work[:B]
-            f_acc.zero_()
-            cur, draw = 0, 0
-            while cur < S:
-                g = min(gamma, S - cur)
-                glen = lens[cur:cur + g]
-                lsum = sum(glen)
-                offs = [sum(glen[:j]) for j in range(g)]
-                # inputs of stage `cur` for both models
-                if cur == 0:
-                    d.place_first(self.x_d, lens[0]); t.place_first(self.x_t, lsum)
+        """The whole loop with the policy of var.py:1318-1372 (gamma only decreases; forced accept at gamma == 1; never break)."""
+        st = self.spec_begin(labels, cfg, gamma, top_k, top_p, noise, thr)
+        res = SampleResult(ids=self.ids[:st.B], f_hat=self.f_acc[:st.B], stats=st.stats)
+        while st.current_stage < st.total_stages:
+            cur = st.current_stage
+            g = self.spec_draft(st)
+            lg = self.spec_verify_forward(st)
+            if trace:
+                res.trace.setdefault("target_logits", []).append((cur, g, lg.clone()))
+            n_acc, matched = self.spec_accept(st)
+            forced = False
+            if n_acc == 0:                                                      # var.py:1353-1364
+                if st.gamma > 1:
+                    st.gamma -= 1
                 else:
-                    d.embed_next(self.nxt_cur, cur, self.x_d, lens[cur], 0); t.embed_next(self.nxt_cur, cur, self.x_t, lsum, 0)
-                f_work.copy_(f_acc)
-                # ---- draft g stages (var.py:949-1024)
-                for j in range(g):
-                    s = cur + j
-                    d.forward(self.x_d, s, 1, self.logits_d)
-                    st["draft_stage_calls"] += 1
-                    q = noise.tensor(draw, B, lens[s], V, self.dev)
-                    cfg_sample(self.logits_d, B, lens[s], V, lad.cfg_t(cfg, s), top_k, top_p, q, noise.seed, draw, noise.image_offset, self.ids, lad.begin(s), L)
-                    draw += 1
-                    last = s == S - 1
-                    qz.next(s, self.ids[:, lad.begin(s):], L, f_work, None if last else self.nxt[j], B)
-                    self.f_snap[j][:B].copy_(f_work)
-                    if j + 1 < g:
-                        d.embed_next(self.nxt[j], s + 1, self.x_d, lens[s + 1], 0)
-                        t.embed_next(self.nxt[j], s + 1, self.x_t, lsum, offs[j + 1])
-                # ---- ONE target forward over the g stages + acceptance scan (var.py:1026-1070, 1160-1227)
-                t.forward(self.x_t, cur, g, self.logits_t)
-                st["target_calls"] += 1
-                if trace:
-                    res.trace.setdefault("target_logits", []).append((cur, g, self.logits_t[:2 * B * lsum * V].view(2 * B, lsum, V).clone()))
-                # draft ids of the chunk, stage j at ids[:, begin(cur+j)...]: contiguous columns begin(cur) .. begin(cur)+lsum
-                verify_accept(self.logits_t, B, glen, V, [lad.cfg_t(cfg, cur + j) for j in range(g)], self.ids, lad.begin(cur), L, thr, self.counts)
-                self.counts_host.copy_(self.counts, non_blocking=False)        # the one host sync of the round
-                c = self.counts_host.tolist()
-                n_acc, matched = c[16], c[:g]
-                forced = False
-                if n_acc == 0:                                                  # var.py:1353-1364
-                    if gamma > 1:
-                        gamma -= 1
-                    else:
-                        n_acc, forced = 1, True
-                        st["forced_accepts"] += 1
-                st["rounds"].append(dict(stage=cur, g=g, matched=matched, total=[B * n for n in glen], n_accept=n_acc, forced=forced))
-                if n_acc > 0:                                                   # commit (var.py:1245-1282, 1349-1350)
-                    f_acc.copy_(self.f_snap[n_acc - 1][:B])
-                    if not forced:
-                        st["accepted_tokens"] += sum(glen[:n_acc])
-                    if cur + n_acc < S:
-                        self.nxt_cur.copy_(self.nxt[n_acc - 1])
-                    cur += n_acc
-                keep = lad.begin(cur) if cur < S else L
-                d.kv_set_len(keep); t.kv_set_len(keep)                          # rollback of the rejected suffix
-            st["gamma_final"] = gamma
-            d.kv_set_len(0); t.kv_set_len(0)
+                    n_acc, forced = 1, True
+                    st.stats["forced_accepts"] += 1
+            st.stats["rounds"].append(dict(stage=cur, g=g, matched=matched, total=[st.B * n for n in st.glen], n_accept=n_acc, forced=forced))
+            self.spec_commit(st, n_acc, forced)
+        self.spec_end(st)
         return res
+
+
+@dataclass
+class SpecState:
+    """Run state of the speculative loop; the public counters carry the reference's names (var.py:912-943)."""
+    sampler: "Sampler"
+    labels: torch.Tensor
+    B: int
+    cfg: float
+    gamma: int
+    top_k: int
+    top_p: float
+    noise: Noise
+    thr: float
+    total_stages: int
+    patch_nums: tuple
+    current_stage: int = 0
+    accept_count: int = 0
+    reject_count: int = 0
+    target_calls: int = 0
+    more_smooth: bool = False
+    draw: int = 0
+    g: int = 0
+    glen: list = field(default_factory=list)
+    drafted: bool = False
+    verified: bool = False
+    stats: Dict[str, object] = field(default_factory=lambda: dict(target_calls=0, draft_stage_calls=0, forced_accepts=0, accepted_tokens=0, rounds=[], gamma_final=0))
+
+    @property
+    def draft_f_hat(self) -> torch.Tensor:        # f_hat of the accepted prefix (after the last commit)
+        return self.sampler.f_acc[:self.B]
+
+    @property
+    def target_f_hat(self) -> torch.Tensor:
+        return self.sampler.f_acc[:self.B]

@@ -198,8 +198,17 @@ class SDVAR(nn.Module):
         self._sampler: Optional[E.Sampler] = None
         self.last_result: Optional[E.SampleResult] = None
 
+    # ---- the reference's helper methods (var.py:580-601, 871-1282), each a thin call into the engine --------------
     def init_param(self, model: VAR, B: int, label_B):
-        raise NotImplementedError("init_param (var.py:580-601) is fused into sdvar_model_begin; use the sampler entry points")
+        """var.py:580-601 -> (sos, cond_BD, cond_BD_or_gss, lvl_pos, first_token_map, first_f_hat), computed by
+        sdvar_model_begin on the device."""
+        labels = model._labels(B, label_B, None)
+        ctx = model.engine_ctx(B, 1)
+        with torch.cuda.device(ctx.device):
+            ctx.begin(labels)
+            cond, lvl_pos, first = ctx.export_prologue()
+        f_hat = cond.new_zeros(B, model.Cvae, model.patch_nums[-1], model.patch_nums[-1])
+        return cond, cond, cond, lvl_pos, first, f_hat
 
     def _get_sampler(self, B: int, gamma: int) -> E.Sampler:
         d, t = self.draft_model, self.target_model
@@ -210,11 +219,9 @@ class SDVAR(nn.Module):
             self._sampler = E.Sampler(tc, t.quant_ctx(tc.max_batch), dc)
         return self._sampler
 
-    @torch.no_grad()
-    def sdvar_autoregressive_infer_cfg_parallel_v1(self, B: int, label_B: Optional[Union[int, torch.LongTensor]] = None, g_seed: Optional[int] = None,
-                                                   cfg: float = 1.5, gamma: int = 2, top_k: int = 0, top_p: float = 0.0, more_smooth: bool = False) -> torch.Tensor:
-        if more_smooth:
-            raise NotImplementedError("more_smooth=True is not built")
+    def _initialize_inference_state(self, B: int, label_B, g_seed: Optional[int], cfg: float, gamma: int) -> E.SpecState:
+        """var.py:871-947.  The returned state carries the reference's field names (current_stage, gamma, total_stages,
+        accept_count, target_calls, patch_nums, cfg, top_k, top_p, draft_f_hat, target_f_hat)."""
         t = self.target_model
         rng = None
         if g_seed is not None:
@@ -223,7 +230,77 @@ class SDVAR(nn.Module):
         smp = self._get_sampler(B, gamma)
         seed = int(torch.seed() & 0x7FFFFFFFFFFFFFFF) if g_seed is None else int(g_seed)
         noise = E.Noise("torch", seed, generator=rng) if self.noise_kind == "torch" else E.Noise(self.noise_kind, seed)
-        res = smp.spec_decode(labels, cfg, gamma, top_k, top_p, noise, thr=self.match_threshold)
+        return smp.spec_begin(labels, cfg, gamma, 0, 0.0, noise, thr=self.match_threshold)     # top_k / top_p set by the caller (var.py:937-938)
+
+    def draft_generate_batch(self, state: E.SpecState, B: int):
+        """var.py:949-1024 -> list of g token tensors (B, pn^2) int64 for stages current_stage .. current_stage+g-1."""
+        smp, lad = state.sampler, state.sampler.lad
+        g = smp.spec_draft(state)
+        cur = state.current_stage
+        return [smp.ids[:B, lad.begin(cur + j):lad.begin(cur + j) + lad.lens[cur + j]].clone() for j in range(g)]
+
+    def target_verify_batch(self, draft_tokens, state: E.SpecState, B: int):
+        """var.py:1026-1070 -> (list of per-stage CFG logits (B, pn^2, V), gamma).  The verified stages are the ones the last
+        draft_generate_batch produced (their next-scale inputs were built while drafting)."""
+        if not draft_tokens:
+            return [], 0
+        assert len(draft_tokens) == state.g, "target_verify_batch verifies the stages of the last draft_generate_batch"
+        smp, lad, cur = state.sampler, state.sampler.lad, state.current_stage
+        lg = smp.spec_verify_forward(state)
+        out, off = [], 0
+        for j in range(state.g):
+            n, t = lad.lens[cur + j], lad.cfg_t(state.cfg, cur + j)
+            out.append((1 + t) * lg[:B, off:off + n] - t * lg[B:, off:off + n])                      # var.py:1062-1067
+            off += n
+        return out, state.g
+
+    def basic_token_matching(self, draft_tokens, target_logits, state, B: int) -> int:
+        """var.py:1160-1227 on arbitrary (tokens, CFG logits) lists: leading stages whose batch match rate is >= 0.5."""
+        if not draft_tokens or not target_logits or len(draft_tokens) != len(target_logits):
+            return 0
+        dev = target_logits[0].device
+        lens = [int(t.shape[1]) for t in draft_tokens]
+        ids = torch.cat([t.to(dev) for t in draft_tokens], 1).contiguous()
+        lg = torch.cat(target_logits, 1)
+        lg2 = torch.cat([lg, lg], 0).contiguous()          # t = 0 makes the kernel's CFG the identity on the first B rows
+        counts = torch.zeros(40, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            E.verify_accept(lg2, B, lens, lg.shape[-1], [0.0] * len(lens), ids, 0, ids.shape[1], self.match_threshold, counts)
+        return int(counts[16].item())
+
+    def advanced_token_matching(self, draft_tokens, target_logits, state, B: int) -> int:
+        return self.basic_token_matching(draft_tokens, target_logits, state, B)       # the reference's stub does the same (var.py:1229-1243)
+
+    def update_state_with_accepted_tokens(self, draft_tokens, accept_length: int, state: E.SpecState, B: int):
+        """var.py:1245-1282 (+ the stage advance of var.py:1349-1350 and the KV rollback the reference lacks)."""
+        state.sampler.spec_commit(state, max(int(accept_length), 0))
+
+    @torch.no_grad()
+    def sdvar_autoregressive_infer_cfg_parallel_v1(self, B: int, label_B: Optional[Union[int, torch.LongTensor]] = None, g_seed: Optional[int] = None,
+                                                   cfg: float = 1.5, gamma: int = 2, top_k: int = 0, top_p: float = 0.0, more_smooth: bool = False) -> torch.Tensor:
+        """var.py:1284-1383 with the resolved semantics of SURVEY.md App. C.1."""
+        if more_smooth:
+            raise NotImplementedError("more_smooth=True is not built")
+        t = self.target_model
+        state = self._initialize_inference_state(B, label_B, g_seed, cfg, gamma)
+        state.top_k, state.top_p = top_k, top_p                               # var.py:1313-1314
+        smp = state.sampler
+        while state.current_stage < state.total_stages:                       # var.py:1318
+            cur = state.current_stage
+            g = smp.spec_draft(state)
+            smp.spec_verify_forward(state)
+            n_acc, matched = smp.spec_accept(state)
+            forced = False
+            if n_acc == 0:                                                    # var.py:1353-1364 (and never `break`: SURVEY F2e)
+                if state.gamma > 1:
+                    state.gamma -= 1
+                else:
+                    n_acc, forced = 1, True
+                    state.stats["forced_accepts"] += 1
+            state.stats["rounds"].append(dict(stage=cur, g=g, matched=matched, total=[B * n for n in state.glen], n_accept=n_acc, forced=forced))
+            smp.spec_commit(state, n_acc, forced)
+        smp.spec_end(state)
+        res = E.SampleResult(ids=smp.ids[:B], f_hat=smp.f_acc[:B], stats=state.stats)
         self.last_result = res
         return t.vae_proxy[0].fhat_to_img(res.f_hat.clone()).add_(1).mul_(0.5)
 

@@ -212,3 +212,48 @@ def test_fp16_kv_cache_vs_oracle(dev):
     assert np.array_equal(res.ids.cpu().numpy(), torch.cat(tr.ids, 1).numpy()), errs
     assert max(errs) <= LOGIT_TOL, errs
     ctx.close(); qc.close()
+
+
+def test_sdvar_helper_methods_follow_the_reference_call_sequence(dev):
+    """The reference's own step functions (var.py:871-1282), driven exactly like parallel_v1 drives them, reproduce the
+    one-call sampler; init_param returns the prologue tensors of var.py:580-601."""
+    import sdvar_amd
+    vae, draft, target, sd = sdvar_amd.build_vae_var_speculative_decoding(device=dev, depth_draft=2, depth_target=4)
+    for m in (draft, target):                                                   # stress weights so the blocks matter
+        sdm, _ = state_dicts(m.depth, LADDER_256)
+        m.load_state_dict({k: v.to(dev) for k, v in sdm.items()})
+    B, labels = 2, torch.tensor([11, 700], device=dev)
+    sd.noise_kind = "host"
+    sd.match_threshold = 0.0                                                    # accept everything: exercises multi-stage commits
+    img = sd.sdvar_autoregressive_infer_cfg_parallel_v1(B=B, label_B=labels, g_seed=9, cfg=1.5, gamma=3, top_k=900, top_p=0.96)
+    ids_ref, st_ref = sd.last_result.ids.clone(), dict(sd.last_result.stats)
+    # the same run, step by step
+    state = sd._initialize_inference_state(B, labels, 9, 1.5, 3)
+    state.top_k, state.top_p = 900, 0.96
+    calls = 0
+    while state.current_stage < state.total_stages:
+        toks = sd.draft_generate_batch(state, B)
+        logits, g = sd.target_verify_batch(toks, state, B)
+        assert g == len(toks) and logits[0].shape == (B, toks[0].shape[1], 4096)
+        n = sd.basic_token_matching(toks, logits, state, B)
+        assert n == g                                                           # thr = 0
+        sd.update_state_with_accepted_tokens(toks, n, state, B)
+        calls += 1
+    state.sampler.spec_end(state)
+    assert calls == st_ref["target_calls"] == 4 and state.accept_count == 10 and state.target_calls == 4
+    assert torch.equal(state.sampler.ids[:B], ids_ref)
+    assert torch.equal(state.draft_f_hat, sd.last_result.f_hat)
+    # known-answer behaviour of basic_token_matching on explicit tensors: 100 % / 50 % / 49 % match -> 2 stages
+    V = 4096
+    lg = [torch.randn(B, n, V, device=dev) for n in (4, 9, 16)]
+    tk = [l.argmax(-1) for l in lg]
+    tk[1].view(-1)[9:] = (tk[1].view(-1)[9:] + 1) % V                           # 9 of 18 match = 0.5 -> accepted
+    tk[2].view(-1)[15:] = (tk[2].view(-1)[15:] + 1) % V                         # 15 of 32 < 0.5 -> rejected
+    sd.match_threshold = 0.5
+    assert sd.basic_token_matching(tk, lg, None, B) == 2
+    # init_param (var.py:580-601)
+    sos, cond, cond2, lvl_pos, first, f0 = sd.init_param(target, B, labels)
+    o = orc.OracleVAR({k: v.cpu() for k, v in target.state_dict().items()}, target.depth, LADDER_256)
+    c_o, lp_o, f_o = o.prologue(labels.cpu())
+    assert torch.equal(cond.cpu(), c_o) and (lvl_pos.cpu() - lp_o).abs().max() == 0 and (first.cpu() - f_o).abs().max() <= 1e-6
+    assert f0.shape == (B, 32, 16, 16) and f0.abs().sum() == 0
