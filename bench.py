@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--mode", default="natural", choices=["natural", "accept_all", "reject_all"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-modes", action="store_true")
+    ap.add_argument("--decode-high-prio", action="store_true", help="experiment: give the decode stream the higher HIP priority")
     ap.add_argument("--serial-decode", action="store_true", help="decode on the sampling stream instead of overlapping it with the next batch")
     ap.add_argument("--gemm-mode", default=None, choices=["f32", "bf16x3"], help="default: sdvar_amd.engine.DEFAULT_GEMM_MODE")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark for the VQVAE decoder convs")
@@ -96,7 +97,7 @@ def main():
     # The VQVAE decode of batch i runs on a second HIP stream and overlaps the sampling loop of batch i+1 (whose early
     # stages leave most CUs idle); f_hat is double-buffered and every decode is finished inside the timed region.
     main_stream = torch.cuda.current_stream()
-    dec_stream = torch.cuda.Stream(device=dev)
+    dec_stream = torch.cuda.Stream(device=dev, priority=0 if not args.decode_high_prio else -1)
     fh_buf = [torch.zeros(B, 32, 16, 16, device=dev) for _ in range(2)]
     dec_done = [None, None]
     state = {"i": 0, "img": None}

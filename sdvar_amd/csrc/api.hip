@@ -14,15 +14,17 @@ namespace sdvar {
 // kernels (gemm.hip, elementwise.hip, attention.hip, sampler.hip, quant.hip)
 int gemm_f32_nt(const float* X, int ldx, const float* W, const float* bias, float* out, int ldo, int M, int N, int K, int epi,
                 const float* res, int ldres, const float* gate, int rows_per_gate, int gate_stride, hipStream_t stream);
-int ln_modulate(const float* x, const float* scale, const float* shift, float* out, uint16_t* outp, size_t ops, int rows, int C, int rows_per_img, int mod_stride, hipStream_t stream);
-int qk_norm_append(const float* qkv, const float* scale_mul, float* q_out, void* k_cache, void* v_cache, int kv_f16, int R, int l, int H, int Lmax, int pos0, hipStream_t stream);
+struct PendingSplitK { const float* ws; const float* bias; const float* gate; int split, rows_per_gate, gate_stride; };
+int ln_modulate(float* x, const float* scale, const float* shift, float* out, uint16_t* outp, size_t ops, int rows, int C, int rows_per_img, int mod_stride, const PendingSplitK* pend, hipStream_t stream);
+float* splitk_workspace(size_t* floats);
+int qk_norm_append(const float* qkv, const float* scale_mul, float* q_out, void* k_cache, void* v_cache, int kv_f16, int R, int l, int H, int Lmax, int pos0, const PendingSplitK* pend, hipStream_t stream);
 int silu_rows(const float* x, float* y, int n, hipStream_t stream);
 int prologue(const long long* labels, const float* class_emb, const float* pos_start, const float* lvl_pos, float* cond, float* x0, int B, int C, int num_classes, hipStream_t stream);
 int build_lvl_pos(const float* lvl_embed, const float* pos, const int* stage_of_tok, float* out, int L, int C, hipStream_t stream);
 int embed_next(const float* nxt, const float* Ww, const float* bw, const float* lvl_pos, float* x, int B, int l, int C, int t0, int ltot, int tok_off, hipStream_t stream);
 int attention_f32(const float* q, const void* kc, const void* vc, int kv_f16, float* out, uint16_t* outp, size_t ops, int R, int H, int l, int Lmax, int Ktot, int n_chunk, const int* qbeg, const int* vis, hipStream_t stream);
 int gemm_bf16x3_nt(const uint16_t* X, size_t xps, const uint16_t* W, size_t wps, const float* bias, float* out, int ldo, uint16_t* outp, size_t ops,
-                   int M, int N, int K, int epi, const float* res, int ldres, const float* gate, int rows_per_gate, int gate_stride, hipStream_t stream);
+                   int M, int N, int K, int epi, const float* res, int ldres, const float* gate, int rows_per_gate, int gate_stride, int* defer, hipStream_t stream);
 int split_planes(const float* x, uint16_t* planes, int rows, int cols, size_t plane_stride, hipStream_t stream);
 void debug_set_gemm_cfg_p(int bm, int split);
 void debug_set_gemm_stamps(unsigned long long* p);
@@ -324,34 +326,44 @@ int sdvar_stage_forward(sdvar_model_t* m, float* x, int32_t s0, int32_t n, float
     const double dM = M, dC = C;
     const bool P = m->d.gemm_mode == 1;                               // bf16x3 split-operand GEMMs: inputs travel as planes
     const size_t ps = (size_t)M * C;                                  // plane stride of this call's (M, C) activations
+    // In bf16x3 mode a split-K GEMM feeding a row kernel leaves its K-slice slabs in the shared workspace and the consumer
+    // (qk_norm_append for QKV; the next ln_modulate for the two gated-residual GEMMs) sums them: no reduce launches.
+    size_t wsf = 0;
+    const float* ws = P ? splitk_workspace(&wsf) : nullptr;
+    PendingSplitK pend{nullptr, nullptr, nullptr, 0, 1, 0};           // unreduced gated residual waiting for the next ln_modulate
+    int defer = 0;
     for (int i = 0; i < m->d.depth; ++i) {
         const BlockW& b = m->blk[i];
         const float* ada = m->ada + (size_t)i * m->Rmax * 6 * C;      // (R, 6C): gamma1 gamma2 scale1 scale2 shift1 shift2
         { ProfScope pp(2, 8 * dM * dC, (P ? 10 : 8) * dM * dC, s);
-          SDVAR_TRY(ln_modulate(x, ada + 2 * C, ada + 4 * C, m->xn, P ? m->xn_p : nullptr, ps, M, C, lsum, 6 * C, s)); }
+          SDVAR_TRY(ln_modulate(x, ada + 2 * C, ada + 4 * C, m->xn, P ? m->xn_p : nullptr, ps, M, C, lsum, 6 * C, &pend, s)); pend.ws = nullptr; }
+        PendingSplitK pq{nullptr, nullptr, nullptr, 0, 1, 0};
         { ProfScope pp(0, 2 * dM * 3 * dC * dC, 4 * (dM * dC + 3 * dC * dC + 3 * dM * dC), s);
-          if (P) SDVAR_TRY(gemm_bf16x3_nt(m->xn_p, ps, b.qkv_wp, (size_t)3 * C * C, b.qkv_bias, m->qkv, 3 * C, nullptr, 0, M, 3 * C, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, s));
+          if (P) { SDVAR_TRY(gemm_bf16x3_nt(m->xn_p, ps, b.qkv_wp, (size_t)3 * C * C, b.qkv_bias, m->qkv, 3 * C, nullptr, 0, M, 3 * C, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, &defer, s));
+                   if (defer) pq = PendingSplitK{ws, b.qkv_bias, nullptr, defer, 1, 0}; }
           else SDVAR_TRY(gemm_f32_nt(m->xn, C, b.qkv_w, b.qkv_bias, m->qkv, 3 * C, M, 3 * C, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, s)); }
         { ProfScope pp(3, 6 * dM * dC, 4 * 6 * dM * dC, s);
-          SDVAR_TRY(qk_norm_append(m->qkv, b.scale_mul, m->qbuf, b.kc, b.vc, m->d.kv_dtype, R, lsum, H, m->L, m->kv_len, s)); }
+          SDVAR_TRY(qk_norm_append(m->qkv, b.scale_mul, m->qbuf, b.kc, b.vc, m->d.kv_dtype, R, lsum, H, m->L, m->kv_len, &pq, s)); }
         { ProfScope pp(1, 4.0 * R * H * 64.0 * lk, R * H * 64.0 * ((m->d.kv_dtype ? 4.0 : 8.0) * Ktot + 8.0 * lsum), s);
           SDVAR_TRY(attention_f32(m->qbuf, b.kc, b.vc, m->d.kv_dtype, m->att, P ? m->att_p : nullptr, ps, R, H, lsum, m->L, Ktot, n, qbeg, vis, s)); }
         { ProfScope pp(0, 2 * dM * dC * dC, 4 * (3 * dM * dC + dC * dC), s);
-          if (P) SDVAR_TRY(gemm_bf16x3_nt(m->att_p, ps, b.proj_wp, (size_t)C * C, b.proj_b, x, C, nullptr, 0, M, C, C, EPI_GATED_RES, x, C, ada, lsum, 6 * C, s));
+          if (P) { SDVAR_TRY(gemm_bf16x3_nt(m->att_p, ps, b.proj_wp, (size_t)C * C, b.proj_b, x, C, nullptr, 0, M, C, C, EPI_GATED_RES, x, C, ada, lsum, 6 * C, &defer, s));
+                   if (defer) pend = PendingSplitK{ws, b.proj_b, ada, defer, lsum, 6 * C}; }
           else SDVAR_TRY(gemm_f32_nt(m->att, C, b.proj_w, b.proj_b, x, C, M, C, C, EPI_GATED_RES, x, C, ada, lsum, 6 * C, s)); }
         { ProfScope pp(2, 8 * dM * dC, (P ? 10 : 8) * dM * dC, s);
-          SDVAR_TRY(ln_modulate(x, ada + 3 * C, ada + 5 * C, m->xn, P ? m->xn_p : nullptr, ps, M, C, lsum, 6 * C, s)); }
+          SDVAR_TRY(ln_modulate(x, ada + 3 * C, ada + 5 * C, m->xn, P ? m->xn_p : nullptr, ps, M, C, lsum, 6 * C, &pend, s)); pend.ws = nullptr; }
         { ProfScope pp(0, 2 * dM * 4 * dC * dC, 4 * (dM * dC + 4 * dC * dC + 4 * dM * dC), s);
-          if (P) SDVAR_TRY(gemm_bf16x3_nt(m->xn_p, ps, b.fc1_wp, (size_t)4 * C * C, b.fc1_b, nullptr, 0, m->hid_p, 4 * ps, M, 4 * C, C, EPI_BIAS_GELU, nullptr, 0, nullptr, 0, 0, s));
+          if (P) SDVAR_TRY(gemm_bf16x3_nt(m->xn_p, ps, b.fc1_wp, (size_t)4 * C * C, b.fc1_b, nullptr, 0, m->hid_p, 4 * ps, M, 4 * C, C, EPI_BIAS_GELU, nullptr, 0, nullptr, 0, 0, nullptr, s));
           else SDVAR_TRY(gemm_f32_nt(m->xn, C, b.fc1_w, b.fc1_b, m->hid, 4 * C, M, 4 * C, C, EPI_BIAS_GELU, nullptr, 0, nullptr, 0, 0, s)); }
         { ProfScope pp(0, 2 * dM * 4 * dC * dC, 4 * (4 * dM * dC + 4 * dC * dC + 2 * dM * dC), s);
-          if (P) SDVAR_TRY(gemm_bf16x3_nt(m->hid_p, 4 * ps, b.fc2_wp, (size_t)4 * C * C, b.fc2_b, x, C, nullptr, 0, M, C, 4 * C, EPI_GATED_RES, x, C, ada + C, lsum, 6 * C, s));
+          if (P) { SDVAR_TRY(gemm_bf16x3_nt(m->hid_p, 4 * ps, b.fc2_wp, (size_t)4 * C * C, b.fc2_b, x, C, nullptr, 0, M, C, 4 * C, EPI_GATED_RES, x, C, ada + C, lsum, 6 * C, &defer, s));
+                   if (defer) pend = PendingSplitK{ws, b.fc2_b, ada + C, defer, lsum, 6 * C}; }
           else SDVAR_TRY(gemm_f32_nt(m->hid, 4 * C, b.fc2_w, b.fc2_b, x, C, M, C, 4 * C, EPI_GATED_RES, x, C, ada + C, lsum, 6 * C, s)); }
     }
-    { ProfScope pp(2, 8 * dM * dC, (P ? 10 : 8) * dM * dC, s);
-      SDVAR_TRY(ln_modulate(x, m->ada_head, m->ada_head + C, m->xn, P ? m->xn_p : nullptr, ps, M, C, lsum, 2 * C, s)); }
+    { ProfScope pp(2, 8 * dM * dC, (P ? 10 : 8) * dM * dC, s);      // also finishes the last block's fc2 residual when it was left split
+      SDVAR_TRY(ln_modulate(x, m->ada_head, m->ada_head + C, m->xn, P ? m->xn_p : nullptr, ps, M, C, lsum, 2 * C, &pend, s)); pend.ws = nullptr; }
     { ProfScope pp(0, 2 * dM * dC * V, 4 * (dM * dC + dC * V + dM * V), s);
-      if (P) SDVAR_TRY(gemm_bf16x3_nt(m->xn_p, ps, m->head_wp, (size_t)V * C, m->head_b, logits, V, nullptr, 0, M, V, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, s));
+      if (P) SDVAR_TRY(gemm_bf16x3_nt(m->xn_p, ps, m->head_wp, (size_t)V * C, m->head_b, logits, V, nullptr, 0, M, V, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, nullptr, s));
       else SDVAR_TRY(gemm_f32_nt(m->xn, C, m->head_w, m->head_b, logits, V, M, V, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, s)); }
     m->kv_len = Ktot;
     return SDVAR_OK;
@@ -476,7 +488,7 @@ int sdvar_op_gemm(const float* X, int32_t ldx, const float* W, const float* bias
 int sdvar_op_ln_modulate(const float* x, const float* scale, const float* shift, float* out, uint16_t* out_planes, uint64_t plane_stride, int32_t rows,
                          int32_t C, int32_t rows_per_img, int32_t mod_stride, void* stream) {
     SDVAR_CHECK_ARG(out || out_planes, "op_ln_modulate: no output");
-    return ln_modulate(x, scale, shift, out, out_planes, (size_t)plane_stride, rows, C, rows_per_img, mod_stride, (hipStream_t)stream);
+    return ln_modulate(const_cast<float*>(x), scale, shift, out, out_planes, (size_t)plane_stride, rows, C, rows_per_img, mod_stride, nullptr, (hipStream_t)stream);
 }
 int sdvar_op_split_planes(const float* x, uint16_t* planes, int32_t rows, int32_t cols, uint64_t plane_stride, void* stream) {
     return split_planes(x, planes, rows, cols, (size_t)plane_stride, (hipStream_t)stream);
@@ -486,11 +498,11 @@ int sdvar_op_gemm_bf16x3(const uint16_t* Xp, uint64_t x_plane_stride, const uint
                          const float* gate, int32_t rows_per_gate, int32_t gate_stride, void* stream) {
     ProfScope ps(0, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), (hipStream_t)stream);
     return gemm_bf16x3_nt(Xp, (size_t)x_plane_stride, Wp, (size_t)w_plane_stride, bias, out, ldo, out_planes, (size_t)out_plane_stride, M, N, K, epi, res, ldres,
-                          gate, rows_per_gate, gate_stride, (hipStream_t)stream);
+                          gate, rows_per_gate, gate_stride, nullptr, (hipStream_t)stream);
 }
 int sdvar_op_qk_norm_append(const float* qkv, const float* scale_mul, float* q_out, void* k_cache, void* v_cache, int32_t kv_f16, int32_t R, int32_t l,
                             int32_t H, int32_t Lmax, int32_t pos0, void* stream) {
-    return qk_norm_append(qkv, scale_mul, q_out, k_cache, v_cache, kv_f16, R, l, H, Lmax, pos0, (hipStream_t)stream);
+    return qk_norm_append(qkv, scale_mul, q_out, k_cache, v_cache, kv_f16, R, l, H, Lmax, pos0, nullptr, (hipStream_t)stream);
 }
 int sdvar_op_attention(const float* q, const void* kc, const void* vc, int32_t kv_f16, float* out, uint16_t* out_planes, uint64_t plane_stride, int32_t R,
                        int32_t H, int32_t l, int32_t Lmax, int32_t Ktot, int32_t n, const int32_t* qbeg, const int32_t* vis, void* stream) {

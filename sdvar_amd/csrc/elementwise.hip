@@ -13,23 +13,49 @@
 
 namespace sdvar {
 
+// A split-K GEMM whose consumer is one of the row kernels below does not run a reduce pass of its own: the consumer sums the
+// K-slice slabs (in slice order - deterministic) while it reads its input anyway ("launch-boundary reduce in the next
+// kernel's prologue").  `PendingSplitK` describes such an unreduced GEMM result: value[m][n] = sum_s ws[s][m][n] + bias[n].
+struct PendingSplitK {
+    const float* ws;        // slabs [split][M][N]; null = nothing pending
+    const float* bias;      // (N)
+    const float* gate;      // gated residual (x += value * gate[row / rows_per_gate]) or null
+    int split, rows_per_gate, gate_stride;
+};
+
 // ------------------------------------------------------------------------------------------------ ln_modulate
 // x (rows, C) ; scale/shift: row r of the CFG batch = row / rows_per_img, element stride `mod_stride` between r's.
 constexpr int LN_MAX_V4 = 8;   // up to C = 64 lanes * 8 * 4 = 2048
 
-__global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+__global__ __launch_bounds__(256) void ln_modulate_kernel(float* __restrict__ x, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, float* __restrict__ out, uint16_t* __restrict__ outp,
-                                                          size_t ops, int rows, int C, int rows_per_img, int mod_stride, float eps) {
+                                                          size_t ops, int rows, int C, int rows_per_img, int mod_stride, float eps, PendingSplitK pend) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int nv = C >> 2;
-    const f32x4* px = reinterpret_cast<const f32x4*>(x + (size_t)row * C);
+    f32x4* px = reinterpret_cast<f32x4*>(x + (size_t)row * C);
     f32x4 v[LN_MAX_V4];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < LN_MAX_V4; ++i) {
         const int idx = lane + 64 * i;
-        if (idx < nv) { v[i] = px[idx]; s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
+        if (idx < nv) {
+            v[i] = px[idx];
+            if (pend.ws) {          // finish the previous block's gated residual: x += (sum of K-slice slabs + bias) * gate, written back
+                const size_t slab = (size_t)rows * C, o = (size_t)row * C + 4 * idx;
+                f32x4 acc = *reinterpret_cast<const f32x4*>(pend.ws + o);
+                for (int k = 1; k < pend.split; ++k) {
+                    const f32x4 p = *reinterpret_cast<const f32x4*>(pend.ws + k * slab + o);
+                    acc[0] += p[0]; acc[1] += p[1]; acc[2] += p[2]; acc[3] += p[3];
+                }
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(pend.bias + 4 * idx);
+                const f32x4 gg = *reinterpret_cast<const f32x4*>(pend.gate + (size_t)(row / pend.rows_per_gate) * pend.gate_stride + 4 * idx);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[i][e] = v[i][e] + (acc[e] + bb[e]) * gg[e];
+                px[idx] = v[i];
+            }
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
     }
     const float mean = wave_sum(s) / (float)C;
     float ss = 0.f;
@@ -71,11 +97,16 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restric
     }
 }
 
-int ln_modulate(const float* x, const float* scale, const float* shift, float* out, uint16_t* outp, size_t ops, int rows, int C, int rows_per_img,
-                int mod_stride, hipStream_t stream) {
+int ln_modulate(float* x, const float* scale, const float* shift, float* out, uint16_t* outp, size_t ops, int rows, int C, int rows_per_img,
+                int mod_stride, const PendingSplitK* pend, hipStream_t stream) {
+    PendingSplitK pd{nullptr, nullptr, nullptr, 0, 1, 0};
+    if (pend && pend->ws) {
+        SDVAR_CHECK_ARG(pend->bias && pend->gate && pend->split >= 1 && pend->rows_per_gate > 0 && pend->gate_stride % 4 == 0, "ln_modulate: bad pending split-K descriptor");
+        pd = *pend;
+    }
     SDVAR_CHECK_ARG(C % 4 == 0 && C <= 64 * 4 * LN_MAX_V4 && rows > 0 && rows_per_img > 0, "ln_modulate: bad shape rows=%d C=%d", rows, C);
     SDVAR_CHECK_ARG(mod_stride % 4 == 0, "ln_modulate: mod_stride must be a multiple of 4");
-    hipLaunchKernelGGL(ln_modulate_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, scale, shift, out, outp, ops, rows, C, rows_per_img, mod_stride, 1e-6f);
+    hipLaunchKernelGGL(ln_modulate_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, scale, shift, out, outp, ops, rows, C, rows_per_img, mod_stride, 1e-6f, pd);
     SDVAR_LAUNCH_CHECK();
     return SDVAR_OK;
 }
@@ -86,7 +117,7 @@ int ln_modulate(const float* x, const float* scale, const float* shift, float* o
 template <typename KV>
 __global__ __launch_bounds__(256) void qk_norm_append_kernel(const float* __restrict__ qkv, const float* __restrict__ scale_mul,
                                                              float* __restrict__ q_out, KV* __restrict__ k_cache,
-                                                             KV* __restrict__ v_cache, int R, int l, int H, int Lmax, int pos0) {
+                                                             KV* __restrict__ v_cache, int R, int l, int H, int Lmax, int pos0, PendingSplitK pend) {
     const int lane = threadIdx.x & 63;
     const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (item >= (long long)R * l * H) return;
@@ -94,8 +125,16 @@ __global__ __launch_bounds__(256) void qk_norm_append_kernel(const float* __rest
     const long long row = item / H;            // r * l + t
     const int t = (int)(row % l), r = (int)(row / l);
     const int C = H * 64;
-    const float* p = qkv + (size_t)row * 3 * C + h * 64 + lane;
-    const float q = p[0], k = p[C], v = p[2 * C];
+    float q, k, v;
+    if (pend.ws) {                 // the QKV GEMM left K-slice slabs: qkv[row][col] = sum_s ws[s][row][col] + bias[col]
+        const size_t slab = (size_t)R * l * 3 * C, o = (size_t)row * 3 * C + h * 64 + lane;
+        q = pend.ws[o]; k = pend.ws[o + C]; v = pend.ws[o + 2 * C];
+        for (int s = 1; s < pend.split; ++s) { q += pend.ws[s * slab + o]; k += pend.ws[s * slab + o + C]; v += pend.ws[s * slab + o + 2 * C]; }
+        q += pend.bias[h * 64 + lane]; k += pend.bias[C + h * 64 + lane]; v += pend.bias[2 * C + h * 64 + lane];
+    } else {
+        const float* p = qkv + (size_t)row * 3 * C + h * 64 + lane;
+        q = p[0]; k = p[C]; v = p[2 * C];
+    }
     const float qn = fmaxf(sqrtf(wave_sum(q * q)), 1e-12f);
     const float kn = fmaxf(sqrtf(wave_sum(k * k)), 1e-12f);
     const float sm = expf(fminf(scale_mul[h], 4.605170249938965f));    // log(100) as the reference's float32 clamp
@@ -106,11 +145,13 @@ __global__ __launch_bounds__(256) void qk_norm_append_kernel(const float* __rest
 }
 
 int qk_norm_append(const float* qkv, const float* scale_mul, float* q_out, void* k_cache, void* v_cache, int kv_f16, int R, int l, int H,
-                   int Lmax, int pos0, hipStream_t stream) {
+                   int Lmax, int pos0, const PendingSplitK* pend, hipStream_t stream) {
+    PendingSplitK pd{nullptr, nullptr, nullptr, 0, 1, 0};
+    if (pend && pend->ws) { SDVAR_CHECK_ARG(pend->bias && pend->split >= 1, "qk_norm_append: bad pending split-K descriptor"); pd = *pend; }
     SDVAR_CHECK_ARG(R > 0 && l > 0 && H > 0 && pos0 >= 0 && pos0 + l <= Lmax, "qk_norm_append: cache overflow pos0=%d l=%d Lmax=%d", pos0, l, Lmax);
     const long long items = (long long)R * l * H;
-    if (kv_f16) hipLaunchKernelGGL(qk_norm_append_kernel<__half>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, qkv, scale_mul, q_out, (__half*)k_cache, (__half*)v_cache, R, l, H, Lmax, pos0);
-    else hipLaunchKernelGGL(qk_norm_append_kernel<float>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, qkv, scale_mul, q_out, (float*)k_cache, (float*)v_cache, R, l, H, Lmax, pos0);
+    if (kv_f16) hipLaunchKernelGGL(qk_norm_append_kernel<__half>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, qkv, scale_mul, q_out, (__half*)k_cache, (__half*)v_cache, R, l, H, Lmax, pos0, pd);
+    else hipLaunchKernelGGL(qk_norm_append_kernel<float>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, qkv, scale_mul, q_out, (float*)k_cache, (float*)v_cache, R, l, H, Lmax, pos0, pd);
     SDVAR_LAUNCH_CHECK();
     return SDVAR_OK;
 }

@@ -561,6 +561,7 @@ static void choose_cfg_p(int M, int N, int K, size_t ws_floats, int* bm_out, int
     *bm_out = bbm; *split_out = bs;
 }
 
+static int* g_defer = nullptr;     // set per call by gemm_bf16x3_nt (single host thread per process uses the library)
 static bool g_use_v2 = true;
 void debug_set_gemm_v2(int on) { g_use_v2 = on != 0; }
 
@@ -614,6 +615,7 @@ static int launch_v3(GemmPArgs a, int epi, int split, hipStream_t stream) {
         p.out = ws; p.ldo = a.N; p.split = split; p.k_per_split = (nkt + split - 1) / split;
         int rc = launch_v3_kernel<PEPI_PARTIAL>(p, tiles * split, stream);
         if (rc) return rc;
+        if (g_defer) { *g_defer = split; return SDVAR_OK; }
         return launch_reduce_p(a, ws, split, epi, stream);
     }
     a.split = 1; a.k_per_split = nkt;
@@ -639,6 +641,7 @@ static int launch_p(GemmPArgs a, int epi, int split, hipStream_t stream) {
         p.out = ws; p.ldo = a.N; p.split = split; p.k_per_split = (nkt + split - 1) / split;
         if (v2) { int rc = launch_v2_kernel<PEPI_PARTIAL>(p, tiles * split, stream); if (rc) return rc; }
         else { hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, WAVES_M, WAVES_N, PEPI_PARTIAL>), dim3(tiles * split), block, lds, stream, p); SDVAR_LAUNCH_CHECK(); }
+        if (g_defer) { *g_defer = split; return SDVAR_OK; }
         const size_t total = (size_t)a.M * (a.N / 4);
         const int rgrid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
         switch (epi) {
@@ -668,8 +671,13 @@ static int launch_p(GemmPArgs a, int epi, int split, hipStream_t stream) {
 
 // X planes [3][M][K] (plane stride xps), W planes [3][N][K] (plane stride wps).  epi: 0 bias -> out fp32; 1 bias + GELU ->
 // outp planes [3][M][N] (plane stride ops); 2 gated residual -> out fp32.
+// defer: when non-null and the shape is split along K, the reduce pass is NOT launched; *defer receives the slice count and the
+// slabs stay in the shared workspace ([split][M][N]) for the consumer kernel to sum (elementwise.hip PendingSplitK); 0 otherwise.
 int gemm_bf16x3_nt(const uint16_t* X, size_t xps, const uint16_t* W, size_t wps, const float* bias, float* out, int ldo, uint16_t* outp, size_t ops,
-                   int M, int N, int K, int epi, const float* res, int ldres, const float* gate, int rows_per_gate, int gate_stride, hipStream_t stream) {
+                   int M, int N, int K, int epi, const float* res, int ldres, const float* gate, int rows_per_gate, int gate_stride, int* defer,
+                   hipStream_t stream) {
+    g_defer = defer;
+    if (defer) *defer = 0;
     SDVAR_CHECK_ARG(X && W, "gemm_bf16x3: null operand");
     SDVAR_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % PBK == 0, "gemm_bf16x3: need K %% 32 == 0 (M=%d N=%d K=%d)", M, N, K);
     SDVAR_CHECK_ARG(epi >= PEPI_BIAS && epi <= PEPI_GATED_RES, "gemm_bf16x3: unknown epilogue %d", epi);

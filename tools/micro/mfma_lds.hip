@@ -5,13 +5,20 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdint.h>
+#ifndef RANDOM_DATA
+#define RANDOM_DATA 0
+#endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <int VAR>
 __global__ __launch_bounds__(512, 2) void k(float* out, int iters, const uint16_t* src) {
     extern __shared__ __attribute__((aligned(16))) uint16_t sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-    for (int i = tid; i < 3 * 6 * 128 * 32; i += 512) sm[i] = (uint16_t)(0x3c00 + (i * 7 % 97));
+    // RANDOM_DATA: realistic high-toggle bf16 operands (sign/exponent/mantissa all varying) instead of a smooth pattern
+    for (int i = tid; i < 3 * 6 * 128 * 32; i += 512) {
+        unsigned h = (unsigned)i * 2654435761u + blockIdx.x * 40503u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        sm[i] = RANDOM_DATA ? (uint16_t)(((h & 0x8000u)) | (0x3c00u + ((h >> 3) & 0x07ffu))) : (uint16_t)(0x3c00 + (i * 7 % 97));
+    }
     __syncthreads();
     const int wm = wave >> 2, wn = wave & 3, sw = (li >> 2) & 3;
     const int offa0 = (wm * 64 + li) * 32, offb = (wn * 32 + li) * 32, ch0 = 8 * ((0 + lh) ^ sw), ch1 = 8 * ((2 + lh) ^ sw);
