@@ -21,13 +21,22 @@ COUNTER_KEYS = ("images", "accepted_tokens", "target_calls", "draft_stage_calls"
 def init_from_env(device_type: str = "cuda") -> Tuple[int, int, int]:
     """(rank, world, local_rank) from the torchrun environment; initialises the process group when world > 1."""
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    if device_type == "cuda":
+        # rehearsals put several ranks on one GPU (SDVAR_DIST_BACKEND=gloo): map the local rank onto the visible devices
+        local = local % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(local)
     if world > 1 and not tdist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = "nccl" if device_type == "cuda" else "gloo"
-        if device_type == "cuda":
-            torch.cuda.set_device(local)
+        backend = os.environ.get("SDVAR_DIST_BACKEND") or ("nccl" if device_type == "cuda" else "gloo")   # "nccl" is RCCL on ROCm
         tdist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+def _coll_device(device):
+    """Collectives run on the GPU with RCCL; with the gloo backend (CPU tests, single-GPU rehearsals) on host tensors."""
+    if tdist.is_available() and tdist.is_initialized() and tdist.get_backend() == "gloo":
+        return "cpu"
+    return device
 
 
 def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
@@ -39,7 +48,7 @@ def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
 
 def gather_counters(stats: Dict[str, int], device) -> Dict[str, object]:
     """All-gather the per-rank counters; returns totals plus the per-rank table (identical on every rank)."""
-    vec = torch.tensor([int(stats.get(k, 0)) for k in COUNTER_KEYS], dtype=torch.int64, device=device)
+    vec = torch.tensor([int(stats.get(k, 0)) for k in COUNTER_KEYS], dtype=torch.int64, device=_coll_device(device))
     if tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1:
         out = [torch.zeros_like(vec) for _ in range(tdist.get_world_size())]
         tdist.all_gather(out, vec)
@@ -54,7 +63,7 @@ def gather_counters(stats: Dict[str, int], device) -> Dict[str, object]:
 
 
 def max_over_ranks(value: float, device) -> float:
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device=_coll_device(device))
     if tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1:
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
     return float(t.item())
