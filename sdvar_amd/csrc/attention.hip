@@ -35,7 +35,7 @@ struct AttnArgs {
 };
 
 template <bool KVH>
-__global__ __launch_bounds__(256) void attention_f32_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attention_f32_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int STAGE = KT * KSTR + KT * 64;              // floats per pipeline stage: K tile then V tile
 
@@ -139,20 +139,46 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(AttnArgs a) {
         const int buf = t & 1, k0 = t * KT;
         if (t + 1 < ntiles) load_tile(k0 + KT);
         if (wave_active) {
-            // ---- scores for 2 sub-tiles of 32 keys
+            // LDS reads are hand-placed (inline asm + counted lgkmcnt): the compiler's schedule fetched every fragment right
+            // before its MFMA and exposed the LDS latency ~50 times per tile (rocprof: 34 % matrix-pipe use).
+            typedef __attribute__((address_space(3))) float* lds_f;
+            const uint32_t kb = (uint32_t)(uintptr_t)(lds_f)(smem + buf * STAGE) + 4u * (li * KSTR + 4 * lh);
+            const uint32_t vb = (uint32_t)(uintptr_t)(lds_f)(smem + buf * STAGE + KT * KSTR) + 4u * (4 * lh * 64 + li);
+            // ---- K fragments of both 32-key sub-tiles (16 x b128), then the 64 score MFMAs
+            f32x4 kf[2][8];
+#define SDVAR_RD128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr) : "memory")
+            SDVAR_RD128(kf[0][0], kb, 0);    SDVAR_RD128(kf[0][1], kb, 32);   SDVAR_RD128(kf[0][2], kb, 64);   SDVAR_RD128(kf[0][3], kb, 96);
+            SDVAR_RD128(kf[0][4], kb, 128);  SDVAR_RD128(kf[0][5], kb, 160);  SDVAR_RD128(kf[0][6], kb, 192);  SDVAR_RD128(kf[0][7], kb, 224);
+            SDVAR_RD128(kf[1][0], kb, 8704); SDVAR_RD128(kf[1][1], kb, 8736); SDVAR_RD128(kf[1][2], kb, 8768); SDVAR_RD128(kf[1][3], kb, 8800);
+            SDVAR_RD128(kf[1][4], kb, 8832); SDVAR_RD128(kf[1][5], kb, 8864); SDVAR_RD128(kf[1][6], kb, 8896); SDVAR_RD128(kf[1][7], kb, 8928);
+#undef SDVAR_RD128
             f32x16 s[2];
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) s[sub][i] = 0.f;
-                const float* pk = smem + buf * STAGE + (sub * 32 + li) * KSTR + 4 * lh;
+                if (sub == 0) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const f32x4 kf = *reinterpret_cast<const f32x4*>(pk + 8 * c);
+                for (int c = 0; c < 8; ++c)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) s[sub] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[c][e], s[sub], 0, 0, 0);
-                }
+                    for (int e = 0; e < 4; ++e) s[sub] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[sub][c][e], qf[c][e], s[sub], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
+            // ---- V operands of the whole tile: 32 x ds_read2st64_b32 (two key rows, 256 B apart, per instruction), issued
+            // before the softmax arithmetic so their latency hides under it.  vf[db][sub][i] = V[key(sub, i, lh)][32 db + li].
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            f32x2 vf[2][2][8];
+#define SDVAR_RDV(dst, addr, r0, r1) asm volatile("ds_read2st64_b32 %0, %1 offset0:" #r0 " offset1:" #r1 : "=v"(dst) : "v"(addr) : "memory")
+#define SDVAR_RDV_SUB(db, sub, base)                                                                                      \
+            SDVAR_RDV(vf[db][sub][0], vb + 128u * db, base + 0, base + 1);   SDVAR_RDV(vf[db][sub][1], vb + 128u * db, base + 2, base + 3);   \
+            SDVAR_RDV(vf[db][sub][2], vb + 128u * db, base + 8, base + 9);   SDVAR_RDV(vf[db][sub][3], vb + 128u * db, base + 10, base + 11); \
+            SDVAR_RDV(vf[db][sub][4], vb + 128u * db, base + 16, base + 17); SDVAR_RDV(vf[db][sub][5], vb + 128u * db, base + 18, base + 19); \
+            SDVAR_RDV(vf[db][sub][6], vb + 128u * db, base + 24, base + 25); SDVAR_RDV(vf[db][sub][7], vb + 128u * db, base + 26, base + 27);
+            SDVAR_RDV_SUB(0, 0, 0) SDVAR_RDV_SUB(1, 0, 0) SDVAR_RDV_SUB(0, 1, 32) SDVAR_RDV_SUB(1, 1, 32)
+#undef SDVAR_RDV_SUB
+#undef SDVAR_RDV
             // ---- mask + online softmax (this lane: one query, keys k0 + sub*32 + (i&3) + 8*(i>>2) + 4*lh)
             float mloc = -INFINITY;
 #pragma unroll
@@ -180,15 +206,19 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(AttnArgs a) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
             // ---- O^T += V^T P^T : step i pairs key (i&3)+8*(i>>2) (half 0) with the same +4 (half 1)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const float* pv = smem + buf * STAGE + KT * KSTR + (sub * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh) * 64 + li;
-                    o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(pv[0], s[sub][i], o0, 0, 0, 0);
-                    o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(pv[32], s[sub][i], o1, 0, 0, 0);
+                    // i = 4g + e: rows (e, e+1) of group g were fetched together: vf[..][2g + (e >> 1)][e & 1]
+                    const int slot = 2 * (i >> 2) + ((i & 3) >> 1), half = i & 1;
+                    o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[0][sub][slot][half], s[sub][i], o0, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[1][sub][slot][half], s[sub][i], o1, 0, 0, 0);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (t + 1 < ntiles) store_tile(buf ^ 1);
         __syncthreads();

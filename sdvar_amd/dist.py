@@ -62,6 +62,32 @@ def gather_counters(stats: Dict[str, int], device) -> Dict[str, object]:
     return res
 
 
+def leading_accepted(matched: Sequence[int], totals: Sequence[int], thr: float) -> int:
+    """Number of leading stages whose match rate is >= thr, with the reference's arithmetic: float32 mean compared as a
+    python float (models/var.py:1203, 1217)."""
+    import numpy as np
+    n = 0
+    for m, t in zip(matched, totals):
+        rate = float(np.float32(m) / np.float32(t))
+        if rate >= thr:
+            n += 1
+        else:
+            break
+    return n
+
+
+def global_accept(matched: Sequence[int], totals: Sequence[int], thr: float, device) -> Tuple[int, Sequence[int], Sequence[int]]:
+    """accept_scope="global" (SURVEY.md section 8e): the reference decides on the mean over the WHOLE batch, so the per-stage
+    (matched, total) counts are summed over the ranks - one all-reduce of 2*gamma int64 per round, latency only - and every
+    rank takes the same decision.  Returns (n_accept, global matched, global totals)."""
+    vec = torch.tensor(list(matched) + list(totals), dtype=torch.int64, device=_coll_device(device))
+    if tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1:
+        tdist.all_reduce(vec, op=tdist.ReduceOp.SUM)
+    v = vec.cpu().tolist()
+    g = len(matched)
+    return leading_accepted(v[:g], v[g:], thr), v[:g], v[g:]
+
+
 def max_over_ranks(value: float, device) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=_coll_device(device))
     if tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1:

@@ -416,6 +416,10 @@ class Sampler:
             verify_accept(self.logits_t, st.B, st.glen, self.t.V, [lad.cfg_t(st.cfg, cur + j) for j in range(g)], self.ids, lad.begin(cur), lad.L, st.thr, self.counts)
             self.counts_host.copy_(self.counts, non_blocking=False)            # the one host sync of the round
         c = self.counts_host.tolist()
+        if st.accept_scope == "global":            # batch-wide decision across ranks (reference-literal for one big batch)
+            from . import dist as D
+            n, matched, _ = D.global_accept(c[:g], c[17:17 + g], st.thr, self.dev)
+            return n, matched
         return c[16], c[:g]
 
     def spec_commit(self, st: "SpecState", n_acc: int, forced: bool = False):
@@ -484,6 +488,7 @@ class SpecState:
     reject_count: int = 0
     target_calls: int = 0
     more_smooth: bool = False
+    accept_scope: str = "shard"                   # "shard": this process decides alone; "global": all-reduce of the match counts
     draw: int = 0
     g: int = 0
     glen: list = field(default_factory=list)

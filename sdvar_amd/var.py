@@ -230,7 +230,9 @@ class SDVAR(nn.Module):
         smp = self._get_sampler(B, gamma)
         seed = int(torch.seed() & 0x7FFFFFFFFFFFFFFF) if g_seed is None else int(g_seed)
         noise = E.Noise("torch", seed, generator=rng) if self.noise_kind == "torch" else E.Noise(self.noise_kind, seed)
-        return smp.spec_begin(labels, cfg, gamma, 0, 0.0, noise, thr=self.match_threshold)     # top_k / top_p set by the caller (var.py:937-938)
+        st = smp.spec_begin(labels, cfg, gamma, 0, 0.0, noise, thr=self.match_threshold)       # top_k / top_p set by the caller (var.py:937-938)
+        st.accept_scope = self.accept_scope
+        return st
 
     def draft_generate_batch(self, state: E.SpecState, B: int):
         """var.py:949-1024 -> list of g token tensors (B, pn^2) int64 for stages current_stage .. current_stage+g-1."""

@@ -41,9 +41,21 @@ def _worker(rank, world, port, out_dir):
     D.barrier()
     agg = D.gather_counters(st, "cpu")
     t = D.max_over_ranks(float(rank + 1), "cpu")
+    # accept_scope="global": rank 0 matched 3/8 and 8/8, rank 1 5/8 and 0/8 -> global rates 0.5 and 0.5 -> both accepted everywhere
+    n_glob, gm, gt = D.global_accept([3, 8] if rank == 0 else [5, 0], [8, 8], 0.5, "cpu")
+    assert (n_glob, list(gm), list(gt)) == (2, [8, 8], [16, 16]), (n_glob, gm, gt)
+    assert D.leading_accepted([3, 8] if rank == 0 else [5, 0], [8, 8], 0.5) == (0 if rank == 0 else 1)        # the shard-scope decisions differ
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), ids=torch.cat(tr.ids, 1).numpy(), lo=lo, hi=hi, images=agg["images"], accepted=agg["accepted_tokens"],
              target_calls=agg["target_calls"], per_rank=np.array(agg["per_rank"]), tmax=t, mean_acc=agg["mean_accepted_tokens_per_step"])
     torch.distributed.destroy_process_group()
+
+
+def test_leading_accepted_float32_mean_semantics():
+    from sdvar_amd.dist import leading_accepted
+    assert leading_accepted([8, 4, 3], [8, 8, 8], 0.5) == 2
+    assert leading_accepted([0], [5], 0.0) == 1 and leading_accepted([5], [5], 2.0) == 0
+    # float32(1)/float32(3) = 0.3333333432674408 >= 0.33333334 (python float) -> accepted, as the reference's .item() compare
+    assert leading_accepted([1], [3], 0.33333334) == 1 and leading_accepted([1], [3], 0.333333344) == 0
 
 
 def test_shard_ranges():
