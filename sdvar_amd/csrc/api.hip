@@ -80,7 +80,7 @@ static int dmalloc(T** p, size_t n) {
 struct BlockW {
     const float *ada_w, *ada_b, *qkv_w, *scale_mul, *proj_w, *proj_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
     float* qkv_bias;     // owned: [q_bias, 0, v_bias]  (basic_var.py:93)
-    void *kc, *vc;       // owned KV cache (Rmax, H, L, 64), fp32 or fp16 (desc.kv_dtype)
+    void *kc, *vc;       // owned KV cache: (Rmax, H, L, 64) fp32 or fp16 (desc.kv_dtype), or the bf16x3 planes of attention_bf16x3.hip (kv_fmt 2)
     uint16_t *qkv_wp, *proj_wp, *fc1_wp, *fc2_wp;   // owned bf16x3 planes of the weights (desc.gemm_mode == 1)
     bool bound;
 };
@@ -92,6 +92,7 @@ using namespace sdvar;
 struct sdvar_model {
     sdvar_model_desc d;
     int C, H, L, Rmax, lmax, S;
+    int kv_fmt, Lkv;     // cache format handed to the kernels (0 fp32, 1 fp16, 2 planes) and its row capacity
     int lens[SDVAR_MAX_STAGES], cum[SDVAR_MAX_STAGES];
     // borrowed
     const float *class_emb, *pos_start, *word_w, *word_b, *nm_w, *nm_b, *head_w, *head_b;
@@ -148,6 +149,9 @@ int sdvar_model_create(const sdvar_model_desc* desc, sdvar_model_t** out) {
         m->lens[s] = desc->patch_nums[s] * desc->patch_nums[s]; c += m->lens[s]; m->cum[s] = c;
     }
     m->L = c;
+    // the split-operand GEMM mode keeps an fp32 cache as exact bf16 planes so that attention runs on the bf16 matrix cores too
+    m->kv_fmt = (desc->kv_dtype == 0 && desc->gemm_mode == 1 && !getenv("SDVAR_ATTN_F32")) ? 2 : desc->kv_dtype;   // env: A/B runs only
+    m->Lkv = (m->kv_fmt == 2) ? (c + 63) / 64 * 64 : c;
     // the largest chunk is a window of max_chunk_stages consecutive stages; stage lengths are non-decreasing
     m->lmax = 0;
     for (int s = 0; s < m->S; ++s) {
@@ -189,9 +193,11 @@ int sdvar_model_create(const sdvar_model_desc* desc, sdvar_model_t** out) {
             SDVAR_TRY(dmalloc(&b.fc1_wp, 3 * 4 * C * C)); SDVAR_TRY(dmalloc(&b.fc2_wp, 3 * 4 * C * C));
         }
         SDVAR_TRY(dmalloc(&b.qkv_bias, 3 * C));
-        const size_t kvb = R * (size_t)m->H * m->L * 64 * (desc->kv_dtype ? 2 : 4);
+        const size_t kvb = R * (size_t)m->H * m->Lkv * 64 * (m->kv_fmt == 2 ? 6 : m->kv_fmt == 1 ? 2 : 4);
         SDVAR_HIP(hipMalloc(&b.kc, kvb));
         SDVAR_HIP(hipMalloc(&b.vc, kvb));
+        SDVAR_HIP(hipMemset(b.kc, 0, kvb));        // the planes kernel streams whole 64-key tiles: rows past kv_len must be finite
+        SDVAR_HIP(hipMemset(b.vc, 0, kvb));
     }
     *out = m;
     return SDVAR_OK;
@@ -332,6 +338,9 @@ int sdvar_stage_forward(sdvar_model_t* m, float* x, int32_t s0, int32_t n, float
     const float* ws = P ? splitk_workspace(&wsf) : nullptr;
     PendingSplitK pend{nullptr, nullptr, nullptr, 0, 1, 0};           // unreduced gated residual waiting for the next ln_modulate
     int defer = 0;
+    // the row kernels have one wave per row: only with >= 1024 rows do they have the parallelism to sum slabs as fast as
+    // the dedicated reduce kernel (measured at M = 16: 37 us per LN launch against 5 + 7 us)
+    int* const dp = (M >= 1024) ? &defer : nullptr;
     for (int i = 0; i < m->d.depth; ++i) {
         const BlockW& b = m->blk[i];
         const float* ada = m->ada + (size_t)i * m->Rmax * 6 * C;      // (R, 6C): gamma1 gamma2 scale1 scale2 shift1 shift2
@@ -339,15 +348,15 @@ int sdvar_stage_forward(sdvar_model_t* m, float* x, int32_t s0, int32_t n, float
           SDVAR_TRY(ln_modulate(x, ada + 2 * C, ada + 4 * C, m->xn, P ? m->xn_p : nullptr, ps, M, C, lsum, 6 * C, &pend, s)); pend.ws = nullptr; }
         PendingSplitK pq{nullptr, nullptr, nullptr, 0, 1, 0};
         { ProfScope pp(0, 2 * dM * 3 * dC * dC, 4 * (dM * dC + 3 * dC * dC + 3 * dM * dC), s);
-          if (P) { SDVAR_TRY(gemm_bf16x3_nt(m->xn_p, ps, b.qkv_wp, (size_t)3 * C * C, b.qkv_bias, m->qkv, 3 * C, nullptr, 0, M, 3 * C, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, &defer, s));
+          if (P) { SDVAR_TRY(gemm_bf16x3_nt(m->xn_p, ps, b.qkv_wp, (size_t)3 * C * C, b.qkv_bias, m->qkv, 3 * C, nullptr, 0, M, 3 * C, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, dp, s));
                    if (defer) pq = PendingSplitK{ws, b.qkv_bias, nullptr, defer, 1, 0}; }
           else SDVAR_TRY(gemm_f32_nt(m->xn, C, b.qkv_w, b.qkv_bias, m->qkv, 3 * C, M, 3 * C, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, s)); }
         { ProfScope pp(3, 6 * dM * dC, 4 * 6 * dM * dC, s);
-          SDVAR_TRY(qk_norm_append(m->qkv, b.scale_mul, m->qbuf, b.kc, b.vc, m->d.kv_dtype, R, lsum, H, m->L, m->kv_len, &pq, s)); }
+          SDVAR_TRY(qk_norm_append(m->qkv, b.scale_mul, m->qbuf, b.kc, b.vc, m->kv_fmt, R, lsum, H, m->Lkv, m->kv_len, &pq, s)); }
         { ProfScope pp(1, 4.0 * R * H * 64.0 * lk, R * H * 64.0 * ((m->d.kv_dtype ? 4.0 : 8.0) * Ktot + 8.0 * lsum), s);
-          SDVAR_TRY(attention_f32(m->qbuf, b.kc, b.vc, m->d.kv_dtype, m->att, P ? m->att_p : nullptr, ps, R, H, lsum, m->L, Ktot, n, qbeg, vis, s)); }
+          SDVAR_TRY(attention_f32(m->qbuf, b.kc, b.vc, m->kv_fmt, m->att, P ? m->att_p : nullptr, ps, R, H, lsum, m->Lkv, Ktot, n, qbeg, vis, s)); }
         { ProfScope pp(0, 2 * dM * dC * dC, 4 * (3 * dM * dC + dC * dC), s);
-          if (P) { SDVAR_TRY(gemm_bf16x3_nt(m->att_p, ps, b.proj_wp, (size_t)C * C, b.proj_b, x, C, nullptr, 0, M, C, C, EPI_GATED_RES, x, C, ada, lsum, 6 * C, &defer, s));
+          if (P) { SDVAR_TRY(gemm_bf16x3_nt(m->att_p, ps, b.proj_wp, (size_t)C * C, b.proj_b, x, C, nullptr, 0, M, C, C, EPI_GATED_RES, x, C, ada, lsum, 6 * C, dp, s));
                    if (defer) pend = PendingSplitK{ws, b.proj_b, ada, defer, lsum, 6 * C}; }
           else SDVAR_TRY(gemm_f32_nt(m->att, C, b.proj_w, b.proj_b, x, C, M, C, C, EPI_GATED_RES, x, C, ada, lsum, 6 * C, s)); }
         { ProfScope pp(2, 8 * dM * dC, (P ? 10 : 8) * dM * dC, s);
@@ -356,7 +365,7 @@ int sdvar_stage_forward(sdvar_model_t* m, float* x, int32_t s0, int32_t n, float
           if (P) SDVAR_TRY(gemm_bf16x3_nt(m->xn_p, ps, b.fc1_wp, (size_t)4 * C * C, b.fc1_b, nullptr, 0, m->hid_p, 4 * ps, M, 4 * C, C, EPI_BIAS_GELU, nullptr, 0, nullptr, 0, 0, nullptr, s));
           else SDVAR_TRY(gemm_f32_nt(m->xn, C, b.fc1_w, b.fc1_b, m->hid, 4 * C, M, 4 * C, C, EPI_BIAS_GELU, nullptr, 0, nullptr, 0, 0, s)); }
         { ProfScope pp(0, 2 * dM * 4 * dC * dC, 4 * (4 * dM * dC + 4 * dC * dC + 2 * dM * dC), s);
-          if (P) { SDVAR_TRY(gemm_bf16x3_nt(m->hid_p, 4 * ps, b.fc2_wp, (size_t)4 * C * C, b.fc2_b, x, C, nullptr, 0, M, C, 4 * C, EPI_GATED_RES, x, C, ada + C, lsum, 6 * C, &defer, s));
+          if (P) { SDVAR_TRY(gemm_bf16x3_nt(m->hid_p, 4 * ps, b.fc2_wp, (size_t)4 * C * C, b.fc2_b, x, C, nullptr, 0, M, C, 4 * C, EPI_GATED_RES, x, C, ada + C, lsum, 6 * C, dp, s));
                    if (defer) pend = PendingSplitK{ws, b.fc2_b, ada + C, defer, lsum, 6 * C}; }
           else SDVAR_TRY(gemm_f32_nt(m->hid, 4 * C, b.fc2_w, b.fc2_b, x, C, M, C, 4 * C, EPI_GATED_RES, x, C, ada + C, lsum, 6 * C, s)); }
     }

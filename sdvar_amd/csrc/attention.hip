@@ -253,8 +253,13 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(AttnArgs a) {
     }
 }
 
+int attention_bf16x3(const float* q, const void* kc, const void* vc, float* out, uint16_t* outp, size_t ops, int R, int H, int l, int Lp,
+                     int Ktot, int n_chunk, const int* qbeg, const int* vis, hipStream_t stream);
+
+// kv_f16: cache format, 0 = fp32, 1 = fp16 (this file), 2 = bf16x3 planes (attention_bf16x3.hip)
 int attention_f32(const float* q, const void* kc, const void* vc, int kv_f16, float* out, uint16_t* outp, size_t ops, int R, int H, int l, int Lmax,
                   int Ktot, int n_chunk, const int* qbeg, const int* vis, hipStream_t stream) {
+    if (kv_f16 == 2) return attention_bf16x3(q, kc, vc, out, outp, ops, R, H, l, Lmax, Ktot, n_chunk, qbeg, vis, stream);
     SDVAR_CHECK_ARG(q && kc && vc && (out || outp), "attention: null operand");
     SDVAR_CHECK_ARG(n_chunk >= 1 && n_chunk <= ATT_MAX_CHUNK, "attention: chunk of %d stages unsupported (max %d)", n_chunk, ATT_MAX_CHUNK);
     SDVAR_CHECK_ARG(R > 0 && H > 0 && l > 0 && Ktot >= l && Ktot <= Lmax, "attention: bad lengths l=%d Ktot=%d Lmax=%d", l, Ktot, Lmax);

@@ -70,6 +70,20 @@ __device__ __forceinline__ void split3(float x, uint16_t& p0, uint16_t& p1, uint
     p0 = (uint16_t)(u0 >> 16); p1 = (uint16_t)(u1 >> 16); p2 = (uint16_t)(__float_as_uint(r2) >> 16);
 }
 
+// eight consecutive values -> three packed bf16x8 words (same split); the top halves of two values are packed with one v_perm_b32
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split8_packed(const float* v, u32x4& a, u32x4& b, u32x4& c) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x0 = v[2 * e], x1 = v[2 * e + 1];
+        const float r0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xFFFF0000u), r1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xFFFF0000u);
+        const float s0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xFFFF0000u), s1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xFFFF0000u);
+        a[e] = __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
+        b[e] = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
+        c[e] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+    }
+}
+
 // Planar bf16x3 tensors are K-BLOCKED: element (row, k) of plane p of a (rows x K) matrix lives at
 //     plane_base[p] + ((k / 32) * rows + row) * 32 + (k % 32)
 // i.e. for every block of 32 k the rows are contiguous 64-byte segments, so the (tile rows) x (32 k) slab a GEMM workgroup

@@ -144,13 +144,89 @@ __global__ __launch_bounds__(256) void qk_norm_append_kernel(const float* __rest
     v_cache[c] = (KV)v;
 }
 
+// Format 2 of the cache (attention_bf16x3.hip): K planes [R][H][3][Lp][64] and V^T planes [R][H][3][64][Lp] with bits 2 and 3
+// of the key position swapped inside every block of 16 keys.  Same arithmetic as above; the fp32 values are split exactly.
+// One workgroup per (64-position block of the cache, head, row): the waves normalise their tokens and write q and the K
+// planes (128-byte rows), V goes through LDS and leaves as 16-byte runs of 8 cache positions per channel row (transposed
+// 2-byte stores cost 2x the whole kernel: 1.15 ms against 0.44 ms per d16 stage-9 call).
+__global__ __launch_bounds__(256) void qk_norm_append_planes_kernel(const float* __restrict__ qkv, const float* __restrict__ scale_mul,
+                                                                    float* __restrict__ q_out, uint16_t* __restrict__ k_cache,
+                                                                    uint16_t* __restrict__ v_cache, int R, int l, int H, int Lp, int pos0, PendingSplitK pend) {
+    __shared__ float vs[64 * 65];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.y, r = blockIdx.z;
+    const int P0 = (pos0 / 64 + blockIdx.x) * 64;
+    const int pb = max(P0, pos0), pe = min(P0 + 64, pos0 + l);
+    const int C = H * 64;
+    const size_t head = ((size_t)r * H + h) * 3 * (size_t)Lp * 64, ps = (size_t)Lp * 64;
+    const float sm = expf(fminf(scale_mul[h], 4.605170249938965f));
+    for (int pos = pb + wave; pos < pe; pos += 4) {
+        const int t = pos - pos0;
+        const size_t row = (size_t)r * l + t;
+        float q, k, v;
+        if (pend.ws) {
+            const size_t slab = (size_t)R * l * 3 * C, o = row * 3 * C + h * 64 + lane;
+            q = pend.ws[o]; k = pend.ws[o + C]; v = pend.ws[o + 2 * C];
+            for (int s = 1; s < pend.split; ++s) { q += pend.ws[s * slab + o]; k += pend.ws[s * slab + o + C]; v += pend.ws[s * slab + o + 2 * C]; }
+            q += pend.bias[h * 64 + lane]; k += pend.bias[C + h * 64 + lane]; v += pend.bias[2 * C + h * 64 + lane];
+        } else {
+            const float* p = qkv + row * 3 * C + h * 64 + lane;
+            q = p[0]; k = p[C]; v = p[2 * C];
+        }
+        const float qn = fmaxf(sqrtf(wave_sum(q * q)), 1e-12f);
+        const float kn = fmaxf(sqrtf(wave_sum(k * k)), 1e-12f);
+        q_out[(((size_t)r * H + h) * l + t) * 64 + lane] = (q / qn) * sm;
+        uint16_t k0, k1, k2;
+        split3(k / kn, k0, k1, k2);
+        uint16_t* pk = k_cache + head + (size_t)pos * 64 + lane;
+        pk[0] = k0; pk[ps] = k1; pk[2 * ps] = k2;
+        vs[(pos - P0) * 65 + lane] = v;
+    }
+    __syncthreads();
+    // thread -> (channel row d, run c of 8 cache positions): positions P0 + 8c .. +7 hold keys P0 + 16 (c >> 1) + 4 (c & 1) + {0..3, 8..11}
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int d = (tid >> 3) + 32 * it, c = tid & 7;
+        const int kb = P0 + 16 * (c >> 1) + 4 * (c & 1);
+        float v[8];
+        int inside = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int key = kb + (e & 3) + 8 * (e >> 2);
+            const bool in = key >= pb && key < pe;
+            inside += in;
+            v[e] = in ? vs[(key - P0) * 65 + d] : 0.f;
+        }
+        uint16_t* pv = v_cache + head + (size_t)d * Lp + P0 + 8 * c;
+        if (inside == 8) {
+            u32x4 a, b, cc;
+            split8_packed(v, a, b, cc);
+            *reinterpret_cast<u32x4*>(pv) = a; *reinterpret_cast<u32x4*>(pv + ps) = b; *reinterpret_cast<u32x4*>(pv + 2 * ps) = cc;
+        } else if (inside) {        // run shared with an earlier or later append: only this call's keys may be written
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int key = kb + (e & 3) + 8 * (e >> 2);
+                if (key >= pb && key < pe) {
+                    uint16_t v0, v1, v2;
+                    split3(v[e], v0, v1, v2);
+                    pv[e] = v0; pv[ps + e] = v1; pv[2 * ps + e] = v2;
+                }
+            }
+        }
+    }
+}
+
 int qk_norm_append(const float* qkv, const float* scale_mul, float* q_out, void* k_cache, void* v_cache, int kv_f16, int R, int l, int H,
                    int Lmax, int pos0, const PendingSplitK* pend, hipStream_t stream) {
     PendingSplitK pd{nullptr, nullptr, nullptr, 0, 1, 0};
     if (pend && pend->ws) { SDVAR_CHECK_ARG(pend->bias && pend->split >= 1, "qk_norm_append: bad pending split-K descriptor"); pd = *pend; }
     SDVAR_CHECK_ARG(R > 0 && l > 0 && H > 0 && pos0 >= 0 && pos0 + l <= Lmax, "qk_norm_append: cache overflow pos0=%d l=%d Lmax=%d", pos0, l, Lmax);
     const long long items = (long long)R * l * H;
-    if (kv_f16) hipLaunchKernelGGL(qk_norm_append_kernel<__half>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, qkv, scale_mul, q_out, (__half*)k_cache, (__half*)v_cache, R, l, H, Lmax, pos0, pd);
+    SDVAR_CHECK_ARG(kv_f16 >= 0 && kv_f16 <= 2, "qk_norm_append: cache format %d (0 = fp32, 1 = fp16, 2 = bf16x3 planes)", kv_f16);
+    if (kv_f16 == 2) {
+        SDVAR_CHECK_ARG(Lmax % 64 == 0, "qk_norm_append: the planes KV format needs Lmax %% 64 == 0 (got %d)", Lmax);
+        hipLaunchKernelGGL(qk_norm_append_planes_kernel, dim3((unsigned)((pos0 + l + 63) / 64 - pos0 / 64), H, R), dim3(256), 0, stream, qkv, scale_mul, q_out, (uint16_t*)k_cache, (uint16_t*)v_cache, R, l, H, Lmax, pos0, pd);
+    } else if (kv_f16) hipLaunchKernelGGL(qk_norm_append_kernel<__half>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, qkv, scale_mul, q_out, (__half*)k_cache, (__half*)v_cache, R, l, H, Lmax, pos0, pd);
     else hipLaunchKernelGGL(qk_norm_append_kernel<float>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, qkv, scale_mul, q_out, (float*)k_cache, (float*)v_cache, R, l, H, Lmax, pos0, pd);
     SDVAR_LAUNCH_CHECK();
     return SDVAR_OK;

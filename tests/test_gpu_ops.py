@@ -289,6 +289,72 @@ def test_fp16_kv_cache_append_and_attention(dev):
 
 
 # ------------------------------------------------------------------------------------------------ bf16x3 split-operand path
+@pytest.mark.parametrize("R,H,lens,prefix", [(2, 4, [1], 0), (2, 2, [4], 1), (4, 3, [25], 30), (2, 4, [100], 155), (2, 16, [256], 424),
+                                             (2, 4, [9, 16], 5), (2, 3, [64, 100, 169], 91), (2, 2, [1, 4], 0), (1, 2, [169, 256], 255), (2, 2, [324], 640)])
+def test_planes_kv_cache_append_and_attention(dev, R, H, lens, prefix):
+    """Cache format 2 (bf16x3 planes, attention on the bf16 matrix cores): append in two calls, then the block-causal attention;
+    K and V are held exactly (three planes = the fp32 value), so the bar is the fp32 kernel's."""
+    lib = E.load_library()
+    l = sum(lens); Ktot = prefix + l; Lp = (Ktot + 5 + 63) // 64 * 64
+    Cw = 64 * H
+    sm = torch.full((H,), math.log(4.0), device=dev)
+    kc = torch.zeros(R, H, 3, Lp, 64, device=dev, dtype=torch.int16); vc = torch.zeros(R, H, 3, 64, Lp, device=dev, dtype=torch.int16)
+    parts = []
+    for i, (n, pos0) in enumerate([(prefix, 0), (l, prefix)]):
+        if n == 0:
+            continue
+        qkv = rnd(10 + i, (R * n, 3 * Cw)).to(dev)
+        qo = torch.zeros(R, H, n, 64, device=dev)
+        E._check(lib.sdvar_op_qk_norm_append(_p(qkv), _p(sm), _p(qo), _p(kc), _p(vc), 2, R, n, H, Lp, pos0, _st()))
+        parts.append(qkv.cpu().view(R, n, 3, H, 64).permute(2, 0, 3, 1, 4))
+    k = F.normalize(torch.cat([p[1] for p in parts], dim=2), dim=-1); v = torch.cat([p[2] for p in parts], dim=2)
+    # the planes reproduce K exactly: sum of the three bf16 planes == fp32 value written by the fp32-format kernel
+    kpl = kc.cpu().view(torch.bfloat16).float().sum(2)[:, :, :Ktot]
+    assert (kpl - k).abs().max().item() <= 1e-6
+    perm = [(p & ~12) | ((p & 4) << 1) | ((p & 8) >> 1) for p in range(Ktot)]
+    vpl = vc.cpu().view(torch.bfloat16).float().sum(2)[:, :, :, perm].transpose(2, 3)
+    assert torch.equal(vpl, v)
+    qbeg = [int(sum(lens[:j])) for j in range(len(lens))]
+    vis = [prefix + int(sum(lens[:j + 1])) for j in range(len(lens))]
+    out = torch.empty(R, l, H * 64, device=dev)
+    n = len(lens)
+    E._check(lib.sdvar_op_attention(_p(qo), _p(kc), _p(vc), 2, _p(out), None, 0, R, H, l, Lp, Ktot, n, (C.c_int32 * n)(*qbeg), (C.c_int32 * n)(*vis), _st()))
+    ref = _attn_ref(qo.cpu(), k, v, qbeg, vis).transpose(1, 2).reshape(R, l, H * 64)
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err <= 2e-5, err
+    # plane output == fp32 output (the projection GEMM's operand)
+    M = R * l
+    outp = torch.zeros(3, H * 64 // 32, M, 32, device=dev, dtype=torch.int16)
+    E._check(lib.sdvar_op_attention(_p(qo), _p(kc), _p(vc), 2, None, _p(outp), M * H * 64, R, H, l, Lp, Ktot, n, (C.c_int32 * n)(*qbeg), (C.c_int32 * n)(*vis), _st()))
+    assert torch.equal(_unplanes(outp.cpu()).float().view(R, l, H * 64), out.cpu())
+
+
+def test_planes_attention_forced_online_rescale(dev):
+    lib = E.load_library()
+    R, H, l, Ktot, Lp = 1, 1, 40, 300, 320
+    q = F.normalize(rnd(1, (R, H, l, 64)), dim=-1) * 50.0
+    k = F.normalize(rnd(2, (R, H, Ktot, 64)), dim=-1)
+    k[0, 0, 200] = q[0, 0, 3] / 50.0
+    k[0, 0, 299] = q[0, 0, 17] / 50.0
+    v = rnd(3, (R, H, Ktot, 64))
+
+    def planes3(t):                                                            # exact 3-way truncation split, like common.h split3
+        out, rest = [], t.clone()
+        for _ in range(3):
+            hi = (rest.view(torch.int32) & -65536).view(torch.float32)
+            out.append((hi.view(torch.int32) >> 16).to(torch.int16)); rest = rest - hi
+        return torch.stack(out)
+    kc = torch.zeros(R, H, 3, Lp, 64, dtype=torch.int16); vc = torch.zeros(R, H, 3, 64, Lp, dtype=torch.int16)
+    kc[:, :, :, :Ktot] = planes3(k).permute(1, 2, 0, 3, 4)
+    perm = torch.tensor([(p & ~12) | ((p & 4) << 1) | ((p & 8) >> 1) for p in range(Ktot)])
+    vc[:, :, :, :, perm] = planes3(v).permute(1, 2, 0, 4, 3)
+    out = torch.empty(R, l, 64, device=dev)
+    qd, kd, vd = q.to(dev), kc.to(dev).contiguous(), vc.to(dev).contiguous()
+    E._check(lib.sdvar_op_attention(_p(qd), _p(kd), _p(vd), 2, _p(out), None, 0, R, H, l, Lp, Ktot, 1, (C.c_int32 * 1)(0), (C.c_int32 * 1)(Ktot), _st()))
+    ref = _attn_ref(q, k, v, [0], [Ktot]).transpose(1, 2).reshape(R, l, 64)
+    assert (out.cpu().double() - ref).abs().max().item() <= 2e-5
+
+
 def _planes(t, dev):
     """fp32 (rows, K) -> device K-blocked planes (3, K/32, rows, 32) int16 through the library's splitter."""
     lib = E.load_library()
