@@ -23,6 +23,7 @@ extern "C" {
 
 typedef struct sdvar_model sdvar_model_t;   /* one VAR transformer: weights (borrowed), KV cache, workspaces */
 typedef struct sdvar_quant sdvar_quant_t;   /* VectorQuantizer2 inference side: codebook, Phi convs, resample tables */
+typedef struct sdvar_vae sdvar_vae_t;       /* VQVAE image decoder (fhat_to_img): conv weights as bf16x3 planes, activation workspaces */
 
 typedef struct {
     int32_t depth;                          /* d: width C = 64 d, heads H = d   (models/__init__.py:26-27) */
@@ -89,6 +90,30 @@ int sdvar_quant_bind(sdvar_quant_t* q, const float* codebook, const float* const
  * = area_down(f_hat) (not written for the last stage; may be NULL there).  ids[b*ids_stride + p]. */
 int sdvar_quant_next(sdvar_quant_t* q, int32_t si, const int64_t* ids, int32_t ids_stride, float* f_hat, float* nxt, int32_t B, void* stream);
 
+/* ---- VQVAE decoder: f_hat -> image (the caller side of the sampler) ------------------ */
+typedef struct {
+    int32_t ch;                             /* base width (160 for vae_ch160v4096z32)          models/vqvae.py:30-33 */
+    int32_t z_channels;                     /* Cvae = 32 */
+    int32_t n_mult;                         /* number of resolution levels */
+    int32_t ch_mult[8];                     /* (1, 1, 2, 2, 4)                                 models/vqvae.py:31 */
+    int32_t num_res_blocks;                 /* 2: every decoder level has num_res_blocks + 1 ResnetBlocks (basic_vae.py:196) */
+    int32_t max_batch;
+    int32_t latent_hw;                      /* side of f_hat: 16 for 256^2 images, 32 for 512^2 */
+} sdvar_vae_desc;
+int sdvar_vae_create(const sdvar_vae_desc* desc /*host*/, sdvar_vae_t** out /*host*/);
+int sdvar_vae_destroy(sdvar_vae_t* v);
+/* number of tensors sdvar_vae_bind expects for this descriptor */
+int sdvar_vae_tensor_count(const sdvar_vae_desc* desc /*host*/);
+/* Host array of device pointers to the fp32 state_dict tensors, in execution order (weight then bias each):
+ * post_quant_conv; decoder.conv_in; decoder.mid.block_1 {norm1, conv1, norm2, conv2}; decoder.mid.attn_1 {norm, qkv,
+ * proj_out}; decoder.mid.block_2; then for level = n_mult-1 .. 0: for i = 0 .. num_res_blocks: up.level.block.i {norm1,
+ * conv1, norm2, conv2, [nin_shortcut if the width changes]}, [up.level.attn.i at the top level]; [up.level.upsample.conv
+ * for level > 0]; decoder.norm_out; decoder.conv_out.   (models/basic_vae.py:163-226)
+ * Conv weights are re-packed into bf16x3 planes (owned copies); biases and GroupNorm affine tensors stay borrowed. */
+int sdvar_vae_bind(sdvar_vae_t* v, const float* const* tensors /*host*/, int32_t n_tensors, void* stream);
+/* vqvae.py:62-63: img (B,3,H,W) = clamp(decoder(post_quant_conv(f_hat (B,Cvae,h,w))), -1, 1), H = h << (n_mult-1) */
+int sdvar_vae_decode(sdvar_vae_t* v, const float* f_hat, int32_t B, float* img, void* stream);
+
 /* ---- sampling / acceptance -------------------------------------------------------------------------------------- */
 /* var.py:199-202 + helpers.py:6-19: CFG with t = cfg*si/(S-1), top-k, top-p, draw = argmax(p/q).
  * q: explicit Exp(1) noise (B*l, V), or NULL to generate the Philox stream of sdvar_amd/noise.py in-kernel from
@@ -125,6 +150,18 @@ int sdvar_op_attention(const float* q, const void* k_cache, const void* v_cache,
                        const int32_t* vis /*host*/, void* stream);
 int sdvar_op_noise_fill(float* q, int32_t B, int32_t l, int32_t V, uint64_t seed, uint32_t draw, uint32_t image_offset, void* stream);
 
+/* conv weight (Cout, Cin, kh, kw) with kh*kw = taps (1 or 9) -> K-blocked planes [3][taps*Cin/32][Cout][32], k = tap*Cin + cin */
+int sdvar_op_conv_weight_planes(const float* w, uint16_t* planes, int32_t Cout, int32_t Cin, int32_t taps, uint64_t plane_stride, void* stream);
+/* fp32 padded pixel rows of a (B,C,H,W) tensor (row(b,y,x) = (b(H+2)+y+1)(W+2)+x+1, frame rows ignored) -> planes
+ * [3][C/32][guard + B(Ho+2)(Wo+2) + guard][32] of the (B,C,H<<up,W<<up) tensor with zero frame and guards.
+ * mode bit 0: GroupNorm(32 groups) with stats (B,32,{mean,rstd}), gamma, beta; bit 1: SiLU. */
+int sdvar_op_vae_prep(const float* in, const float* stats, const float* gamma, const float* beta, uint16_t* planes, uint64_t plane_stride, int32_t B, int32_t C,
+                      int32_t H, int32_t W, int32_t up, int32_t mode, int32_t guard, void* stream);
+/* out[M][N] = conv(x planes, w planes) + bias (+ res[M][N]) on padded pixel rows; taps = 9: 3x3 with row_pitch = W+2 (x_row0 = guard
+ * rows >= row_pitch+1), taps = 1: 1x1.  workspace: split-K slabs (may be NULL: no split); force_split > 0 overrides the heuristic. */
+int sdvar_op_conv_bf16x3(const uint16_t* x_planes, uint64_t x_plane_stride, uint64_t x_rows, int32_t x_row0, const uint16_t* w_planes, uint64_t w_plane_stride,
+                         const float* bias, const float* res, float* out, int32_t M, int32_t N, int32_t Cin, int32_t taps, int32_t row_pitch, float* workspace,
+                         uint64_t workspace_floats, int32_t force_split, void* stream);
 /* tuning aid (tools/gemm_bench.py --sweep): force the GEMM row tile (32/64/128) and K-slice count; 0 = automatic */
 int sdvar_debug_set_gemm_cfg(int32_t bm, int32_t split);
 /* diagnostic: per-workgroup s_memtime stamps (4 x u64 per workgroup: entry, main loop start, main loop end, exit) of the

@@ -338,9 +338,7 @@ int sdvar_stage_forward(sdvar_model_t* m, float* x, int32_t s0, int32_t n, float
     const float* ws = P ? splitk_workspace(&wsf) : nullptr;
     PendingSplitK pend{nullptr, nullptr, nullptr, 0, 1, 0};           // unreduced gated residual waiting for the next ln_modulate
     int defer = 0;
-    // the row kernels have one wave per row: only with >= 1024 rows do they have the parallelism to sum slabs as fast as
-    // the dedicated reduce kernel (measured at M = 16: 37 us per LN launch against 5 + 7 us)
-    int* const dp = (M >= 1024) ? &defer : nullptr;
+    int* const dp = &defer;      // every split-K GEMM below leaves its K-slice sum to the row kernel that reads the result next
     for (int i = 0; i < m->d.depth; ++i) {
         const BlockW& b = m->blk[i];
         const float* ada = m->ada + (size_t)i * m->Rmax * 6 * C;      // (R, 6C): gamma1 gamma2 scale1 scale2 shift1 shift2

@@ -1,0 +1,262 @@
+// 3x3 / 1x1 convolution of the VQVAE decoder (models/basic_vae.py:163-226 behind vqvae.py:62-63 fhat_to_img) as an implicit
+// GEMM on the bf16 matrix cores with split operands - the arithmetic contract of gemm_bf16x3.hip (fp32 values held exactly
+// as three bf16 planes, six plane products, fp32 accumulate).
+//
+// Activation layout ("padded pixel rows"): an image batch (B, C, H, W) is stored channel-last with a one-pixel zero frame,
+//     row(b, y, x) = (b (H+2) + y + 1) (W+2) + x + 1,   M = B (H+2) (W+2) rows,
+// fp32 tensors are [M][C]; GEMM operands are K-blocked planes [3][C/32][G + M + G][32] bf16 with G >= W+3 zero guard rows on
+// both ends.  With that layout the A tile of tap (dy, dx) and channel block cb of a 3x3 convolution is the SAME run of
+// rows shifted by dy (W+2) + dx - one contiguous, fully coalesced LDS-DMA per 16 rows, no im2col, no bounds tests (frame
+// pixels are real zeros in the planes; frame rows of the OUTPUT are computed like any other row and ignored downstream).
+// Weights (Cout, Cin, kh, kw) are re-packed once as planes [3][taps Cin / 32][Cout][32] with k = tap Cin + cin.
+//
+// Kernel: 256 x 160 workgroup tile (every decoder width - 160, 320, 640, 1920 - is a multiple of 160), 8 waves, each
+// 32 rows x 160 columns (5 MFMA column tiles: one A fragment feeds 5 x 6 MFMAs), K-step 32, 2-stage LDS-DMA ring of
+// 78 KB, XOR-swizzled 64-byte rows (conflict-free ds_read_b128), hand-placed fragment reads with counted lgkmcnt, the
+// DMA instructions of the next K-step spread between the MFMA groups (as gemm_bf16x3_v3_kernel).
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace sdvar {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+enum { CEPI_BIAS = 0, CEPI_BIAS_RES = 1, CEPI_PARTIAL = 2 };
+constexpr int CBM = 256, CBN = 160;
+constexpr int CSTAGE = 3 * (CBM + CBN) * 32;        // bf16 elements per stage: X planes [3][256][32] then W planes [3][160][32]
+
+struct ConvArgs {
+    const uint16_t* X; const uint16_t* W;          // planes; X rows include the guards
+    size_t xps, wps;                               // plane strides (elements)
+    size_t x_rows;                                 // rows per channel block of X (G + M + G)
+    int x_row0;                                    // G
+    const float* bias; const float* res; float* out;
+    int M, N, cb, taps, w2, ldo, split, k_per_split;   // cb = Cin / 32; K-steps = taps * cb
+};
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void conv_bf16x3_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t csm[];
+    const int tiles_m = (a.M + CBM - 1) / CBM, tiles_n = (a.N + CBN - 1) / CBN, ntile = tiles_m * tiles_n;
+    const int ks = blockIdx.x / ntile;
+    const int lid = xcd_remap(blockIdx.x - ks * ntile, ntile);
+    const int tm = lid / tiles_n, tn = lid - tm * tiles_n;          // the column tiles of one row tile are neighbours: they share the A panel in L2
+    const int m0 = tm * CBM, n0 = tn * CBN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+
+    // DMA: per plane wave w fills X rows [32w, 32w+32) (two 16-row groups) and W rows [16w, 16w+16) (+ [128 + 16w, ..) for w < 2)
+    const int r16 = lane >> 2;
+    const int xr0 = 32 * wave + r16, xr1 = xr0 + 16, wr0 = 16 * wave + r16, wr1 = 128 + wr0;
+    const int cx0 = (lane & 3) ^ ((xr0 >> 2) & 3), cx1 = (lane & 3) ^ ((xr1 >> 2) & 3), cw0 = (lane & 3) ^ ((wr0 >> 2) & 3), cw1 = (lane & 3) ^ ((wr1 >> 2) & 3);
+    const int nkt = a.taps * a.cb;
+    const int kt0 = ks * a.k_per_split;
+    const int nk = min(nkt - kt0, a.k_per_split);
+    const uint16_t* sx0 = a.X + ((size_t)a.x_row0 + min(m0 + xr0, a.M - 1)) * 32 + 8 * cx0;
+    const uint16_t* sx1 = a.X + ((size_t)a.x_row0 + min(m0 + xr1, a.M - 1)) * 32 + 8 * cx1;
+    const uint16_t* sw0 = a.W + (size_t)min(n0 + wr0, a.N - 1) * 32 + 8 * cw0;
+    const uint16_t* sw1 = a.W + (size_t)min(n0 + wr1, a.N - 1) * 32 + 8 * cw1;
+    const bool two_w = wave < 2;
+    // K-step t (global index kt0 + t) = (tap, channel block): X offset = (cblk x_rows + tap shift) rows, W offset = (kt0 + t) N rows
+    long long xoff = 0; size_t woff = 0;
+    auto set_step = [&](int t) {
+        const int kb = kt0 + t, tap = kb / a.cb, c = kb - tap * a.cb;
+        const int shift = (a.taps == 9) ? (tap / 3 - 1) * a.w2 + (tap % 3 - 1) : 0;
+        xoff = ((long long)c * (long long)a.x_rows + shift) * 32;
+        woff = (size_t)kb * a.N * 32;
+    };
+    // DMA instruction q of the current step -> stage st: q in [0, 9): plane q / 3, kind q % 3 (X group 0, X group 1, W group 0); q in [9, 12): W group 1 of plane q - 9
+    auto issue_one = [&](uint16_t* st, int q) {
+        if (q < 9) {
+            const int p = q / 3, kind = q % 3;
+            if (kind == 0) __builtin_amdgcn_global_load_lds((glb_ptr_t)(sx0 + xoff + p * a.xps), (lds_ptr_t)(st + p * 8192 + wave * 1024), 16, 0, 0);
+            else if (kind == 1) __builtin_amdgcn_global_load_lds((glb_ptr_t)(sx1 + xoff + p * a.xps), (lds_ptr_t)(st + p * 8192 + wave * 1024 + 512), 16, 0, 0);
+            else __builtin_amdgcn_global_load_lds((glb_ptr_t)(sw0 + woff + p * a.wps), (lds_ptr_t)(st + 3 * 8192 + p * 5120 + wave * 512), 16, 0, 0);
+        } else if (two_w) {
+            const int p = q - 9;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(sw1 + woff + p * a.wps), (lds_ptr_t)(st + 3 * 8192 + p * 5120 + 4096 + wave * 512), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    const int sw = (li >> 2) & 3;
+    const int offa = (wave * 32 + li) * 32, offb = 3 * 8192 + li * 32;       // element offsets inside a stage
+    const int ch0 = 8 * ((0 + lh) ^ sw), ch1 = 8 * ((2 + lh) ^ sw);
+
+    set_step(0);
+#pragma unroll
+    for (int q = 0; q < 12; ++q) issue_one(csm, q);
+    for (int t = 0; t < nk; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const bool pf = t + 1 < nk;
+        if (pf) set_step(t + 1);
+        uint16_t* nst = csm + ((t + 1) & 1) * CSTAGE;
+        const uint32_t sb = (uint32_t)(uintptr_t)(lds_ptr_t)(csm + (t & 1) * CSTAGE);
+        const uint32_t aa0 = sb + 2 * (offa + ch0), aa1 = sb + 2 * (offa + ch1), ab0 = sb + 2 * (offb + ch0), ab1 = sb + 2 * (offb + ch1);
+        bf16x8 fa[2][3], fb[2][3][5];
+#define SDVAR_LDS_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr) : "memory")
+        // X plane p at +16384 p bytes; W plane p at +10240 p bytes, column tile j at +2048 j
+#define SDVAR_RD_B(s, ab, p, pb) SDVAR_LDS_RD(fb[s][p][0], ab, pb); SDVAR_LDS_RD(fb[s][p][1], ab, pb + 2048); SDVAR_LDS_RD(fb[s][p][2], ab, pb + 4096); \
+                                 SDVAR_LDS_RD(fb[s][p][3], ab, pb + 6144); SDVAR_LDS_RD(fb[s][p][4], ab, pb + 8192)
+        // sub-step 0: 18 reads, then the first 12 of sub-step 1 (lgkmcnt is a 4-bit counter: at most 15 may be waited on)
+        SDVAR_LDS_RD(fa[0][0], aa0, 0); SDVAR_LDS_RD(fa[0][1], aa0, 16384); SDVAR_LDS_RD(fa[0][2], aa0, 32768);
+        SDVAR_RD_B(0, ab0, 2, 20480); SDVAR_RD_B(0, ab0, 1, 10240); SDVAR_RD_B(0, ab0, 0, 0);
+        SDVAR_LDS_RD(fa[1][0], aa1, 0); SDVAR_LDS_RD(fa[1][1], aa1, 16384); SDVAR_LDS_RD(fa[1][2], aa1, 32768);
+        SDVAR_RD_B(1, ab1, 2, 20480);
+        SDVAR_LDS_RD(fb[1][1][0], ab1, 10240); SDVAR_LDS_RD(fb[1][1][1], ab1, 12288); SDVAR_LDS_RD(fb[1][1][2], ab1, 14336); SDVAR_LDS_RD(fb[1][1][3], ab1, 16384);
+        asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                if (s == 1 && j == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][0], fb[s][2][j], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][1], fb[s][1][j], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][2], fb[s][0][j], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][0], fb[s][1][j], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][1], fb[s][0][j], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][0], fb[s][0][j], acc[j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (s == 0 && j == 0) {          // the last 6 fragment reads of sub-step 1, behind the first MFMA group
+                    SDVAR_LDS_RD(fb[1][1][4], ab1, 18432);
+                    SDVAR_RD_B(1, ab1, 0, 0);
+                }
+                if (pf) {
+                    const int grp = 5 * s + j;      // 0..9: 12 DMA instructions of K-step t+1
+                    issue_one(nst, grp);
+                    if (grp >= 8) issue_one(nst, grp + 2);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#undef SDVAR_RD_B
+#undef SDVAR_LDS_RD
+    }
+
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int n = n0 + j * 32 + li;
+        if (n >= a.N) continue;
+        const float bv = (EPI != CEPI_PARTIAL && a.bias) ? a.bias[n] : 0.f;
+        float* outp = (EPI == CEPI_PARTIAL) ? a.out + (size_t)ks * a.M * a.ldo : a.out;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (m >= a.M) continue;
+            float v = acc[j][r] + bv;
+            if (EPI == CEPI_BIAS_RES) v += a.res[(size_t)m * a.ldo + n];
+            outp[(size_t)m * a.ldo + n] = v;
+        }
+    }
+}
+
+// out = sum_s slab[s] + bias (+ res)
+__global__ __launch_bounds__(256) void conv_reduce_kernel(const float* __restrict__ ws, int split, const float* __restrict__ bias, const float* res,
+                                                          float* out, int M, int N) {
+    const int nv = N >> 2;
+    const size_t total = (size_t)M * nv, slab = (size_t)M * N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i % nv) * 4;
+        f32x4 acc = *reinterpret_cast<const f32x4*>(ws + 4 * i);
+        for (int s = 1; s < split; ++s) {
+            const f32x4 p = *reinterpret_cast<const f32x4*>(ws + s * slab + 4 * i);
+            acc[0] += p[0]; acc[1] += p[1]; acc[2] += p[2]; acc[3] += p[3];
+        }
+        if (bias) { const f32x4 b = *reinterpret_cast<const f32x4*>(bias + n); acc[0] += b[0]; acc[1] += b[1]; acc[2] += b[2]; acc[3] += b[3]; }
+        if (res) { const f32x4 r = *reinterpret_cast<const f32x4*>(res + 4 * i); acc[0] += r[0]; acc[1] += r[1]; acc[2] += r[2]; acc[3] += r[3]; }
+        *reinterpret_cast<f32x4*>(out + 4 * i) = acc;
+    }
+}
+
+// conv weight (Cout, Cin, taps) fp32 -> planes [3][taps Cin / 32][Cout][32], k = tap Cin + cin
+__global__ __launch_bounds__(256) void conv_weight_planes_kernel(const float* __restrict__ w, uint16_t* __restrict__ p, int Cout, int Cin, int taps, size_t ps) {
+    const int K = taps * Cin;
+    const size_t total = (size_t)Cout * K;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i / K), k = (int)(i % K), tap = k / Cin, ci = k - tap * Cin;
+        uint16_t p0, p1, p2;
+        split3(w[((size_t)co * Cin + ci) * taps + tap], p0, p1, p2);
+        const size_t o = kb_index(co, k, Cout);
+        p[o] = p0; p[ps + o] = p1; p[2 * ps + o] = p2;
+    }
+}
+
+int conv_weight_planes(const float* w, uint16_t* planes, int Cout, int Cin, int taps, size_t plane_stride, hipStream_t stream) {
+    SDVAR_CHECK_ARG(w && planes && Cout > 0 && Cin % 32 == 0 && (taps == 1 || taps == 9), "conv_weight_planes: Cout=%d Cin=%d taps=%d", Cout, Cin, taps);
+    hipLaunchKernelGGL(conv_weight_planes_kernel, dim3(1024), dim3(256), 0, stream, w, planes, Cout, Cin, taps, plane_stride);
+    SDVAR_LAUNCH_CHECK();
+    return SDVAR_OK;
+}
+
+// split heuristic: fill the 256 CUs (one resident workgroup each) without leaving a mostly empty last round
+static int conv_choose_split(int M, int N, int nkt, size_t ws_floats) {
+    const long tiles = (long)((M + CBM - 1) / CBM) * ((N + CBN - 1) / CBN);
+    double best = 1e30; int bs = 1;
+    for (int split = 1; split <= 16 && split <= nkt / 2; ++split) {
+        if (split > 1 && ((size_t)split * M * N > ws_floats || N % 4)) break;
+        const int kps = (nkt + split - 1) / split;
+        if ((nkt + kps - 1) / kps != split) continue;
+        const long rounds = (tiles * split + 255) / 256;
+        double cyc = (double)rounds * (kps * 2100.0 + 3000.0);               // 60 MFMAs per wave and K-step, 2 waves per SIMD + DMA/sync; prologue + epilogue
+        if (split > 1) cyc += 4000.0 + (double)(split + 2) * M * N * 4.0 / 4000.0;
+        if (cyc < best) { best = cyc; bs = split; }
+    }
+    return bs;
+}
+
+// out[M][N] = conv(X planes, W planes) + bias (+ res[M][N]).  taps = 9: 3x3 with row pitch w2 = W + 2; taps = 1: 1x1 (plain GEMM).
+int conv_bf16x3(const uint16_t* X, size_t xps, size_t x_rows, int x_row0, const uint16_t* W, size_t wps, const float* bias, const float* res, float* out,
+                int M, int N, int Cin, int taps, int w2, float* ws, size_t ws_floats, int force_split, hipStream_t stream) {
+    SDVAR_CHECK_ARG(X && W && out, "conv: null operand");
+    SDVAR_CHECK_ARG(M > 0 && N > 0 && Cin > 0 && Cin % 32 == 0 && (taps == 1 || taps == 9), "conv: M=%d N=%d Cin=%d taps=%d", M, N, Cin, taps);
+    SDVAR_CHECK_ARG(taps == 1 || (w2 >= 3 && x_row0 >= w2 + 1), "conv: guard rows %d < row pitch %d + 1", x_row0, w2);
+    SDVAR_CHECK_ARG(x_rows >= (size_t)x_row0 + (size_t)M + (taps == 9 ? w2 + 1 : 0), "conv: plane rows %zu too few", x_rows);
+    SDVAR_CHECK_ARG(((uintptr_t)X % 16) == 0 && ((uintptr_t)W % 16) == 0 && xps % 8 == 0 && wps % 8 == 0, "conv: planes must be 16-byte aligned");
+    ConvArgs a{X, W, xps, wps, x_rows, x_row0, bias, res, out, M, N, Cin / 32, taps, w2, N, 1, taps * (Cin / 32)};
+    const int nkt = taps * (Cin / 32);
+    const int tiles = ((M + CBM - 1) / CBM) * ((N + CBN - 1) / CBN);
+    int split = force_split > 0 ? force_split : conv_choose_split(M, N, nkt, ws ? ws_floats : 0);
+    if (split > nkt) split = nkt;
+    if (split > 1) {
+        SDVAR_CHECK_ARG(ws && (size_t)split * M * N <= ws_floats && N % 4 == 0, "conv: split-K workspace too small");
+        const int kps = (nkt + split - 1) / split;
+        split = (nkt + kps - 1) / kps;
+        a.k_per_split = kps; a.split = split;
+    }
+    const size_t lds = 2 * (size_t)CSTAGE * sizeof(uint16_t);      // 156 KB
+    static bool attr_set = false;
+    if (!attr_set) {
+        SDVAR_HIP(hipFuncSetAttribute((const void*)conv_bf16x3_kernel<CEPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SDVAR_HIP(hipFuncSetAttribute((const void*)conv_bf16x3_kernel<CEPI_BIAS_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SDVAR_HIP(hipFuncSetAttribute((const void*)conv_bf16x3_kernel<CEPI_PARTIAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    if (split > 1) {
+        ConvArgs p = a;
+        p.out = ws;
+        hipLaunchKernelGGL((conv_bf16x3_kernel<CEPI_PARTIAL>), dim3(tiles * split), dim3(512), lds, stream, p);
+        SDVAR_LAUNCH_CHECK();
+        const size_t total = (size_t)M * (N / 4);
+        const int rgrid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        hipLaunchKernelGGL(conv_reduce_kernel, dim3(rgrid), dim3(256), 0, stream, ws, split, bias, res, out, M, N);
+        SDVAR_LAUNCH_CHECK();
+        return SDVAR_OK;
+    }
+    if (res) hipLaunchKernelGGL((conv_bf16x3_kernel<CEPI_BIAS_RES>), dim3(tiles), dim3(512), lds, stream, a);
+    else hipLaunchKernelGGL((conv_bf16x3_kernel<CEPI_BIAS>), dim3(tiles), dim3(512), lds, stream, a);
+    SDVAR_LAUNCH_CHECK();
+    return SDVAR_OK;
+}
+
+}  // namespace sdvar

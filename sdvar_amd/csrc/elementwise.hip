@@ -27,36 +27,15 @@ struct PendingSplitK {
 // x (rows, C) ; scale/shift: row r of the CFG batch = row / rows_per_img, element stride `mod_stride` between r's.
 constexpr int LN_MAX_V4 = 8;   // up to C = 64 lanes * 8 * 4 = 2048
 
-__global__ __launch_bounds__(256) void ln_modulate_kernel(float* __restrict__ x, const float* __restrict__ scale,
-                                                          const float* __restrict__ shift, float* __restrict__ out, uint16_t* __restrict__ outp,
-                                                          size_t ops, int rows, int C, int rows_per_img, int mod_stride, float eps, PendingSplitK pend) {
-    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+// LayerNorm + modulation of one row held by one wave (v[i] = float4 number lane + 64 i of the row)
+__device__ __forceinline__ void ln_row_finish(const f32x4* v, int lane, int row, const float* __restrict__ scale, const float* __restrict__ shift,
+                                              float* __restrict__ out, uint16_t* __restrict__ outp, size_t ops, int rows, int C, int rows_per_img,
+                                              int mod_stride, float eps) {
     const int nv = C >> 2;
-    f32x4* px = reinterpret_cast<f32x4*>(x + (size_t)row * C);
-    f32x4 v[LN_MAX_V4];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAX_V4; ++i) {
-        const int idx = lane + 64 * i;
-        if (idx < nv) {
-            v[i] = px[idx];
-            if (pend.ws) {          // finish the previous block's gated residual: x += (sum of K-slice slabs + bias) * gate, written back
-                const size_t slab = (size_t)rows * C, o = (size_t)row * C + 4 * idx;
-                f32x4 acc = *reinterpret_cast<const f32x4*>(pend.ws + o);
-                for (int k = 1; k < pend.split; ++k) {
-                    const f32x4 p = *reinterpret_cast<const f32x4*>(pend.ws + k * slab + o);
-                    acc[0] += p[0]; acc[1] += p[1]; acc[2] += p[2]; acc[3] += p[3];
-                }
-                const f32x4 bb = *reinterpret_cast<const f32x4*>(pend.bias + 4 * idx);
-                const f32x4 gg = *reinterpret_cast<const f32x4*>(pend.gate + (size_t)(row / pend.rows_per_gate) * pend.gate_stride + 4 * idx);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[i][e] = v[i][e] + (acc[e] + bb[e]) * gg[e];
-                px[idx] = v[i];
-            }
-            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-        }
-    }
+    for (int i = 0; i < LN_MAX_V4; ++i)
+        if (lane + 64 * i < nv) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     const float mean = wave_sum(s) / (float)C;
     float ss = 0.f;
 #pragma unroll
@@ -97,6 +76,67 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(float* __restrict__ x,
     }
 }
 
+// x[row] += (sum of K-slice slabs + bias) * gate for float4 number idx of the row (slabs summed in slice order); returns the new value
+__device__ __forceinline__ f32x4 pending_residual(const PendingSplitK& pend, f32x4 xv, int row, int idx, int rows, int C) {
+    const size_t slab = (size_t)rows * C, o = (size_t)row * C + 4 * idx;
+    f32x4 acc = *reinterpret_cast<const f32x4*>(pend.ws + o);
+    for (int k = 1; k < pend.split; ++k) {
+        const f32x4 p = *reinterpret_cast<const f32x4*>(pend.ws + k * slab + o);
+        acc[0] += p[0]; acc[1] += p[1]; acc[2] += p[2]; acc[3] += p[3];
+    }
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(pend.bias + 4 * idx);
+    const f32x4 gg = *reinterpret_cast<const f32x4*>(pend.gate + (size_t)(row / pend.rows_per_gate) * pend.gate_stride + 4 * idx);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) xv[e] = xv[e] + (acc[e] + bb[e]) * gg[e];
+    return xv;
+}
+
+__global__ __launch_bounds__(256) void ln_modulate_kernel(float* __restrict__ x, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, float* __restrict__ out, uint16_t* __restrict__ outp,
+                                                          size_t ops, int rows, int C, int rows_per_img, int mod_stride, float eps, PendingSplitK pend) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = C >> 2;
+    f32x4* px = reinterpret_cast<f32x4*>(x + (size_t)row * C);
+    f32x4 v[LN_MAX_V4];
+#pragma unroll
+    for (int i = 0; i < LN_MAX_V4; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < nv) {
+            v[i] = px[idx];
+            if (pend.ws) {          // finish the previous block's gated residual, written back
+                v[i] = pending_residual(pend, v[i], row, idx, rows, C);
+                px[idx] = v[i];
+            }
+        }
+    }
+    ln_row_finish(v, lane, row, scale, shift, out, outp, ops, rows, C, rows_per_img, mod_stride, eps);
+}
+
+// Same result bit for bit, one WORKGROUP per row, for a pending split-K residual at small row counts: with one wave per row
+// a 16-row stage has 16 waves on the whole chip summing up to 32 slabs each (37 us measured); here 256 threads share the
+// slab sum of one row (phase 1, through LDS) and wave 0 then normalises it exactly as above.
+__global__ __launch_bounds__(256) void ln_modulate_row_kernel(float* __restrict__ x, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, float* __restrict__ out, uint16_t* __restrict__ outp,
+                                                              size_t ops, int rows, int C, int rows_per_img, int mod_stride, float eps, PendingSplitK pend) {
+    __shared__ f32x4 vsm[64 * LN_MAX_V4];
+    const int tid = threadIdx.x, row = blockIdx.x;
+    const int nv = C >> 2;
+    f32x4* px = reinterpret_cast<f32x4*>(x + (size_t)row * C);
+    for (int idx = tid; idx < nv; idx += 256) {
+        const f32x4 nvv = pending_residual(pend, px[idx], row, idx, rows, C);
+        px[idx] = nvv;
+        vsm[idx] = nvv;
+    }
+    __syncthreads();
+    if (tid >= 64) return;
+    f32x4 v[LN_MAX_V4];
+#pragma unroll
+    for (int i = 0; i < LN_MAX_V4; ++i)
+        if (tid + 64 * i < nv) v[i] = vsm[tid + 64 * i];
+    ln_row_finish(v, tid, row, scale, shift, out, outp, ops, rows, C, rows_per_img, mod_stride, eps);
+}
+
 int ln_modulate(float* x, const float* scale, const float* shift, float* out, uint16_t* outp, size_t ops, int rows, int C, int rows_per_img,
                 int mod_stride, const PendingSplitK* pend, hipStream_t stream) {
     PendingSplitK pd{nullptr, nullptr, nullptr, 0, 1, 0};
@@ -106,7 +146,8 @@ int ln_modulate(float* x, const float* scale, const float* shift, float* out, ui
     }
     SDVAR_CHECK_ARG(C % 4 == 0 && C <= 64 * 4 * LN_MAX_V4 && rows > 0 && rows_per_img > 0, "ln_modulate: bad shape rows=%d C=%d", rows, C);
     SDVAR_CHECK_ARG(mod_stride % 4 == 0, "ln_modulate: mod_stride must be a multiple of 4");
-    hipLaunchKernelGGL(ln_modulate_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, scale, shift, out, outp, ops, rows, C, rows_per_img, mod_stride, 1e-6f, pd);
+    if (pd.ws && rows < 1024) hipLaunchKernelGGL(ln_modulate_row_kernel, dim3(rows), dim3(256), 0, stream, x, scale, shift, out, outp, ops, rows, C, rows_per_img, mod_stride, 1e-6f, pd);
+    else hipLaunchKernelGGL(ln_modulate_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, scale, shift, out, outp, ops, rows, C, rows_per_img, mod_stride, 1e-6f, pd);
     SDVAR_LAUNCH_CHECK();
     return SDVAR_OK;
 }

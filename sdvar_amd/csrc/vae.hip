@@ -1,0 +1,567 @@
+// VQVAE decoder f_hat -> image (the caller side of the sampler: vae.fhat_to_img at /root/reference/models/vqvae.py:62-63,
+// Decoder at models/basic_vae.py:163-226, ResnetBlock :47-73, AttnBlock :76-103, Upsample2x :24-30) as one C-ABI call.
+//
+// Everything between the convolutions works on the "padded pixel rows" layout of conv.hip: fp32 activations [M][C] with
+// M = B (H+2) (W+2), GEMM operands as K-blocked bf16x3 planes with zero frame and guard rows.  Per layer:
+//     GroupNorm statistics      gn_partial_kernel + gn_finalize_kernel  (fp32 partial sums per thread, fp64 across threads)
+//     GN * gamma + beta, SiLU, optional nearest 2x up-sampling, exact split into planes      prep_planes_kernel (one pass)
+//     3x3 / 1x1 convolution + bias (+ residual)                                              conv.hip
+//     single-head attention over the H W tokens of the 16x16 levels                          vae_attn_kernel
+//     norm_out + SiLU + conv_out (160 -> 3) + clamp                                          convout_partial / convout_gather
+// All kernels here are HBM-bound row kernels (16-byte accesses, channel-last rows are contiguous).
+#include <math.h>
+
+#include <vector>
+
+#include "../../include/sdvar_hip.h"
+#include "common.h"
+
+namespace sdvar {
+
+int conv_weight_planes(const float* w, uint16_t* planes, int Cout, int Cin, int taps, size_t plane_stride, hipStream_t stream);
+int conv_bf16x3(const uint16_t* X, size_t xps, size_t x_rows, int x_row0, const uint16_t* W, size_t wps, const float* bias, const float* res, float* out,
+                int M, int N, int Cin, int taps, int w2, float* ws, size_t ws_floats, int force_split, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------------- layout helpers
+// (B, C, H, W) fp32 -> padded pixel rows [M][C] (frame rows zero)
+__global__ __launch_bounds__(256) void rows_from_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C, int H, int W) {
+    const int w2 = W + 2, h2 = H + 2;
+    const size_t total = (size_t)B * h2 * w2 * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const size_t row = i / C;
+        const int x = (int)(row % w2) - 1, y = (int)((row / w2) % h2) - 1, b = (int)(row / ((size_t)w2 * h2));
+        out[i] = (x >= 0 && x < W && y >= 0 && y < H) ? in[(((size_t)b * C + c) * H + y) * W + x] : 0.f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------- GroupNorm statistics
+// 32 groups, eps 1e-6 (basic_vae.py:20).  Grid (chunks, B), 320 threads: thread = (pixel lane, channel quad); requires (C/4) | 320.
+__global__ __launch_bounds__(320) void gn_partial_kernel(const float* __restrict__ x, double* __restrict__ part, int C, int H, int W, int rows_per_chunk) {
+    __shared__ float sm[2 * 8 * 640];            // [sum | sumsq][pixel lane][channel]  (C <= 640 at 2 lanes ... C = 160 at 8 lanes: lanes * C <= 1280)
+    const int b = blockIdx.y, chunk = blockIdx.x, nq = C >> 2, npl = 320 / nq;
+    const int q = threadIdx.x % nq, pl = threadIdx.x / nq;
+    const int w2 = W + 2;
+    const int y0 = chunk * rows_per_chunk, y1 = min(H, y0 + rows_per_chunk);
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {0.f, 0.f, 0.f, 0.f};
+    const int npix = (y1 - y0) * W;
+    for (int p = pl; p < npix; p += npl) {
+        const int y = y0 + p / W, xx = p % W;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((size_t)(b * (H + 2) + y + 1) * w2 + xx + 1) * C + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s[e] += v[e]; ss[e] += v[e] * v[e]; }
+    }
+    const int NL = npl * C;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { sm[pl * C + 4 * q + e] = s[e]; sm[NL + pl * C + 4 * q + e] = ss[e]; }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int g = threadIdx.x, cpg = C / 32;
+        double a = 0.0, a2 = 0.0;
+        for (int l = 0; l < npl; ++l)
+            for (int c = g * cpg; c < (g + 1) * cpg; ++c) { a += (double)sm[l * C + c]; a2 += (double)sm[NL + l * C + c]; }
+        double* o = part + (((size_t)b * gridDim.x + chunk) * 32 + g) * 2;
+        o[0] = a; o[1] = a2;
+    }
+}
+
+__global__ void gn_finalize_kernel(const double* __restrict__ part, float* __restrict__ stats, int nchunk, double count, double eps) {
+    const int b = blockIdx.x, g = threadIdx.x;      // 32 threads
+    double a = 0.0, a2 = 0.0;
+    for (int c = 0; c < nchunk; ++c) { const double* p = part + (((size_t)b * nchunk + c) * 32 + g) * 2; a += p[0]; a2 += p[1]; }
+    const double mean = a / count, var = fmax(a2 / count - mean * mean, 0.0);
+    stats[((size_t)b * 32 + g) * 2] = (float)mean;
+    stats[((size_t)b * 32 + g) * 2 + 1] = (float)(1.0 / sqrt(var + eps));
+}
+
+// ---------------------------------------------------------------------------------------------------- planes producer
+// in: fp32 padded rows of a (B, C, Hi, Wi) tensor.  out: planes [3][C/32][G + M_out + G][32] of the (B, C, Ho, Wo) tensor,
+// Ho = Hi << up.  mode bit 0: GroupNorm (stats, gamma, beta); bit 1: SiLU.  Thread = (output row incl. guards, 8 channels).
+__global__ __launch_bounds__(256) void prep_planes_kernel(const float* __restrict__ in, const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, uint16_t* __restrict__ outp, size_t ops, int B, int C, int Hi, int Wi,
+                                                          int up, int mode, int G) {
+    const int Ho = Hi << up, Wo = Wi << up, w2o = Wo + 2, h2o = Ho + 2, w2i = Wi + 2;
+    const size_t Mo = (size_t)B * h2o * w2o, R = Mo + 2 * (size_t)G;
+    const int c8n = C >> 3, cpg = C / 32;
+    const size_t total = R * c8n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % c8n);
+        const size_t r = i / c8n;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        bool live = false;
+        if (r >= (size_t)G && r < (size_t)G + Mo) {
+            const size_t row = r - G;
+            const int x = (int)(row % w2o) - 1, y = (int)((row / w2o) % h2o) - 1, b = (int)(row / ((size_t)w2o * h2o));
+            if (x >= 0 && x < Wo && y >= 0 && y < Ho) {
+                live = true;
+                const float* p = in + (((size_t)b * (Hi + 2) + (y >> up) + 1) * w2i + (x >> up) + 1) * C + 8 * c8;
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(p), a1 = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = a0[e]; v[4 + e] = a1[e]; }
+                if (mode & 1) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int c = 8 * c8 + e, g = c / cpg;
+                        const float mean = stats[((size_t)b * 32 + g) * 2], rstd = stats[((size_t)b * 32 + g) * 2 + 1];
+                        v[e] = ((v[e] - mean) * rstd) * gamma[c] + beta[c];
+                    }
+                }
+                if (mode & 2) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = v[e] / (1.0f + expf(-v[e]));
+                }
+            }
+        }
+        u32x4 a = {0, 0, 0, 0}, bq = {0, 0, 0, 0}, cq = {0, 0, 0, 0};
+        if (live) split8_packed(v, a, bq, cq);
+        const size_t o = ((size_t)(c8 >> 2) * R + r) * 32 + 8 * (c8 & 3);
+        *reinterpret_cast<u32x4*>(outp + o) = a; *reinterpret_cast<u32x4*>(outp + ops + o) = bq; *reinterpret_cast<u32x4*>(outp + 2 * ops + o) = cq;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------- AttnBlock core
+// qkv: padded rows [M][3C] (q | k | v), N = H W tokens per image.  out: padded rows [M][C] (frame rows zero):
+//     out[i] = sum_j softmax_j(q_i . k_j / sqrt(C)) v_j                         basic_vae.py:92-101
+// Workgroup = 16 queries of one image, 256 threads.  Scores: thread = key (N <= 256 per pass), q broadcast from LDS;
+// output: thread = channel (C <= 768), probabilities broadcast from LDS.
+constexpr int VA_QT = 16;
+__global__ __launch_bounds__(256) void vae_attn_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) float vsm[];
+    const int N = H * W, w2 = W + 2;
+    float* qs = vsm;                 // [VA_QT][C]
+    float* ps = vsm + VA_QT * C;     // [VA_QT][N]
+    const int b = blockIdx.y, q0 = blockIdx.x * VA_QT, tid = threadIdx.x;
+    auto row_of = [&](int tok) { return ((size_t)b * (H + 2) + tok / W + 1) * w2 + tok % W + 1; };
+    const float scale = 1.0f / sqrtf((float)C);
+    for (int i = tid; i < VA_QT * C; i += 256) {
+        const int qi = i / C, c = i - qi * C;
+        qs[i] = (q0 + qi < N) ? qkv[row_of(q0 + qi) * 3 * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = tid; j < N; j += 256) {
+        const float* kp = qkv + row_of(j) * 3 * C + C;
+        float acc[VA_QT];
+#pragma unroll
+        for (int qi = 0; qi < VA_QT; ++qi) acc[qi] = 0.f;
+        for (int c = 0; c < C; c += 4) {
+            const f32x4 kv = *reinterpret_cast<const f32x4*>(kp + c);
+#pragma unroll
+            for (int qi = 0; qi < VA_QT; ++qi) {
+                const f32x4 qv = *reinterpret_cast<const f32x4*>(qs + qi * C + c);
+                acc[qi] += (qv[0] * kv[0] + qv[1] * kv[1]) + (qv[2] * kv[2] + qv[3] * kv[3]);
+            }
+        }
+#pragma unroll
+        for (int qi = 0; qi < VA_QT; ++qi) ps[qi * N + j] = acc[qi] * scale;
+    }
+    __syncthreads();
+    {   // softmax rows: wave w owns queries 4w .. 4w+3
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int qi = 4 * wave; qi < 4 * wave + 4; ++qi) {
+            float m = -INFINITY;
+            for (int j = lane; j < N; j += 64) m = fmaxf(m, ps[qi * N + j]);
+            m = wave_max(m);
+            float s = 0.f;
+            for (int j = lane; j < N; j += 64) { const float e = expf(ps[qi * N + j] - m); ps[qi * N + j] = e; s += e; }
+            s = wave_sum(s);
+            const float inv = 1.0f / s;
+            for (int j = lane; j < N; j += 64) ps[qi * N + j] *= inv;
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float acc[VA_QT];
+#pragma unroll
+        for (int qi = 0; qi < VA_QT; ++qi) acc[qi] = 0.f;
+        for (int j = 0; j < N; ++j) {
+            const float v = qkv[row_of(j) * 3 * C + 2 * C + c];
+#pragma unroll
+            for (int qi = 0; qi < VA_QT; ++qi) acc[qi] += ps[qi * N + j] * v;
+        }
+#pragma unroll
+        for (int qi = 0; qi < VA_QT; ++qi) if (q0 + qi < N) out[row_of(q0 + qi) * C + c] = acc[qi];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------- conv_out
+// y = conv3x3(silu(GN(x)), w (3, C, 3, 3)) + b, clamped to [-1, 1] (vqvae.py:63).  Pass 1: t[row][tap*3 + o] = sum_c act[row][c] w[o][c][tap]
+// (thread = padded row, activations staged through LDS in 32-channel slabs, weights are wave-uniform scalar loads);
+// pass 2: out[b][o][y][x] = b[o] + sum_tap t[row + shift(tap)][tap*3 + o].
+__global__ __launch_bounds__(256) void convout_partial_kernel(const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, const float* __restrict__ wt /* [C][28]: k = tap*3+o */,
+                                                              float* __restrict__ t, int B, int C, int H, int W) {
+    __shared__ float tile[256 * 33];
+    const int w2 = W + 2, h2 = H + 2, cpg = C / 32;
+    const size_t M = (size_t)B * h2 * w2;
+    const size_t r0 = (size_t)blockIdx.x * 256;
+    const int tid = threadIdx.x;
+    const size_t row = r0 + tid;
+    bool live = false; int b = 0;
+    if (row < M) {
+        const int xx = (int)(row % w2) - 1, y = (int)((row / w2) % h2) - 1;
+        b = (int)(row / ((size_t)w2 * h2));
+        live = xx >= 0 && xx < W && y >= 0 && y < H;
+    }
+    float acc[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) acc[k] = 0.f;
+    for (int c0 = 0; c0 < C; c0 += 32) {
+        __syncthreads();
+        // coalesced load of rows r0 .. r0+255, channels c0 .. c0+31: thread -> (row = i / 8, 4 channels)
+        for (int i = tid; i < 256 * 8; i += 256) {
+            const int rr = i >> 3, cq = (i & 7) * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (r0 + rr < M) v = *reinterpret_cast<const f32x4*>(x + (r0 + rr) * C + c0 + cq);
+            tile[rr * 33 + cq] = v[0]; tile[rr * 33 + cq + 1] = v[1]; tile[rr * 33 + cq + 2] = v[2]; tile[rr * 33 + cq + 3] = v[3];
+        }
+        __syncthreads();
+        if (live) {
+            for (int cc = 0; cc < 32; ++cc) {
+                const int c = c0 + cc, g = c / cpg;
+                const float mean = stats[((size_t)b * 32 + g) * 2], rstd = stats[((size_t)b * 32 + g) * 2 + 1];
+                float v = ((tile[tid * 33 + cc] - mean) * rstd) * gamma[c] + beta[c];
+                v = v / (1.0f + expf(-v));
+                const float* w = wt + (size_t)c * 28;
+#pragma unroll
+                for (int k = 0; k < 27; ++k) acc[k] += v * w[k];
+            }
+        }
+    }
+    if (row < M) {
+#pragma unroll
+        for (int k = 0; k < 27; ++k) t[row * 28 + k] = acc[k];
+    }
+}
+
+__global__ __launch_bounds__(256) void convout_gather_kernel(const float* __restrict__ t, const float* __restrict__ bias, float* __restrict__ img, int B, int H, int W) {
+    const int w2 = W + 2;
+    const size_t total = (size_t)B * 3 * H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W), y = (int)((i / W) % H), o = (int)((i / ((size_t)W * H)) % 3), b = (int)(i / ((size_t)3 * W * H));
+        const size_t row = ((size_t)b * (H + 2) + y + 1) * w2 + x + 1;
+        float acc = bias[o];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) acc += t[(size_t)((long long)row + (tap / 3 - 1) * w2 + (tap % 3 - 1)) * 28 + tap * 3 + o];
+        img[i] = fminf(fmaxf(acc, -1.0f), 1.0f);
+    }
+}
+
+// conv_out weight (3, C, 3, 3) -> [C][28] with k = tap * 3 + o
+__global__ void convout_weight_kernel(const float* __restrict__ w, float* __restrict__ wt, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * 28) return;
+    const int c = i / 28, k = i % 28;
+    wt[i] = (k < 27) ? w[((size_t)(k % 3) * C + c) * 9 + k / 3] : 0.f;
+}
+
+}  // namespace sdvar
+
+using namespace sdvar;
+
+// ======================================================================================================== decoder object
+namespace {
+
+template <typename T>
+int vmalloc(T** p, size_t n) {
+    *p = nullptr;
+    SDVAR_HIP(hipMalloc((void**)p, n * sizeof(T)));
+    return SDVAR_OK;
+}
+#define VAE_TRY(call) do { int rc_ = (call); if (rc_ != SDVAR_OK) return rc_; } while (0)
+
+struct ConvW { uint16_t* wp = nullptr; size_t wps = 0; const float* bias = nullptr; int cin = 0, cout = 0, taps = 0; };
+struct NormW { const float* gamma = nullptr; const float* beta = nullptr; int C = 0; };
+struct ResW { NormW n1, n2; ConvW c1, c2, sc; bool has_sc = false; };
+struct AttnW { NormW n; ConvW qkv, proj; };
+struct Level { std::vector<ResW> blocks; std::vector<AttnW> attns; ConvW up; bool has_up = false; };
+
+}  // namespace
+
+struct sdvar_vae {
+    sdvar_vae_desc d;
+    int nlev, H0;
+    ConvW post_quant, conv_in;
+    ResW mid1, mid2; AttnW mid_attn;
+    std::vector<Level> levels;            // in execution order (deepest first)
+    NormW norm_out; float* wt_out = nullptr; const float* b_out = nullptr; int c_out = 0;
+    bool bound = false;
+    // workspaces
+    float *fa = nullptr, *fb = nullptr, *fc = nullptr, *t27 = nullptr, *ws = nullptr, *stats = nullptr;
+    double* part = nullptr;
+    uint16_t *p1 = nullptr, *p2 = nullptr;
+    size_t f_floats = 0, p1_elems = 0, p2_elems = 0, ws_floats = 0;
+    std::vector<void*> owned;
+};
+
+static int guard_rows(int W) { return (W + 3 + 15) / 16 * 16; }
+
+// planes of a (B, C, H, W) tensor: elements per plane and rows per channel block
+static size_t plane_rows(int B, int H, int W) { return (size_t)B * (H + 2) * (W + 2) + 2 * (size_t)guard_rows(W); }
+
+extern "C" {
+
+int sdvar_vae_create(const sdvar_vae_desc* desc, sdvar_vae_t** out) {
+    SDVAR_CHECK_ARG(desc && out, "vae_create: null argument");
+    SDVAR_CHECK_ARG(desc->n_mult >= 1 && desc->n_mult <= 8 && desc->num_res_blocks >= 1 && desc->max_batch >= 1 && desc->latent_hw >= 1, "vae_create: bad descriptor");
+    SDVAR_CHECK_ARG(desc->z_channels % 32 == 0 && desc->ch % 32 == 0, "vae_create: channel counts must be multiples of 32 (ch=%d z=%d)", desc->ch, desc->z_channels);
+    for (int i = 0; i < desc->n_mult; ++i) {
+        const int c = desc->ch * desc->ch_mult[i];
+        SDVAR_CHECK_ARG(c <= 640 * 2 && 320 % (c / 4) == 0, "vae_create: width %d unsupported by the GroupNorm kernel ((C/4) must divide 320)", c);
+    }
+    sdvar_vae* v = new sdvar_vae();
+    v->d = *desc; v->nlev = desc->n_mult; v->H0 = desc->latent_hw;
+    const int B = desc->max_batch;
+    // largest fp32 activation / plane tensors over the levels (level lv runs at H0 << (nlev-1-lv) with width ch*mult[lv]; the
+    // first block of a level and the up-sampling conv see the previous level's width)
+    size_t fmax_ = 0, pmax = 0;
+    int cprev = desc->ch * desc->ch_mult[desc->n_mult - 1];
+    for (int lv = desc->n_mult - 1; lv >= 0; --lv) {
+        const int H = v->H0 << (desc->n_mult - 1 - lv), c = desc->ch * desc->ch_mult[lv];
+        const int cm = c > cprev ? c : cprev;
+        const size_t M = (size_t)B * (H + 2) * (H + 2);
+        const size_t cf = (lv == desc->n_mult - 1) ? (size_t)3 * cm : (size_t)cm;       // qkv rows at the attention level
+        if (M * cf > fmax_) fmax_ = M * cf;
+        if (plane_rows(B, H, H) * cm > pmax) pmax = plane_rows(B, H, H) * cm;
+        cprev = c;
+    }
+    v->f_floats = fmax_; v->p1_elems = 3 * pmax; v->p2_elems = 3 * pmax;
+    v->ws_floats = (size_t)64 << 20;
+    const int Hl = v->H0 << (desc->n_mult - 1);
+    if (vmalloc(&v->fa, v->f_floats) || vmalloc(&v->fb, v->f_floats) || vmalloc(&v->fc, v->f_floats) || vmalloc(&v->p1, v->p1_elems) ||
+        vmalloc(&v->p2, v->p2_elems) || vmalloc(&v->ws, v->ws_floats) || vmalloc(&v->t27, (size_t)B * (Hl + 2) * (Hl + 2) * 28) ||
+        vmalloc(&v->stats, (size_t)B * 64) || vmalloc(&v->part, (size_t)B * 64 * 32 * 2)) {
+        sdvar_vae_destroy(v);
+        return SDVAR_ERR_HIP;
+    }
+    *out = v;
+    return SDVAR_OK;
+}
+
+int sdvar_vae_destroy(sdvar_vae_t* v) {
+    if (!v) return SDVAR_OK;
+    void* bufs[] = {v->fa, v->fb, v->fc, v->p1, v->p2, v->ws, v->t27, v->stats, v->part, v->wt_out};
+    for (void* p : bufs) if (p) (void)hipFree(p);
+    for (void* p : v->owned) (void)hipFree(p);
+    delete v;
+    return SDVAR_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+struct Binder {
+    sdvar_vae* v; const float* const* t; int n, pos; hipStream_t s; int rc;
+    const float* next() { if (pos >= n) { rc = SDVAR_ERR_ARG; return nullptr; } return t[pos++]; }
+    void conv(ConvW& c, int cin, int cout, int taps) {
+        const float* w = next(); const float* b = next();
+        if (rc || !w || !b) { rc = SDVAR_ERR_ARG; return; }
+        c.cin = cin; c.cout = cout; c.taps = taps; c.bias = b;
+        c.wps = (size_t)taps * cin * cout;
+        uint16_t* p = nullptr;
+        if (hipMalloc((void**)&p, 3 * c.wps * sizeof(uint16_t)) != hipSuccess) { rc = SDVAR_ERR_HIP; return; }
+        v->owned.push_back(p);
+        c.wp = p;
+        const int r = conv_weight_planes(w, p, cout, cin, taps, c.wps, s);
+        if (r) rc = r;
+    }
+    void norm(NormW& nw, int C) { nw.gamma = next(); nw.beta = next(); nw.C = C; if (!nw.gamma || !nw.beta) rc = SDVAR_ERR_ARG; }
+    void res(ResW& r, int cin, int cout) {
+        norm(r.n1, cin); conv(r.c1, cin, cout, 9); norm(r.n2, cout); conv(r.c2, cout, cout, 9);
+        r.has_sc = cin != cout;
+        if (r.has_sc) conv(r.sc, cin, cout, 1);
+    }
+    void attn(AttnW& a, int C) { norm(a.n, C); conv(a.qkv, C, 3 * C, 1); conv(a.proj, C, C, 1); }
+};
+
+}  // namespace
+
+extern "C" {
+
+int sdvar_vae_tensor_count(const sdvar_vae_desc* d) {
+    if (!d) return -1;
+    int n = 2 + 2;                                         // post_quant_conv, conv_in
+    n += 8 + 6 + 8;                                        // mid.block_1, mid.attn_1, mid.block_2
+    int cprev = d->ch * d->ch_mult[d->n_mult - 1];
+    for (int lv = d->n_mult - 1; lv >= 0; --lv) {
+        const int c = d->ch * d->ch_mult[lv];
+        for (int i = 0; i <= d->num_res_blocks; ++i) {
+            n += 8 + (cprev != c ? 2 : 0);
+            cprev = c;
+            if (lv == d->n_mult - 1) n += 6;
+        }
+        if (lv != 0) n += 2;
+    }
+    return n + 2 + 2;                                      // norm_out, conv_out
+}
+
+int sdvar_vae_bind(sdvar_vae_t* v, const float* const* tensors, int32_t n_tensors, void* stream) {
+    SDVAR_CHECK_ARG(v && tensors, "vae_bind: null argument");
+    SDVAR_CHECK_ARG(n_tensors == sdvar_vae_tensor_count(&v->d), "vae_bind: expected %d tensors, got %d", sdvar_vae_tensor_count(&v->d), n_tensors);
+    for (int i = 0; i < n_tensors; ++i) SDVAR_CHECK_ARG(tensors[i], "vae_bind: tensor %d is null", i);
+    for (void* p : v->owned) (void)hipFree(p);
+    v->owned.clear(); v->levels.clear();
+    const sdvar_vae_desc& d = v->d;
+    Binder b{v, tensors, n_tensors, 0, (hipStream_t)stream, SDVAR_OK};
+    const int z = d.z_channels, ctop = d.ch * d.ch_mult[d.n_mult - 1];
+    b.conv(v->post_quant, z, z, 9);
+    b.conv(v->conv_in, z, ctop, 9);
+    b.res(v->mid1, ctop, ctop); b.attn(v->mid_attn, ctop); b.res(v->mid2, ctop, ctop);
+    int cprev = ctop;
+    for (int lv = d.n_mult - 1; lv >= 0; --lv) {
+        Level L;
+        const int c = d.ch * d.ch_mult[lv];
+        for (int i = 0; i <= d.num_res_blocks; ++i) {
+            ResW r; b.res(r, cprev, c); L.blocks.push_back(r); cprev = c;
+            if (lv == d.n_mult - 1) { AttnW a; b.attn(a, c); L.attns.push_back(a); }
+        }
+        L.has_up = lv != 0;
+        if (L.has_up) b.conv(L.up, c, c, 9);
+        v->levels.push_back(L);
+    }
+    b.norm(v->norm_out, cprev);
+    const float* wo = b.next(); v->b_out = b.next(); v->c_out = cprev;
+    if (b.rc) { set_error("vae_bind: failed while binding tensor %d", b.pos); return b.rc; }
+    if (v->wt_out) { (void)hipFree(v->wt_out); v->wt_out = nullptr; }
+    SDVAR_HIP(hipMalloc((void**)&v->wt_out, (size_t)cprev * 28 * sizeof(float)));
+    hipLaunchKernelGGL(convout_weight_kernel, dim3((cprev * 28 + 255) / 256), dim3(256), 0, (hipStream_t)stream, wo, v->wt_out, cprev);
+    SDVAR_LAUNCH_CHECK();
+    v->bound = true;
+    return SDVAR_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+struct Runner {
+    sdvar_vae* v; int B; hipStream_t s;
+    int H = 0;                               // current resolution (square)
+    float *x, *h, *t;                        // residual stream, temporary, third buffer
+
+    size_t M() const { return (size_t)B * (H + 2) * (H + 2); }
+    int stats_of(const float* src, int C) {
+        const int nch = H < 64 ? H : 64, rpc = (H + nch - 1) / nch, chunks = (H + rpc - 1) / rpc;
+        hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, B), dim3(320), 0, s, src, v->part, C, H, H, rpc);
+        SDVAR_LAUNCH_CHECK();
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(32), 0, s, v->part, v->stats, chunks, (double)H * H * (C / 32), 1e-6);
+        SDVAR_LAUNCH_CHECK();
+        return SDVAR_OK;
+    }
+    // planes of (optionally normalised / activated / up-sampled) src -> dst planes; returns via out params the operand geometry
+    int prep(const float* src, int C, const NormW* nw, int silu, int up, uint16_t* dst, size_t dst_elems, size_t* ops, size_t* rows, int* G) {
+        const int Ho = H << up;
+        *G = guard_rows(Ho); *rows = plane_rows(B, Ho, Ho); *ops = *rows * (size_t)C;
+        SDVAR_CHECK_ARG(3 * *ops <= dst_elems, "vae: plane buffer too small");
+        if (nw) VAE_TRY(stats_of(src, C));
+        const size_t total = *rows * (C / 8);
+        const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+        hipLaunchKernelGGL(prep_planes_kernel, dim3(grid), dim3(256), 0, s, src, v->stats, nw ? nw->gamma : nullptr, nw ? nw->beta : nullptr, dst, *ops, B, C, H, H,
+                           up, (nw ? 1 : 0) | (silu ? 2 : 0), *G);
+        SDVAR_LAUNCH_CHECK();
+        return SDVAR_OK;
+    }
+    int conv(const ConvW& c, const uint16_t* xp, size_t ops, size_t rows, int G, const float* res, float* out) {
+        SDVAR_CHECK_ARG(M() * c.cout <= v->f_floats, "vae: activation buffer too small");
+        return conv_bf16x3(xp, ops, rows, G, c.wp, c.wps, c.bias, res, out, (int)M(), c.cout, c.cin, c.taps, H + 2, v->ws, v->ws_floats, 0, s);
+    }
+    int resblock(const ResW& r) {        // x <- shortcut(x) + conv2(silu(gn2(conv1(silu(gn1(x))))))          basic_vae.py:62-73
+        size_t ops, rows; int G;
+        const float* resid = x;
+        if (r.has_sc) {
+            VAE_TRY(prep(x, r.c1.cin, nullptr, 0, 0, v->p2, v->p2_elems, &ops, &rows, &G));
+            VAE_TRY(conv(r.sc, v->p2, ops, rows, G, nullptr, t));
+            resid = t;
+        }
+        VAE_TRY(prep(x, r.c1.cin, &r.n1, 1, 0, v->p1, v->p1_elems, &ops, &rows, &G));
+        VAE_TRY(conv(r.c1, v->p1, ops, rows, G, nullptr, h));
+        VAE_TRY(prep(h, r.c2.cin, &r.n2, 1, 0, v->p1, v->p1_elems, &ops, &rows, &G));
+        if (r.has_sc) { VAE_TRY(conv(r.c2, v->p1, ops, rows, G, resid, t)); float* tmp = x; x = t; t = tmp; }
+        else VAE_TRY(conv(r.c2, v->p1, ops, rows, G, resid, x));
+        return SDVAR_OK;
+    }
+    int attnblock(const AttnW& a) {       // x <- x + proj(attn(qkv(gn(x))))                                   basic_vae.py:86-103
+        size_t ops, rows; int G;
+        const int C = a.n.C;
+        VAE_TRY(prep(x, C, &a.n, 0, 0, v->p1, v->p1_elems, &ops, &rows, &G));
+        VAE_TRY(conv(a.qkv, v->p1, ops, rows, G, nullptr, h));
+        const int N = H * H;
+        const size_t lds = ((size_t)VA_QT * C + (size_t)VA_QT * N) * sizeof(float);
+        SDVAR_CHECK_ARG(lds <= 160 * 1024, "vae: attention tile of %zu bytes does not fit the LDS (C=%d, %d tokens)", lds, C, N);
+        SDVAR_HIP(hipFuncSetAttribute((const void*)vae_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SDVAR_HIP(hipMemsetAsync(t, 0, M() * C * sizeof(float), s));
+        hipLaunchKernelGGL(vae_attn_kernel, dim3((N + VA_QT - 1) / VA_QT, B), dim3(256), lds, s, h, t, C, H, H);
+        SDVAR_LAUNCH_CHECK();
+        VAE_TRY(prep(t, C, nullptr, 0, 0, v->p1, v->p1_elems, &ops, &rows, &G));
+        VAE_TRY(conv(a.proj, v->p1, ops, rows, G, x, x));
+        return SDVAR_OK;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int sdvar_vae_decode(sdvar_vae_t* v, const float* f_hat, int32_t B, float* img, void* stream) {
+    SDVAR_CHECK_ARG(v && f_hat && img, "vae_decode: null argument");
+    SDVAR_CHECK_ARG(v->bound, "vae_decode: weights not bound");
+    SDVAR_CHECK_ARG(B >= 1 && B <= v->d.max_batch, "vae_decode: batch %d exceeds max_batch %d", B, v->d.max_batch);
+    hipStream_t s = (hipStream_t)stream;
+    Runner r{v, B, s, v->H0, v->fa, v->fb, v->fc};
+    const int z = v->d.z_channels;
+    size_t ops, rows; int G;
+    {
+        const size_t total = r.M() * z;
+        hipLaunchKernelGGL(rows_from_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, f_hat, r.h, B, z, r.H, r.H);
+        SDVAR_LAUNCH_CHECK();
+    }
+    VAE_TRY(r.prep(r.h, z, nullptr, 0, 0, v->p1, v->p1_elems, &ops, &rows, &G));
+    VAE_TRY(r.conv(v->post_quant, v->p1, ops, rows, G, nullptr, r.t));                     // vqvae.py:63 post_quant_conv
+    VAE_TRY(r.prep(r.t, z, nullptr, 0, 0, v->p1, v->p1_elems, &ops, &rows, &G));
+    VAE_TRY(r.conv(v->conv_in, v->p1, ops, rows, G, nullptr, r.x));                        // basic_vae.py:216 conv_in
+    VAE_TRY(r.resblock(v->mid1)); VAE_TRY(r.attnblock(v->mid_attn)); VAE_TRY(r.resblock(v->mid2));
+    for (const Level& L : v->levels) {
+        for (size_t i = 0; i < L.blocks.size(); ++i) {
+            VAE_TRY(r.resblock(L.blocks[i]));
+            if (i < L.attns.size()) VAE_TRY(r.attnblock(L.attns[i]));
+        }
+        if (L.has_up) {                                                                    // Upsample2x: conv(interpolate(x, 2, nearest))
+            VAE_TRY(r.prep(r.x, L.up.cin, nullptr, 0, 1, v->p1, v->p1_elems, &ops, &rows, &G));
+            r.H <<= 1;
+            VAE_TRY(r.conv(L.up, v->p1, ops, rows, G, nullptr, r.h));
+            float* tmp = r.x; r.x = r.h; r.h = tmp;
+        }
+    }
+    // norm_out + SiLU + conv_out + clamp
+    VAE_TRY(r.stats_of(r.x, v->c_out));
+    const size_t M = r.M();
+    hipLaunchKernelGGL(convout_partial_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, r.x, v->stats, v->norm_out.gamma, v->norm_out.beta, v->wt_out,
+                       v->t27, B, v->c_out, r.H, r.H);
+    SDVAR_LAUNCH_CHECK();
+    const size_t total = (size_t)B * 3 * r.H * r.H;
+    hipLaunchKernelGGL(convout_gather_kernel, dim3((unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192)), dim3(256), 0, s, v->t27, v->b_out, img, B, r.H, r.H);
+    SDVAR_LAUNCH_CHECK();
+    return SDVAR_OK;
+}
+
+/* single operators for the parity tests */
+int sdvar_op_conv_weight_planes(const float* w, uint16_t* planes, int32_t Cout, int32_t Cin, int32_t taps, uint64_t plane_stride, void* stream) {
+    return conv_weight_planes(w, planes, Cout, Cin, taps, (size_t)plane_stride, (hipStream_t)stream);
+}
+int sdvar_op_vae_prep(const float* in, const float* stats, const float* gamma, const float* beta, uint16_t* planes, uint64_t plane_stride, int32_t B, int32_t C,
+                      int32_t H, int32_t W, int32_t up, int32_t mode, int32_t guard, void* stream) {
+    SDVAR_CHECK_ARG(in && planes && C % 32 == 0 && (!(mode & 1) || (stats && gamma && beta)), "vae_prep: bad arguments");
+    const size_t rows = (size_t)B * ((H << up) + 2) * ((W << up) + 2) + 2 * (size_t)guard, total = rows * (C / 8);
+    hipLaunchKernelGGL(prep_planes_kernel, dim3((unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192)), dim3(256), 0, (hipStream_t)stream, in, stats, gamma,
+                       beta, planes, (size_t)plane_stride, B, C, H, W, up, mode, guard);
+    SDVAR_LAUNCH_CHECK();
+    return SDVAR_OK;
+}
+int sdvar_op_conv_bf16x3(const uint16_t* x_planes, uint64_t x_plane_stride, uint64_t x_rows, int32_t x_row0, const uint16_t* w_planes, uint64_t w_plane_stride,
+                         const float* bias, const float* res, float* out, int32_t M, int32_t N, int32_t Cin, int32_t taps, int32_t row_pitch, float* workspace,
+                         uint64_t workspace_floats, int32_t force_split, void* stream) {
+    return conv_bf16x3(x_planes, (size_t)x_plane_stride, (size_t)x_rows, x_row0, w_planes, (size_t)w_plane_stride, bias, res, out, M, N, Cin, taps, row_pitch, workspace,
+                       (size_t)workspace_floats, force_split, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -40,6 +40,11 @@ class _ModelDesc(C.Structure):
                 ("cvae", C.c_int32), ("num_classes", C.c_int32), ("max_batch", C.c_int32), ("max_chunk_stages", C.c_int32), ("kv_dtype", C.c_int32), ("gemm_mode", C.c_int32)]
 
 
+class _VaeDesc(C.Structure):
+    _fields_ = [("ch", C.c_int32), ("z_channels", C.c_int32), ("n_mult", C.c_int32), ("ch_mult", C.c_int32 * 8), ("num_res_blocks", C.c_int32),
+                ("max_batch", C.c_int32), ("latent_hw", C.c_int32)]
+
+
 _P, _I, _D, _U64, _U32 = C.c_void_p, C.c_int32, C.c_double, C.c_uint64, C.c_uint32
 # name -> (restype, argtypes); must list every symbol declared in include/sdvar_hip.h (tests/test_abi.py checks it)
 _SIGNATURES = {
@@ -61,6 +66,11 @@ _SIGNATURES = {
     "sdvar_quant_destroy": (_I, [_P]),
     "sdvar_quant_bind": (_I, [_P, _P, C.POINTER(_P), C.POINTER(_P)]),
     "sdvar_quant_next": (_I, [_P, _I, _P, _I, _P, _P, _I, _P]),
+    "sdvar_vae_create": (_I, [C.POINTER(_VaeDesc), C.POINTER(_P)]),
+    "sdvar_vae_destroy": (_I, [_P]),
+    "sdvar_vae_tensor_count": (_I, [C.POINTER(_VaeDesc)]),
+    "sdvar_vae_bind": (_I, [_P, C.POINTER(_P), _I, _P]),
+    "sdvar_vae_decode": (_I, [_P, _P, _I, _P, _P]),
     "sdvar_cfg_sample": (_I, [_P, _I, _I, _I, _D, _I, _D, _P, _U64, _U32, _U32, _P, _I, _P, _P]),
     "sdvar_verify_accept": (_I, [_P, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_D), _P, _I, _D, _P, _P, _P]),
     "sdvar_op_gemm": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P]),
@@ -69,6 +79,9 @@ _SIGNATURES = {
     "sdvar_op_gemm_bf16x3": (_I, [_P, _U64, _P, _U64, _P, _P, _I, _P, _U64, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P]),
     "sdvar_op_qk_norm_append": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "sdvar_op_attention": (_I, [_P, _P, _P, _I, _P, _P, _U64, _I, _I, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), _P]),
+    "sdvar_op_conv_weight_planes": (_I, [_P, _P, _I, _I, _I, _U64, _P]),
+    "sdvar_op_vae_prep": (_I, [_P, _P, _P, _P, _P, _U64, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "sdvar_op_conv_bf16x3": (_I, [_P, _U64, _U64, _I, _P, _U64, _P, _P, _P, _I, _I, _I, _I, _I, _P, _U64, _I, _P]),
     "sdvar_op_noise_fill": (_I, [_P, _I, _I, _I, _U64, _U32, _U32, _P]),
     "sdvar_debug_set_gemm_cfg": (_I, [_I, _I]),
     "sdvar_debug_set_gemm_stamps": (_I, [_P]),
@@ -229,6 +242,69 @@ class QuantCtx:
     def close(self):
         if self.h:
             self.lib.sdvar_quant_destroy(self.h); self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class VaeCtx:
+    """sdvar_vae_t from the VQVAE state_dict: `fhat_to_img` (vqvae.py:62-63) as hand-written HIP (csrc/conv.hip, csrc/vae.hip)."""
+
+    def __init__(self, vae_sd: Dict[str, torch.Tensor], max_batch: int, device, latent_hw: int = 16, ch: Optional[int] = None,
+                 ch_mult: Sequence[int] = (1, 1, 2, 2, 4), num_res_blocks: int = 2):
+        self.lib = load_library()
+        self.device = torch.device(device)
+        z = vae_sd["post_quant_conv.weight"].shape[0]
+        ch = ch if ch is not None else vae_sd["decoder.norm_out.weight"].shape[0] // ch_mult[0]
+        d = _VaeDesc()
+        d.ch, d.z_channels, d.n_mult, d.num_res_blocks, d.max_batch, d.latent_hw = ch, z, len(ch_mult), num_res_blocks, max_batch, latent_hw
+        for i, m in enumerate(ch_mult):
+            d.ch_mult[i] = m
+        self.desc, self.max_batch, self.latent_hw, self.z = d, max_batch, latent_hw, z
+        self.out_hw = latent_hw << (len(ch_mult) - 1)
+        names = ["post_quant_conv", "decoder.conv_in"]
+        res = lambda p, sc: [p + ".norm1", p + ".conv1", p + ".norm2", p + ".conv2"] + ([p + ".nin_shortcut"] if sc else [])
+        att = lambda p: [p + ".norm", p + ".qkv", p + ".proj_out"]
+        names += res("decoder.mid.block_1", False) + att("decoder.mid.attn_1") + res("decoder.mid.block_2", False)
+        for lv in reversed(range(len(ch_mult))):
+            for i in range(num_res_blocks + 1):
+                p = f"decoder.up.{lv}.block.{i}"
+                names += res(p, p + ".nin_shortcut.weight" in vae_sd)
+                if lv == len(ch_mult) - 1:
+                    names += att(f"decoder.up.{lv}.attn.{i}")
+            if lv != 0:
+                names.append(f"decoder.up.{lv}.upsample.conv")
+        names += ["decoder.norm_out", "decoder.conv_out"]
+        self.tensors = []                                   # keeps the device copies alive: biases and GroupNorm affine stay borrowed
+        for n in names:
+            self.tensors += [_f32(vae_sd[n + ".weight"], self.device), _f32(vae_sd[n + ".bias"], self.device)]
+        want = self.lib.sdvar_vae_tensor_count(C.byref(d))
+        if want != len(self.tensors):
+            raise SdvarError(f"VQVAE decoder layout mismatch: the library expects {want} tensors, the state_dict walk found {len(self.tensors)}")
+        self.h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _check(self.lib.sdvar_vae_create(C.byref(d), C.byref(self.h)))
+            arr = (_P * len(self.tensors))(*[t.data_ptr() for t in self.tensors])
+            _check(self.lib.sdvar_vae_bind(self.h, arr, len(self.tensors), _stream()))
+
+    def decode(self, f_hat: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """f_hat (B, Cvae, h, w) fp32 on the device -> image (B, 3, H, W) in [-1, 1]; runs on torch's current stream."""
+        B = f_hat.shape[0]
+        if f_hat.dtype != torch.float32 or not f_hat.is_contiguous() or f_hat.device != self.device:
+            f_hat = f_hat.to(device=self.device, dtype=torch.float32).contiguous()
+        if tuple(f_hat.shape[1:]) != (self.z, self.latent_hw, self.latent_hw) or B > self.max_batch:
+            raise SdvarError(f"decode: f_hat {tuple(f_hat.shape)} does not fit (max_batch {self.max_batch}, {self.z} x {self.latent_hw}^2)")
+        if out is None:
+            out = torch.empty(B, 3, self.out_hw, self.out_hw, device=self.device, dtype=torch.float32)
+        _check(self.lib.sdvar_vae_decode(self.h, _ptr(f_hat), B, _ptr(out), _stream()))
+        return out
+
+    def close(self):
+        if self.h:
+            self.lib.sdvar_vae_destroy(self.h); self.h = C.c_void_p()
 
     def __del__(self):
         try:

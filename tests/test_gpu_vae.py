@@ -1,0 +1,141 @@
+"""VQVAE decoder on HIP (csrc/conv.hip, csrc/vae.hip) against PyTorch fp32 on the same weights.
+
+The decoder is the caller side of the sampler (vae.fhat_to_img, /root/reference/models/vqvae.py:62-63,
+models/basic_vae.py:163-226).  Floating point: the bar is 1e-4 on the [-1, 1] image (the same bar the MIOpen decode is held to in
+test_gpu_e2e.py) and 2e-5 on single convolutions; the split-operand arithmetic itself is exact to ~1e-6 (test_gpu_ops.py)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rnd
+from sdvar_amd import engine as E
+from sdvar_amd.vqvae import VQVAE
+from sdvar_amd.weights import vae_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+def _st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _rows(x):
+    """(B, C, H, W) -> padded pixel rows (B (H+2) (W+2), C)"""
+    return F.pad(x, (1, 1, 1, 1)).permute(0, 2, 3, 1).reshape(-1, x.shape[1]).contiguous()
+
+
+def _unrows(r, B, H, W):
+    return r.view(B, H + 2, W + 2, -1)[:, 1:-1, 1:-1].permute(0, 3, 1, 2)
+
+
+def _guard(W):
+    return (W + 3 + 15) // 16 * 16
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,taps,res,split", [(2, 64, 96, 8, 9, False, 0), (1, 32, 32, 16, 9, False, 0), (2, 160, 160, 12, 9, True, 0),
+                                                         (2, 320, 160, 6, 1, False, 0), (2, 128, 320, 5, 9, True, 3), (1, 640, 1920, 4, 1, False, 4),
+                                                         (3, 96, 40, 7, 9, False, 2)])
+def test_conv_matches_torch(dev, B, Cin, Cout, H, taps, res, split):
+    lib = E.load_library()
+    W = H + 1                                                                  # non-square on purpose
+    x = rnd(1, (B, Cin, H, W)).to(dev)
+    k = 3 if taps == 9 else 1
+    w = (rnd(2, (Cout, Cin, k, k)) / (Cin * taps) ** 0.5).to(dev); b = rnd(3, (Cout,), 0.1).to(dev)
+    r = rnd(4, (B, Cout, H, W)).to(dev) if res else None
+    G = _guard(W); M = B * (H + 2) * (W + 2); R = M + 2 * G
+    xp = torch.full((3, Cin // 32, R, 32), 0x7FC0, dtype=torch.int16, device=dev)          # NaN patterns: every row must be written
+    E._check(lib.sdvar_op_vae_prep(_p(_rows(x)), None, None, None, _p(xp), (Cin // 32) * R * 32, B, Cin, H, W, 0, 0, G, _st()))
+    wp = torch.zeros(3, taps * Cin // 32, Cout, 32, dtype=torch.int16, device=dev)
+    E._check(lib.sdvar_op_conv_weight_planes(_p(w), _p(wp), Cout, Cin, taps, taps * Cin * Cout, _st()))
+    out = torch.empty(M, Cout, device=dev)
+    ws = torch.empty(max(split, 1) * M * Cout, device=dev)
+    rr = _rows(r) if res else None
+    E._check(lib.sdvar_op_conv_bf16x3(_p(xp), (Cin // 32) * R * 32, R, G, _p(wp), taps * Cin * Cout, _p(b), _p(rr), _p(out), M, Cout, Cin, taps, W + 2,
+                                      _p(ws), ws.numel(), split, _st()))
+    want = F.conv2d(x.double(), w.double(), b.double(), padding=k // 2) + (r.double() if res else 0)
+    got = _unrows(out, B, H, W).double()
+    assert torch.isfinite(out).all()
+    err = (got - want).abs().max().item()
+    assert err <= 2e-5, err
+
+
+@pytest.mark.parametrize("up,mode", [(0, 0), (0, 3), (1, 0), (0, 1)])
+def test_prep_groupnorm_silu_upsample(dev, up, mode):
+    lib = E.load_library()
+    B, Cc, H, W = 2, 64, 6, 5
+    x = rnd(5, (B, Cc, H, W), 2.0).to(dev)
+    gamma, beta = (1 + rnd(6, (Cc,), 0.1)).to(dev), rnd(7, (Cc,), 0.1).to(dev)
+    xg = x.view(B, 32, -1).double()
+    mean, var = xg.mean(-1), xg.var(-1, unbiased=False)
+    stats = torch.stack([mean, 1 / torch.sqrt(var + 1e-6)], -1).float().contiguous()
+    Ho, Wo = H << up, W << up
+    G = _guard(Wo); M = B * (Ho + 2) * (Wo + 2); R = M + 2 * G
+    xp = torch.full((3, Cc // 32, R, 32), 0x7FC0, dtype=torch.int16, device=dev)
+    E._check(lib.sdvar_op_vae_prep(_p(_rows(x)), _p(stats), _p(gamma), _p(beta), _p(xp), (Cc // 32) * R * 32, B, Cc, H, W, up, mode, G, _st()))
+    v = sum((xp[k].to(torch.int32) << 16).view(torch.float32).double() for k in range(3))   # (C/32, R, 32)
+    v = v.permute(1, 0, 2).reshape(R, Cc)
+    assert v[:G].abs().max().item() == 0 and v[G + M:].abs().max().item() == 0              # guards
+    full = v[G:G + M].view(B, Ho + 2, Wo + 2, Cc)
+    assert full[:, 0].abs().max().item() == 0 and full[:, :, 0].abs().max().item() == 0 and full[:, -1].abs().max().item() == 0 and full[:, :, -1].abs().max().item() == 0
+    want = x
+    if mode & 1:
+        want = F.group_norm(want, 32, gamma, beta, eps=1e-6)
+    if mode & 2:
+        want = F.silu(want)
+    if up:
+        want = F.interpolate(want, scale_factor=2, mode="nearest")
+    got = full[:, 1:-1, 1:-1].permute(0, 3, 1, 2)
+    assert (got - want.double()).abs().max().item() <= (2e-6 if mode else 0.0)
+
+
+def _decode_pair(dev, ch, B, latent=16, seed=11):
+    pns = (1, 2, 3, 4, 5, 6, 8, 10, 13, 16)
+    sd = vae_state_dict(pns, "stress", seed, V=64, Cvae=32, ch=ch, with_encoder=False)
+    vae = VQVAE(vocab_size=64, z_channels=32, ch=ch, v_patch_nums=pns, with_encoder=False)
+    vae.load_state_dict(sd)
+    vae = vae.to(dev)
+    ctx = E.VaeCtx(sd, B, dev, latent_hw=latent)
+    f_hat = rnd(seed + 1, (B, 32, latent, latent), 1.5).to(dev)
+    return vae, ctx, f_hat
+
+
+def test_decoder_small_width_matches_pytorch(dev):
+    vae, ctx, f_hat = _decode_pair(dev, 32, 3)
+    got = ctx.decode(f_hat)
+    want = vae.fhat_to_img(f_hat.clone())
+    assert got.shape == want.shape == (3, 3, 256, 256)
+    err = (got - want).abs().max().item()
+    assert err <= 1e-4, err
+    assert (got - ctx.decode(f_hat)).abs().max().item() == 0                    # deterministic
+    sub = ctx.decode(f_hat[:1])                                                # other batch size: other split-K choices, same image
+    assert (sub - got[:1]).abs().max().item() <= 2e-5
+
+
+def test_decoder_reference_width_matches_pytorch(dev):
+    """vae_ch160v4096z32 geometry (the checkpoint the reference loads): ch = 160, widths 640/320/160, 256^2 output."""
+    vae, ctx, f_hat = _decode_pair(dev, 160, 2)
+    got = ctx.decode(f_hat)
+    want = vae.fhat_to_img(f_hat.clone())
+    err = (got - want).abs().max().item()
+    assert err <= 1e-4, err
+    assert float(got.min()) >= -1.0 and float(got.max()) <= 1.0
+
+
+def test_decoder_rejects_bad_shapes(dev):
+    _, ctx, f_hat = _decode_pair(dev, 32, 1)
+    with pytest.raises(E.SdvarError):
+        ctx.decode(torch.zeros(2, 32, 16, 16, device=dev))                      # exceeds max_batch
+    with pytest.raises(E.SdvarError):
+        ctx.decode(torch.zeros(1, 32, 8, 8, device=dev))
