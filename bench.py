@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-modes", action="store_true")
     ap.add_argument("--decode-high-prio", action="store_true", help="experiment: give the decode stream the higher HIP priority")
+    ap.add_argument("--torch-decode", action="store_true", help="A/B: decode with the PyTorch/MIOpen reference decoder instead of the HIP decoder")
     ap.add_argument("--serial-decode", action="store_true", help="decode on the sampling stream instead of overlapping it with the next batch")
     ap.add_argument("--gemm-mode", default=None, choices=["f32", "bf16x3"], help="default: sdvar_amd.engine.DEFAULT_GEMM_MODE")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark for the VQVAE decoder convs")
@@ -96,6 +97,7 @@ def main():
 
     # The VQVAE decode of batch i runs on a second HIP stream and overlaps the sampling loop of batch i+1 (whose early
     # stages leave most CUs idle); f_hat is double-buffered and every decode is finished inside the timed region.
+    decode = vae.fhat_to_img_torch if args.torch_decode else vae.fhat_to_img
     main_stream = torch.cuda.current_stream()
     dec_stream = torch.cuda.Stream(device=dev, priority=0 if not args.decode_high_prio else -1)
     fh_buf = [torch.zeros(B, 32, 16, 16, device=dev) for _ in range(2)]
@@ -106,7 +108,7 @@ def main():
         res = smp.spec_decode(labels, 1.5, args.gamma, 900, 0.96, E.Noise("device", seed, image_offset=lo), thr=thr[mode])
         st = dict(res.stats); st["images"] = B
         if args.serial_decode:
-            state["img"] = vae.fhat_to_img(res.f_hat).add_(1).mul_(0.5)          # (B,3,256,256) in [0,1]  (var.py:215)
+            state["img"] = decode(res.f_hat).add_(1).mul_(0.5)                   # (B,3,256,256) in [0,1]  (var.py:215)
             return state["img"], st
         j = state["i"] & 1; state["i"] += 1
         if dec_done[j] is not None:
@@ -115,7 +117,7 @@ def main():
         ready = torch.cuda.Event(); ready.record(main_stream)
         dec_stream.wait_event(ready)
         with torch.cuda.stream(dec_stream):
-            state["img"] = vae.fhat_to_img(fh_buf[j]).add_(1).mul_(0.5)
+            state["img"] = decode(fh_buf[j]).add_(1).mul_(0.5)
             dec_done[j] = torch.cuda.Event(); dec_done[j].record(dec_stream)
         return state["img"], st
 
@@ -150,6 +152,11 @@ def main():
     nd_steps = max(2, args.steps // 2)
     dt_nd = timed_nodecode(nd_steps)
     log(f"no-decode: {B * world * nd_steps / dt_nd:.2f} images/s")
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(5):
+        decode(fh_buf[0])
+    torch.cuda.synchronize(); dec_ms = (time.perf_counter() - t0) / 5 * 1e3
+    log(f"decode alone: {dec_ms:.2f} ms per batch of {B} ({'PyTorch/MIOpen' if args.torch_decode else 'HIP decoder'})")
 
     extra = {}
     if not args.no_extra_modes:
@@ -209,6 +216,7 @@ def main():
         "mean_accepted_tokens_per_step": agg["mean_accepted_tokens_per_step"],
         "target_calls": agg["target_calls"], "draft_stage_calls": agg["draft_stage_calls"], "forced_accepts": agg["forced_accepts"],
         "images_per_s_no_decode": B * world * nd_steps / dt_nd,
+        "decode_ms_per_batch": dec_ms, "decoder": "pytorch-miopen" if args.torch_decode else "hip (csrc/conv.hip, csrc/vae.hip)",
         "modes": extra, "roofline": roofline, "roofline_verify_attention": roofline_attn, "kernel_class_ms_per_step": class_ms,
     }
 

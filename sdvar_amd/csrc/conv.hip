@@ -2,12 +2,13 @@
 // GEMM on the bf16 matrix cores with split operands - the arithmetic contract of gemm_bf16x3.hip (fp32 values held exactly
 // as three bf16 planes, six plane products, fp32 accumulate).
 //
-// Activation layout ("padded pixel rows"): an image batch (B, C, H, W) is stored channel-last with a one-pixel zero frame,
-//     row(b, y, x) = (b (H+2) + y + 1) (W+2) + x + 1,   M = B (H+2) (W+2) rows,
-// fp32 tensors are [M][C]; GEMM operands are K-blocked planes [3][C/32][G + M + G][32] bf16 with G >= W+3 zero guard rows on
-// both ends.  With that layout the A tile of tap (dy, dx) and channel block cb of a 3x3 convolution is the SAME run of
-// rows shifted by dy (W+2) + dx - one contiguous, fully coalesced LDS-DMA per 16 rows, no im2col, no bounds tests (frame
-// pixels are real zeros in the planes; frame rows of the OUTPUT are computed like any other row and ignored downstream).
+// Layouts: fp32 activations are dense channel-last rows [M][C], M = B H W, row(b, y, x) = (b H + y) W + x.  The GEMM A operand
+// is the same tensor as K-blocked planes [3][C/32][G + Mp + G][32] bf16 over "padded pixel rows": a one-pixel zero frame
+// around every image, prow(b, y, x) = (b (H+2) + y + 1) (W+2) + x + 1, Mp = B (H+2) (W+2), plus G >= W+3 zero guard rows on
+// both ends.  With that layout the A rows of tap (dy, dx) and channel block cb of a 3x3 convolution are the rows of the
+// centre tap shifted by dy (W+2) + dx: every lane of the LDS-DMA computes prow(m) once and adds a wave-uniform offset per
+// K-step - no im2col, no bounds tests (the frame is real zeros), and only the B H W real pixels are computed: 256^2 x 8
+// images = 2048 row tiles = exactly 8 rounds of the 256 CUs.
 // Weights (Cout, Cin, kh, kw) are re-packed once as planes [3][taps Cin / 32][Cout][32] with k = tap Cin + cin.
 //
 // Kernel: 256 x 160 workgroup tile (every decoder width - 160, 320, 640, 1920 - is a multiple of 160), 8 waves, each
@@ -34,7 +35,7 @@ struct ConvArgs {
     size_t x_rows;                                 // rows per channel block of X (G + M + G)
     int x_row0;                                    // G
     const float* bias; const float* res; float* out;
-    int M, N, cb, taps, w2, ldo, split, k_per_split;   // cb = Cin / 32; K-steps = taps * cb
+    int M, N, cb, taps, ih, iw, ldo, split, k_per_split;   // cb = Cin / 32; K-steps = taps * cb; (ih, iw): image size, M = B ih iw
 };
 
 template <int EPI>
@@ -56,8 +57,13 @@ __global__ __launch_bounds__(512, 2) void conv_bf16x3_kernel(ConvArgs a) {
     const int nkt = a.taps * a.cb;
     const int kt0 = ks * a.k_per_split;
     const int nk = min(nkt - kt0, a.k_per_split);
-    const uint16_t* sx0 = a.X + ((size_t)a.x_row0 + min(m0 + xr0, a.M - 1)) * 32 + 8 * cx0;
-    const uint16_t* sx1 = a.X + ((size_t)a.x_row0 + min(m0 + xr1, a.M - 1)) * 32 + 8 * cx1;
+    const int w2 = a.iw + 2;
+    auto prow = [&](int m) {                    // dense pixel index -> padded pixel row of the planes
+        const int hw = a.ih * a.iw, b = m / hw, rem = m - b * hw, y = rem / a.iw, x = rem - y * a.iw;
+        return (size_t)(b * (a.ih + 2) + y + 1) * w2 + x + 1;
+    };
+    const uint16_t* sx0 = a.X + ((size_t)a.x_row0 + prow(min(m0 + xr0, a.M - 1))) * 32 + 8 * cx0;
+    const uint16_t* sx1 = a.X + ((size_t)a.x_row0 + prow(min(m0 + xr1, a.M - 1))) * 32 + 8 * cx1;
     const uint16_t* sw0 = a.W + (size_t)min(n0 + wr0, a.N - 1) * 32 + 8 * cw0;
     const uint16_t* sw1 = a.W + (size_t)min(n0 + wr1, a.N - 1) * 32 + 8 * cw1;
     const bool two_w = wave < 2;
@@ -65,7 +71,7 @@ __global__ __launch_bounds__(512, 2) void conv_bf16x3_kernel(ConvArgs a) {
     long long xoff = 0; size_t woff = 0;
     auto set_step = [&](int t) {
         const int kb = kt0 + t, tap = kb / a.cb, c = kb - tap * a.cb;
-        const int shift = (a.taps == 9) ? (tap / 3 - 1) * a.w2 + (tap % 3 - 1) : 0;
+        const int shift = (a.taps == 9) ? (tap / 3 - 1) * w2 + (tap % 3 - 1) : 0;
         xoff = ((long long)c * (long long)a.x_rows + shift) * 32;
         woff = (size_t)kb * a.N * 32;
     };
@@ -144,6 +150,20 @@ __global__ __launch_bounds__(512, 2) void conv_bf16x3_kernel(ConvArgs a) {
 #undef SDVAR_LDS_RD
     }
 
+    // epilogue.  The residual is fetched for the whole wave tile first (80 independent loads in flight: the operand
+    // fragments are dead by now), then added and stored: interleaved load -> add -> store chains cost 35 us per workgroup.
+    float rv[5][16];
+    if (EPI == CEPI_BIAS_RES) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int n = n0 + j * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                rv[j][r] = (n < a.N && m < a.M) ? a.res[(size_t)m * a.ldo + n] : 0.f;
+            }
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
         const int n = n0 + j * 32 + li;
@@ -155,7 +175,7 @@ __global__ __launch_bounds__(512, 2) void conv_bf16x3_kernel(ConvArgs a) {
             const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             if (m >= a.M) continue;
             float v = acc[j][r] + bv;
-            if (EPI == CEPI_BIAS_RES) v += a.res[(size_t)m * a.ldo + n];
+            if (EPI == CEPI_BIAS_RES) v += rv[j][r];
             outp[(size_t)m * a.ldo + n] = v;
         }
     }
@@ -215,15 +235,17 @@ static int conv_choose_split(int M, int N, int nkt, size_t ws_floats) {
     return bs;
 }
 
-// out[M][N] = conv(X planes, W planes) + bias (+ res[M][N]).  taps = 9: 3x3 with row pitch w2 = W + 2; taps = 1: 1x1 (plain GEMM).
+// out[B H W][N] = conv(X planes of a (B, Cin, H, W) tensor, W planes) + bias (+ res[B H W][N]).  taps = 9: 3x3, pad 1; taps = 1: 1x1.
 int conv_bf16x3(const uint16_t* X, size_t xps, size_t x_rows, int x_row0, const uint16_t* W, size_t wps, const float* bias, const float* res, float* out,
-                int M, int N, int Cin, int taps, int w2, float* ws, size_t ws_floats, int force_split, hipStream_t stream) {
+                int B, int H, int Wd, int N, int Cin, int taps, float* ws, size_t ws_floats, int force_split, hipStream_t stream) {
+    const int M = B * H * Wd, w2 = Wd + 2;
+    const size_t Mp = (size_t)B * (H + 2) * w2;
     SDVAR_CHECK_ARG(X && W && out, "conv: null operand");
     SDVAR_CHECK_ARG(M > 0 && N > 0 && Cin > 0 && Cin % 32 == 0 && (taps == 1 || taps == 9), "conv: M=%d N=%d Cin=%d taps=%d", M, N, Cin, taps);
-    SDVAR_CHECK_ARG(taps == 1 || (w2 >= 3 && x_row0 >= w2 + 1), "conv: guard rows %d < row pitch %d + 1", x_row0, w2);
-    SDVAR_CHECK_ARG(x_rows >= (size_t)x_row0 + (size_t)M + (taps == 9 ? w2 + 1 : 0), "conv: plane rows %zu too few", x_rows);
+    SDVAR_CHECK_ARG(B > 0 && H > 0 && Wd > 0 && x_row0 >= w2 + 1, "conv: guard rows %d < row pitch %d + 1", x_row0, w2);
+    SDVAR_CHECK_ARG(x_rows >= (size_t)x_row0 + Mp + w2 + 1, "conv: plane rows %zu too few", x_rows);
     SDVAR_CHECK_ARG(((uintptr_t)X % 16) == 0 && ((uintptr_t)W % 16) == 0 && xps % 8 == 0 && wps % 8 == 0, "conv: planes must be 16-byte aligned");
-    ConvArgs a{X, W, xps, wps, x_rows, x_row0, bias, res, out, M, N, Cin / 32, taps, w2, N, 1, taps * (Cin / 32)};
+    ConvArgs a{X, W, xps, wps, x_rows, x_row0, bias, res, out, M, N, Cin / 32, taps, H, Wd, N, 1, taps * (Cin / 32)};
     const int nkt = taps * (Cin / 32);
     const int tiles = ((M + CBM - 1) / CBM) * ((N + CBN - 1) / CBN);
     int split = force_split > 0 ? force_split : conv_choose_split(M, N, nkt, ws ? ws_floats : 0);

@@ -1,8 +1,8 @@
 // VQVAE decoder f_hat -> image (the caller side of the sampler: vae.fhat_to_img at /root/reference/models/vqvae.py:62-63,
 // Decoder at models/basic_vae.py:163-226, ResnetBlock :47-73, AttnBlock :76-103, Upsample2x :24-30) as one C-ABI call.
 //
-// Everything between the convolutions works on the "padded pixel rows" layout of conv.hip: fp32 activations [M][C] with
-// M = B (H+2) (W+2), GEMM operands as K-blocked bf16x3 planes with zero frame and guard rows.  Per layer:
+// Layouts as in conv.hip: fp32 activations are dense channel-last rows [B H W][C]; GEMM operands are K-blocked bf16x3 planes over
+// padded pixel rows (zero frame, guard rows).  Per layer:
 //     GroupNorm statistics      gn_partial_kernel + gn_finalize_kernel  (fp32 partial sums per thread, fp64 across threads)
 //     GN * gamma + beta, SiLU, optional nearest 2x up-sampling, exact split into planes      prep_planes_kernel (one pass)
 //     3x3 / 1x1 convolution + bias (+ residual)                                              conv.hip
@@ -20,34 +20,31 @@ namespace sdvar {
 
 int conv_weight_planes(const float* w, uint16_t* planes, int Cout, int Cin, int taps, size_t plane_stride, hipStream_t stream);
 int conv_bf16x3(const uint16_t* X, size_t xps, size_t x_rows, int x_row0, const uint16_t* W, size_t wps, const float* bias, const float* res, float* out,
-                int M, int N, int Cin, int taps, int w2, float* ws, size_t ws_floats, int force_split, hipStream_t stream);
+                int B, int H, int Wd, int N, int Cin, int taps, float* ws, size_t ws_floats, int force_split, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------------- layout helpers
-// (B, C, H, W) fp32 -> padded pixel rows [M][C] (frame rows zero)
+// (B, C, H, W) fp32 -> channel-last rows [B H W][C]
 __global__ __launch_bounds__(256) void rows_from_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C, int H, int W) {
-    const int w2 = W + 2, h2 = H + 2;
-    const size_t total = (size_t)B * h2 * w2 * C;
+    const size_t total = (size_t)B * H * W * C;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
         const size_t row = i / C;
-        const int x = (int)(row % w2) - 1, y = (int)((row / w2) % h2) - 1, b = (int)(row / ((size_t)w2 * h2));
-        out[i] = (x >= 0 && x < W && y >= 0 && y < H) ? in[(((size_t)b * C + c) * H + y) * W + x] : 0.f;
+        const int x = (int)(row % W), y = (int)((row / W) % H), b = (int)(row / ((size_t)W * H));
+        out[i] = in[(((size_t)b * C + c) * H + y) * W + x];
     }
 }
 
 // ---------------------------------------------------------------------------------------------------- GroupNorm statistics
 // 32 groups, eps 1e-6 (basic_vae.py:20).  Grid (chunks, B), 320 threads: thread = (pixel lane, channel quad); requires (C/4) | 320.
 __global__ __launch_bounds__(320) void gn_partial_kernel(const float* __restrict__ x, double* __restrict__ part, int C, int H, int W, int rows_per_chunk) {
-    __shared__ float sm[2 * 8 * 640];            // [sum | sumsq][pixel lane][channel]  (C <= 640 at 2 lanes ... C = 160 at 8 lanes: lanes * C <= 1280)
+    __shared__ float sm[2 * 1280];               // [sum | sumsq][pixel lane][channel]: lanes * C = 320 * 4
     const int b = blockIdx.y, chunk = blockIdx.x, nq = C >> 2, npl = 320 / nq;
     const int q = threadIdx.x % nq, pl = threadIdx.x / nq;
-    const int w2 = W + 2;
     const int y0 = chunk * rows_per_chunk, y1 = min(H, y0 + rows_per_chunk);
     float s[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {0.f, 0.f, 0.f, 0.f};
     const int npix = (y1 - y0) * W;
     for (int p = pl; p < npix; p += npl) {
-        const int y = y0 + p / W, xx = p % W;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((size_t)(b * (H + 2) + y + 1) * w2 + xx + 1) * C + 4 * q);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)b * H + y0) * W + p) * C + 4 * q);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { s[e] += v[e]; ss[e] += v[e] * v[e]; }
     }
@@ -75,12 +72,12 @@ __global__ void gn_finalize_kernel(const double* __restrict__ part, float* __res
 }
 
 // ---------------------------------------------------------------------------------------------------- planes producer
-// in: fp32 padded rows of a (B, C, Hi, Wi) tensor.  out: planes [3][C/32][G + M_out + G][32] of the (B, C, Ho, Wo) tensor,
+// in: fp32 rows [B Hi Wi][C] of a (B, C, Hi, Wi) tensor.  out: planes [3][C/32][G + M_out + G][32] of the (B, C, Ho, Wo) tensor,
 // Ho = Hi << up.  mode bit 0: GroupNorm (stats, gamma, beta); bit 1: SiLU.  Thread = (output row incl. guards, 8 channels).
 __global__ __launch_bounds__(256) void prep_planes_kernel(const float* __restrict__ in, const float* __restrict__ stats, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, uint16_t* __restrict__ outp, size_t ops, int B, int C, int Hi, int Wi,
                                                           int up, int mode, int G) {
-    const int Ho = Hi << up, Wo = Wi << up, w2o = Wo + 2, h2o = Ho + 2, w2i = Wi + 2;
+    const int Ho = Hi << up, Wo = Wi << up, w2o = Wo + 2, h2o = Ho + 2;
     const size_t Mo = (size_t)B * h2o * w2o, R = Mo + 2 * (size_t)G;
     const int c8n = C >> 3, cpg = C / 32;
     const size_t total = R * c8n;
@@ -94,7 +91,7 @@ __global__ __launch_bounds__(256) void prep_planes_kernel(const float* __restric
             const int x = (int)(row % w2o) - 1, y = (int)((row / w2o) % h2o) - 1, b = (int)(row / ((size_t)w2o * h2o));
             if (x >= 0 && x < Wo && y >= 0 && y < Ho) {
                 live = true;
-                const float* p = in + (((size_t)b * (Hi + 2) + (y >> up) + 1) * w2i + (x >> up) + 1) * C + 8 * c8;
+                const float* p = in + (((size_t)b * Hi + (y >> up)) * Wi + (x >> up)) * C + 8 * c8;
                 const f32x4 a0 = *reinterpret_cast<const f32x4*>(p), a1 = *reinterpret_cast<const f32x4*>(p + 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[e] = a0[e]; v[4 + e] = a1[e]; }
@@ -120,18 +117,18 @@ __global__ __launch_bounds__(256) void prep_planes_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------- AttnBlock core
-// qkv: padded rows [M][3C] (q | k | v), N = H W tokens per image.  out: padded rows [M][C] (frame rows zero):
+// qkv: rows [B N][3C] (q | k | v), N = H W tokens per image.  out: rows [B N][C]:
 //     out[i] = sum_j softmax_j(q_i . k_j / sqrt(C)) v_j                         basic_vae.py:92-101
 // Workgroup = 16 queries of one image, 256 threads.  Scores: thread = key (N <= 256 per pass), q broadcast from LDS;
 // output: thread = channel (C <= 768), probabilities broadcast from LDS.
 constexpr int VA_QT = 16;
 __global__ __launch_bounds__(256) void vae_attn_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, int H, int W) {
     extern __shared__ __attribute__((aligned(16))) float vsm[];
-    const int N = H * W, w2 = W + 2;
+    const int N = H * W;
     float* qs = vsm;                 // [VA_QT][C]
     float* ps = vsm + VA_QT * C;     // [VA_QT][N]
     const int b = blockIdx.y, q0 = blockIdx.x * VA_QT, tid = threadIdx.x;
-    auto row_of = [&](int tok) { return ((size_t)b * (H + 2) + tok / W + 1) * w2 + tok % W + 1; };
+    auto row_of = [&](int tok) { return (size_t)b * N + tok; };
     const float scale = 1.0f / sqrtf((float)C);
     for (int i = tid; i < VA_QT * C; i += 256) {
         const int qi = i / C, c = i - qi * C;
@@ -191,17 +188,13 @@ __global__ __launch_bounds__(256) void convout_partial_kernel(const float* __res
                                                               const float* __restrict__ beta, const float* __restrict__ wt /* [C][28]: k = tap*3+o */,
                                                               float* __restrict__ t, int B, int C, int H, int W) {
     __shared__ float tile[256 * 33];
-    const int w2 = W + 2, h2 = H + 2, cpg = C / 32;
-    const size_t M = (size_t)B * h2 * w2;
+    const int cpg = C / 32;
+    const size_t M = (size_t)B * H * W;
     const size_t r0 = (size_t)blockIdx.x * 256;
     const int tid = threadIdx.x;
     const size_t row = r0 + tid;
-    bool live = false; int b = 0;
-    if (row < M) {
-        const int xx = (int)(row % w2) - 1, y = (int)((row / w2) % h2) - 1;
-        b = (int)(row / ((size_t)w2 * h2));
-        live = xx >= 0 && xx < W && y >= 0 && y < H;
-    }
+    const bool live = row < M;
+    const int b = live ? (int)(row / ((size_t)H * W)) : 0;
     float acc[27];
 #pragma unroll
     for (int k = 0; k < 27; ++k) acc[k] = 0.f;
@@ -227,21 +220,22 @@ __global__ __launch_bounds__(256) void convout_partial_kernel(const float* __res
             }
         }
     }
-    if (row < M) {
+    if (live) {
 #pragma unroll
         for (int k = 0; k < 27; ++k) t[row * 28 + k] = acc[k];
     }
 }
 
 __global__ __launch_bounds__(256) void convout_gather_kernel(const float* __restrict__ t, const float* __restrict__ bias, float* __restrict__ img, int B, int H, int W) {
-    const int w2 = W + 2;
     const size_t total = (size_t)B * 3 * H * W;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int x = (int)(i % W), y = (int)((i / W) % H), o = (int)((i / ((size_t)W * H)) % 3), b = (int)(i / ((size_t)3 * W * H));
-        const size_t row = ((size_t)b * (H + 2) + y + 1) * w2 + x + 1;
         float acc = bias[o];
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) acc += t[(size_t)((long long)row + (tap / 3 - 1) * w2 + (tap % 3 - 1)) * 28 + tap * 3 + o];
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) acc += t[(((size_t)b * H + yy) * W + xx) * 28 + tap * 3 + o];
+        }
         img[i] = fminf(fmaxf(acc, -1.0f), 1.0f);
     }
 }
@@ -318,7 +312,7 @@ int sdvar_vae_create(const sdvar_vae_desc* desc, sdvar_vae_t** out) {
     for (int lv = desc->n_mult - 1; lv >= 0; --lv) {
         const int H = v->H0 << (desc->n_mult - 1 - lv), c = desc->ch * desc->ch_mult[lv];
         const int cm = c > cprev ? c : cprev;
-        const size_t M = (size_t)B * (H + 2) * (H + 2);
+        const size_t M = (size_t)B * H * H;
         const size_t cf = (lv == desc->n_mult - 1) ? (size_t)3 * cm : (size_t)cm;       // qkv rows at the attention level
         if (M * cf > fmax_) fmax_ = M * cf;
         if (plane_rows(B, H, H) * cm > pmax) pmax = plane_rows(B, H, H) * cm;
@@ -328,7 +322,7 @@ int sdvar_vae_create(const sdvar_vae_desc* desc, sdvar_vae_t** out) {
     v->ws_floats = (size_t)64 << 20;
     const int Hl = v->H0 << (desc->n_mult - 1);
     if (vmalloc(&v->fa, v->f_floats) || vmalloc(&v->fb, v->f_floats) || vmalloc(&v->fc, v->f_floats) || vmalloc(&v->p1, v->p1_elems) ||
-        vmalloc(&v->p2, v->p2_elems) || vmalloc(&v->ws, v->ws_floats) || vmalloc(&v->t27, (size_t)B * (Hl + 2) * (Hl + 2) * 28) ||
+        vmalloc(&v->p2, v->p2_elems) || vmalloc(&v->ws, v->ws_floats) || vmalloc(&v->t27, (size_t)B * Hl * Hl * 28) ||
         vmalloc(&v->stats, (size_t)B * 64) || vmalloc(&v->part, (size_t)B * 64 * 32 * 2)) {
         sdvar_vae_destroy(v);
         return SDVAR_ERR_HIP;
@@ -439,7 +433,7 @@ struct Runner {
     int H = 0;                               // current resolution (square)
     float *x, *h, *t;                        // residual stream, temporary, third buffer
 
-    size_t M() const { return (size_t)B * (H + 2) * (H + 2); }
+    size_t M() const { return (size_t)B * H * H; }
     int stats_of(const float* src, int C) {
         const int nch = H < 64 ? H : 64, rpc = (H + nch - 1) / nch, chunks = (H + rpc - 1) / rpc;
         hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, B), dim3(320), 0, s, src, v->part, C, H, H, rpc);
@@ -463,7 +457,7 @@ struct Runner {
     }
     int conv(const ConvW& c, const uint16_t* xp, size_t ops, size_t rows, int G, const float* res, float* out) {
         SDVAR_CHECK_ARG(M() * c.cout <= v->f_floats, "vae: activation buffer too small");
-        return conv_bf16x3(xp, ops, rows, G, c.wp, c.wps, c.bias, res, out, (int)M(), c.cout, c.cin, c.taps, H + 2, v->ws, v->ws_floats, 0, s);
+        return conv_bf16x3(xp, ops, rows, G, c.wp, c.wps, c.bias, res, out, B, H, H, c.cout, c.cin, c.taps, v->ws, v->ws_floats, 0, s);
     }
     int resblock(const ResW& r) {        // x <- shortcut(x) + conv2(silu(gn2(conv1(silu(gn1(x))))))          basic_vae.py:62-73
         size_t ops, rows; int G;
@@ -489,7 +483,6 @@ struct Runner {
         const size_t lds = ((size_t)VA_QT * C + (size_t)VA_QT * N) * sizeof(float);
         SDVAR_CHECK_ARG(lds <= 160 * 1024, "vae: attention tile of %zu bytes does not fit the LDS (C=%d, %d tokens)", lds, C, N);
         SDVAR_HIP(hipFuncSetAttribute((const void*)vae_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        SDVAR_HIP(hipMemsetAsync(t, 0, M() * C * sizeof(float), s));
         hipLaunchKernelGGL(vae_attn_kernel, dim3((N + VA_QT - 1) / VA_QT, B), dim3(256), lds, s, h, t, C, H, H);
         SDVAR_LAUNCH_CHECK();
         VAE_TRY(prep(t, C, nullptr, 0, 0, v->p1, v->p1_elems, &ops, &rows, &G));
@@ -558,9 +551,9 @@ int sdvar_op_vae_prep(const float* in, const float* stats, const float* gamma, c
     return SDVAR_OK;
 }
 int sdvar_op_conv_bf16x3(const uint16_t* x_planes, uint64_t x_plane_stride, uint64_t x_rows, int32_t x_row0, const uint16_t* w_planes, uint64_t w_plane_stride,
-                         const float* bias, const float* res, float* out, int32_t M, int32_t N, int32_t Cin, int32_t taps, int32_t row_pitch, float* workspace,
+                         const float* bias, const float* res, float* out, int32_t B, int32_t H, int32_t W, int32_t N, int32_t Cin, int32_t taps, float* workspace,
                          uint64_t workspace_floats, int32_t force_split, void* stream) {
-    return conv_bf16x3(x_planes, (size_t)x_plane_stride, (size_t)x_rows, x_row0, w_planes, (size_t)w_plane_stride, bias, res, out, M, N, Cin, taps, row_pitch, workspace,
+    return conv_bf16x3(x_planes, (size_t)x_plane_stride, (size_t)x_rows, x_row0, w_planes, (size_t)w_plane_stride, bias, res, out, B, H, W, N, Cin, taps, workspace,
                        (size_t)workspace_floats, force_split, (hipStream_t)stream);
 }
 

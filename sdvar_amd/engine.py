@@ -81,7 +81,7 @@ _SIGNATURES = {
     "sdvar_op_attention": (_I, [_P, _P, _P, _I, _P, _P, _U64, _I, _I, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), _P]),
     "sdvar_op_conv_weight_planes": (_I, [_P, _P, _I, _I, _I, _U64, _P]),
     "sdvar_op_vae_prep": (_I, [_P, _P, _P, _P, _P, _U64, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "sdvar_op_conv_bf16x3": (_I, [_P, _U64, _U64, _I, _P, _U64, _P, _P, _P, _I, _I, _I, _I, _I, _P, _U64, _I, _P]),
+    "sdvar_op_conv_bf16x3": (_I, [_P, _U64, _U64, _I, _P, _U64, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _U64, _I, _P]),
     "sdvar_op_noise_fill": (_I, [_P, _I, _I, _I, _U64, _U32, _U32, _P]),
     "sdvar_debug_set_gemm_cfg": (_I, [_I, _I]),
     "sdvar_debug_set_gemm_stamps": (_I, [_P]),

@@ -1,10 +1,10 @@
-"""VQVAE parameter container + image decoder with the reference's state_dict layout.
+"""VQVAE parameter container with the reference's state_dict layout.
 
-Only the quantizer tensors (codebook, shared Phi convs) are on the HIP hot path (sdvar_amd/csrc/quant.hip).  The conv
-decoder `fhat_to_img` (/root/reference/models/vqvae.py:62-63, models/basic_vae.py:163-226) is the "next" row of the scope
-table: it runs on PyTorch-ROCm (MIOpen) here.  Module/parameter names follow the upstream
-checkpoint `vae_ch160v4096z32.pth` so it loads unchanged; the encoder is kept as parameters only (it is never run in
-sampling).
+The quantizer tensors (codebook, shared Phi convs) feed sdvar_amd/csrc/quant.hip; the conv decoder `fhat_to_img`
+(/root/reference/models/vqvae.py:62-63, models/basic_vae.py:163-226) runs as hand-written HIP
+(csrc/conv.hip, csrc/vae.hip) through engine.VaeCtx.  The nn.Module graph below exists for the parameter names - they follow
+the upstream checkpoint `vae_ch160v4096z32.pth` so it loads unchanged - and as the PyTorch reference the GPU parity tests
+compare against (`fhat_to_img_torch`); the sampler never runs it.  The encoder is parameters only (sampling never encodes).
 """
 from __future__ import annotations
 
@@ -145,6 +145,7 @@ class VQVAE(nn.Module):
         self.V = self.vocab_size = vocab_size
         self.Cvae = z_channels
         ch_mult, nrb = (1, 1, 2, 2, 4), 2
+        self._ch_mult, self._nrb, self._hip_ctx = ch_mult, nrb, None
         if with_encoder:
             self.encoder = Encoder(ch, ch_mult, nrb, z_channels)
         self.decoder = Decoder(ch, ch_mult, nrb, z_channels)
@@ -159,10 +160,33 @@ class VQVAE(nn.Module):
 
     @torch.no_grad()
     def fhat_to_img(self, f_hat: torch.Tensor) -> torch.Tensor:      # vqvae.py:62-63
+        """(B, Cvae, h, w) -> (B, 3, 16h, 16w) in [-1, 1] on the HIP decoder.  GPU tensors only: there is no CPU path."""
+        from . import engine as E
+        if not f_hat.is_cuda:
+            raise E.SdvarError("VQVAE.fhat_to_img runs on the HIP decoder and needs a GPU tensor (fhat_to_img_torch is the PyTorch test reference)")
+        B, hw = f_hat.shape[0], f_hat.shape[-1]
+        ctx = self._hip_ctx
+        if ctx is None or ctx.device != f_hat.device or ctx.max_batch < B or ctx.latent_hw != hw:
+            if ctx is not None:
+                ctx.close()
+            sd = {k: v for k, v in self.state_dict().items() if k.startswith(("decoder.", "post_quant_conv."))}
+            ctx = self._hip_ctx = E.VaeCtx(sd, B, f_hat.device, latent_hw=hw, ch_mult=self._ch_mult, num_res_blocks=self._nrb)
+        return ctx.decode(f_hat)
+
+    def refresh_hip(self):
+        """Drop the HIP decoder's copy of the weights (call after changing decoder parameters in place)."""
+        if self._hip_ctx is not None:
+            self._hip_ctx.close()
+        self._hip_ctx = None
+
+    @torch.no_grad()
+    def fhat_to_img_torch(self, f_hat: torch.Tensor) -> torch.Tensor:
+        """The same function on PyTorch ops (MIOpen on a GPU): test reference only."""
         return self.decoder(self.post_quant_conv(f_hat)).clamp_(-1, 1)
 
     def load_state_dict(self, state_dict, strict=True, assign=False):  # vqvae.py:92-95
         key = "quantize.ema_vocab_hit_SV"
         if key in state_dict and state_dict[key].shape[0] != self.quantize.ema_vocab_hit_SV.shape[0]:
             state_dict[key] = self.quantize.ema_vocab_hit_SV
+        self.refresh_hip()
         return super().load_state_dict(state_dict, strict=strict, assign=assign)

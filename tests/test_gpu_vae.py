@@ -32,12 +32,12 @@ def _p(t):
 
 
 def _rows(x):
-    """(B, C, H, W) -> padded pixel rows (B (H+2) (W+2), C)"""
-    return F.pad(x, (1, 1, 1, 1)).permute(0, 2, 3, 1).reshape(-1, x.shape[1]).contiguous()
+    """(B, C, H, W) -> channel-last rows (B H W, C)"""
+    return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).contiguous()
 
 
 def _unrows(r, B, H, W):
-    return r.view(B, H + 2, W + 2, -1)[:, 1:-1, 1:-1].permute(0, 3, 1, 2)
+    return r.view(B, H, W, -1).permute(0, 3, 1, 2)
 
 
 def _guard(W):
@@ -54,7 +54,7 @@ def test_conv_matches_torch(dev, B, Cin, Cout, H, taps, res, split):
     k = 3 if taps == 9 else 1
     w = (rnd(2, (Cout, Cin, k, k)) / (Cin * taps) ** 0.5).to(dev); b = rnd(3, (Cout,), 0.1).to(dev)
     r = rnd(4, (B, Cout, H, W)).to(dev) if res else None
-    G = _guard(W); M = B * (H + 2) * (W + 2); R = M + 2 * G
+    G = _guard(W); M = B * H * W; R = B * (H + 2) * (W + 2) + 2 * G
     xp = torch.full((3, Cin // 32, R, 32), 0x7FC0, dtype=torch.int16, device=dev)          # NaN patterns: every row must be written
     E._check(lib.sdvar_op_vae_prep(_p(_rows(x)), None, None, None, _p(xp), (Cin // 32) * R * 32, B, Cin, H, W, 0, 0, G, _st()))
     wp = torch.zeros(3, taps * Cin // 32, Cout, 32, dtype=torch.int16, device=dev)
@@ -62,7 +62,7 @@ def test_conv_matches_torch(dev, B, Cin, Cout, H, taps, res, split):
     out = torch.empty(M, Cout, device=dev)
     ws = torch.empty(max(split, 1) * M * Cout, device=dev)
     rr = _rows(r) if res else None
-    E._check(lib.sdvar_op_conv_bf16x3(_p(xp), (Cin // 32) * R * 32, R, G, _p(wp), taps * Cin * Cout, _p(b), _p(rr), _p(out), M, Cout, Cin, taps, W + 2,
+    E._check(lib.sdvar_op_conv_bf16x3(_p(xp), (Cin // 32) * R * 32, R, G, _p(wp), taps * Cin * Cout, _p(b), _p(rr), _p(out), B, H, W, Cout, Cin, taps,
                                       _p(ws), ws.numel(), split, _st()))
     want = F.conv2d(x.double(), w.double(), b.double(), padding=k // 2) + (r.double() if res else 0)
     got = _unrows(out, B, H, W).double()
@@ -114,7 +114,7 @@ def _decode_pair(dev, ch, B, latent=16, seed=11):
 def test_decoder_small_width_matches_pytorch(dev):
     vae, ctx, f_hat = _decode_pair(dev, 32, 3)
     got = ctx.decode(f_hat)
-    want = vae.fhat_to_img(f_hat.clone())
+    want = vae.fhat_to_img_torch(f_hat.clone())
     assert got.shape == want.shape == (3, 3, 256, 256)
     err = (got - want).abs().max().item()
     assert err <= 1e-4, err
@@ -127,7 +127,7 @@ def test_decoder_reference_width_matches_pytorch(dev):
     """vae_ch160v4096z32 geometry (the checkpoint the reference loads): ch = 160, widths 640/320/160, 256^2 output."""
     vae, ctx, f_hat = _decode_pair(dev, 160, 2)
     got = ctx.decode(f_hat)
-    want = vae.fhat_to_img(f_hat.clone())
+    want = vae.fhat_to_img_torch(f_hat.clone())
     err = (got - want).abs().max().item()
     assert err <= 1e-4, err
     assert float(got.min()) >= -1.0 and float(got.max()) <= 1.0
@@ -139,3 +139,13 @@ def test_decoder_rejects_bad_shapes(dev):
         ctx.decode(torch.zeros(2, 32, 16, 16, device=dev))                      # exceeds max_batch
     with pytest.raises(E.SdvarError):
         ctx.decode(torch.zeros(1, 32, 8, 8, device=dev))
+
+
+def test_module_entry_point_uses_the_hip_decoder(dev):
+    """VQVAE.fhat_to_img (the call VAR.autoregressive_infer_cfg makes, var.py:215) == engine.VaeCtx.decode; CPU tensors are refused."""
+    vae, ctx, f_hat = _decode_pair(dev, 32, 2)
+    got = vae.fhat_to_img(f_hat)
+    assert torch.equal(got, ctx.decode(f_hat))
+    assert (got - vae.fhat_to_img_torch(f_hat.clone())).abs().max().item() <= 1e-4
+    with pytest.raises(E.SdvarError):
+        vae.fhat_to_img(f_hat.cpu())
