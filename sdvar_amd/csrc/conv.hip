@@ -36,6 +36,7 @@ struct ConvArgs {
     int x_row0;                                    // G
     const float* bias; const float* res; float* out;
     int M, N, cb, taps, ih, iw, ldo, split, k_per_split;   // cb = Cin / 32; K-steps = taps * cb; (ih, iw): image size, M = B ih iw
+    double* gn_part; int cpg;                      // optional GroupNorm partial sums of the OUTPUT: [M/256][32 groups][sum, sumsq], cpg = N / 32
 };
 
 template <int EPI>
@@ -177,6 +178,37 @@ __global__ __launch_bounds__(512, 2) void conv_bf16x3_kernel(ConvArgs a) {
             float v = acc[j][r] + bv;
             if (EPI == CEPI_BIAS_RES) v += rv[j][r];
             outp[(size_t)m * a.ldo + n] = v;
+            acc[j][r] = v;
+        }
+    }
+    // GroupNorm statistics of the tile just written (the next layer's norm): per column sum / sum of squares over the 256 rows
+    // (all of one image: the host enables this only when H W is a multiple of 256), reduced lane -> wave -> workgroup through
+    // LDS in a fixed order, then per group in fp64.  Saves a full read of the activation tensor per normalisation.
+    if (EPI != CEPI_PARTIAL && a.gn_part) {
+        float* red = reinterpret_cast<float*>(csm);          // [2][8][160]
+        __syncthreads();                                     // every wave is done with the operand stages
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            float s1 = 0.f, s2 = 0.f;
+            if (n0 + j * 32 + li < a.N) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s1 += acc[j][r]; s2 += acc[j][r] * acc[j][r]; }
+            }
+            const auto w1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(s1), __float_as_uint(s1), false, false);
+            const auto w2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(s2), __float_as_uint(s2), false, false);
+            if (lh == 0) {
+                red[wave * 160 + j * 32 + li] = __uint_as_float(w1[0]) + __uint_as_float(w1[1]);
+                red[1280 + wave * 160 + j * 32 + li] = __uint_as_float(w2[0]) + __uint_as_float(w2[1]);
+            }
+        }
+        __syncthreads();
+        const int gl = tid, col0 = gl * a.cpg;
+        if (col0 < CBN && n0 + col0 < a.N) {
+            double a1 = 0.0, a2 = 0.0;
+            for (int w = 0; w < 8; ++w)
+                for (int c = 0; c < a.cpg; ++c) { a1 += (double)red[w * 160 + col0 + c]; a2 += (double)red[1280 + w * 160 + col0 + c]; }
+            double* o = a.gn_part + ((size_t)tm * 32 + (n0 + col0) / a.cpg) * 2;
+            o[0] = a1; o[1] = a2;
         }
     }
 }
@@ -236,8 +268,11 @@ static int conv_choose_split(int M, int N, int nkt, size_t ws_floats) {
 }
 
 // out[B H W][N] = conv(X planes of a (B, Cin, H, W) tensor, W planes) + bias (+ res[B H W][N]).  taps = 9: 3x3, pad 1; taps = 1: 1x1.
+// gn_part (optional): receives the GroupNorm partial sums of the output, [B H W / 256][32][2] doubles, when the shape allows the fused
+// epilogue (no split-K, H W a multiple of 256, 32 groups that tile the 160-column workgroup tile); *gn_done tells whether it was written.
 int conv_bf16x3(const uint16_t* X, size_t xps, size_t x_rows, int x_row0, const uint16_t* W, size_t wps, const float* bias, const float* res, float* out,
-                int B, int H, int Wd, int N, int Cin, int taps, float* ws, size_t ws_floats, int force_split, hipStream_t stream) {
+                int B, int H, int Wd, int N, int Cin, int taps, float* ws, size_t ws_floats, int force_split, double* gn_part, int* gn_done, hipStream_t stream) {
+    if (gn_done) *gn_done = 0;
     const int M = B * H * Wd, w2 = Wd + 2;
     const size_t Mp = (size_t)B * (H + 2) * w2;
     SDVAR_CHECK_ARG(X && W && out, "conv: null operand");
@@ -245,7 +280,7 @@ int conv_bf16x3(const uint16_t* X, size_t xps, size_t x_rows, int x_row0, const 
     SDVAR_CHECK_ARG(B > 0 && H > 0 && Wd > 0 && x_row0 >= w2 + 1, "conv: guard rows %d < row pitch %d + 1", x_row0, w2);
     SDVAR_CHECK_ARG(x_rows >= (size_t)x_row0 + Mp + w2 + 1, "conv: plane rows %zu too few", x_rows);
     SDVAR_CHECK_ARG(((uintptr_t)X % 16) == 0 && ((uintptr_t)W % 16) == 0 && xps % 8 == 0 && wps % 8 == 0, "conv: planes must be 16-byte aligned");
-    ConvArgs a{X, W, xps, wps, x_rows, x_row0, bias, res, out, M, N, Cin / 32, taps, H, Wd, N, 1, taps * (Cin / 32)};
+    ConvArgs a{X, W, xps, wps, x_rows, x_row0, bias, res, out, M, N, Cin / 32, taps, H, Wd, N, 1, taps * (Cin / 32), nullptr, 1};
     const int nkt = taps * (Cin / 32);
     const int tiles = ((M + CBM - 1) / CBM) * ((N + CBN - 1) / CBN);
     int split = force_split > 0 ? force_split : conv_choose_split(M, N, nkt, ws ? ws_floats : 0);
@@ -275,6 +310,7 @@ int conv_bf16x3(const uint16_t* X, size_t xps, size_t x_rows, int x_row0, const 
         SDVAR_LAUNCH_CHECK();
         return SDVAR_OK;
     }
+    if (gn_part && N % 32 == 0 && CBN % (N / 32) == 0 && (H * Wd) % CBM == 0) { a.gn_part = gn_part; a.cpg = N / 32; if (gn_done) *gn_done = 1; }
     if (res) hipLaunchKernelGGL((conv_bf16x3_kernel<CEPI_BIAS_RES>), dim3(tiles), dim3(512), lds, stream, a);
     else hipLaunchKernelGGL((conv_bf16x3_kernel<CEPI_BIAS>), dim3(tiles), dim3(512), lds, stream, a);
     SDVAR_LAUNCH_CHECK();

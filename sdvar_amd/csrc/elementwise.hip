@@ -201,27 +201,40 @@ __global__ __launch_bounds__(256) void qk_norm_append_planes_kernel(const float*
     const int C = H * 64;
     const size_t head = ((size_t)r * H + h) * 3 * (size_t)Lp * 64, ps = (size_t)Lp * 64;
     const float sm = expf(fminf(scale_mul[h], 4.605170249938965f));
-    for (int pos = pb + wave; pos < pe; pos += 4) {
-        const int t = pos - pos0;
-        const size_t row = (size_t)r * l + t;
-        float q, k, v;
-        if (pend.ws) {
-            const size_t slab = (size_t)R * l * 3 * C, o = row * 3 * C + h * 64 + lane;
-            q = pend.ws[o]; k = pend.ws[o + C]; v = pend.ws[o + 2 * C];
-            for (int s = 1; s < pend.split; ++s) { q += pend.ws[s * slab + o]; k += pend.ws[s * slab + o + C]; v += pend.ws[s * slab + o + 2 * C]; }
-            q += pend.bias[h * 64 + lane]; k += pend.bias[C + h * 64 + lane]; v += pend.bias[2 * C + h * 64 + lane];
-        } else {
-            const float* p = qkv + row * 3 * C + h * 64 + lane;
-            q = p[0]; k = p[C]; v = p[2 * C];
+    // wave w owns positions pb + w, + 4, ...; four of them are in flight at a time (their loads - up to 3 x split slab reads
+    // each - are independent, the wave reductions are not the bottleneck)
+    for (int pos4 = pb + wave; pos4 < pe; pos4 += 16) {
+        float q[4], k[4], v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int pos = pos4 + 4 * u;
+            q[u] = k[u] = v[u] = 0.f;
+            if (pos >= pe) continue;
+            const size_t row = (size_t)r * l + (pos - pos0);
+            if (pend.ws) {
+                const size_t slab = (size_t)R * l * 3 * C, o = row * 3 * C + h * 64 + lane;
+                q[u] = pend.ws[o]; k[u] = pend.ws[o + C]; v[u] = pend.ws[o + 2 * C];
+                for (int s = 1; s < pend.split; ++s) { q[u] += pend.ws[s * slab + o]; k[u] += pend.ws[s * slab + o + C]; v[u] += pend.ws[s * slab + o + 2 * C]; }
+                q[u] += pend.bias[h * 64 + lane]; k[u] += pend.bias[C + h * 64 + lane]; v[u] += pend.bias[2 * C + h * 64 + lane];
+            } else {
+                const float* p = qkv + row * 3 * C + h * 64 + lane;
+                q[u] = p[0]; k[u] = p[C]; v[u] = p[2 * C];
+            }
         }
-        const float qn = fmaxf(sqrtf(wave_sum(q * q)), 1e-12f);
-        const float kn = fmaxf(sqrtf(wave_sum(k * k)), 1e-12f);
-        q_out[(((size_t)r * H + h) * l + t) * 64 + lane] = (q / qn) * sm;
-        uint16_t k0, k1, k2;
-        split3(k / kn, k0, k1, k2);
-        uint16_t* pk = k_cache + head + (size_t)pos * 64 + lane;
-        pk[0] = k0; pk[ps] = k1; pk[2 * ps] = k2;
-        vs[(pos - P0) * 65 + lane] = v;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int pos = pos4 + 4 * u;
+            if (pos >= pe) continue;
+            const int t = pos - pos0;
+            const float qn = fmaxf(sqrtf(wave_sum(q[u] * q[u])), 1e-12f);
+            const float kn = fmaxf(sqrtf(wave_sum(k[u] * k[u])), 1e-12f);
+            q_out[(((size_t)r * H + h) * l + t) * 64 + lane] = (q[u] / qn) * sm;
+            uint16_t k0, k1, k2;
+            split3(k[u] / kn, k0, k1, k2);
+            uint16_t* pk = k_cache + head + (size_t)pos * 64 + lane;
+            pk[0] = k0; pk[ps] = k1; pk[2 * ps] = k2;
+            vs[(pos - P0) * 65 + lane] = v[u];
+        }
     }
     __syncthreads();
     // thread -> (channel row d, run c of 8 cache positions): positions P0 + 8c .. +7 hold keys P0 + 16 (c >> 1) + 4 (c & 1) + {0..3, 8..11}

@@ -20,7 +20,7 @@ namespace sdvar {
 
 int conv_weight_planes(const float* w, uint16_t* planes, int Cout, int Cin, int taps, size_t plane_stride, hipStream_t stream);
 int conv_bf16x3(const uint16_t* X, size_t xps, size_t x_rows, int x_row0, const uint16_t* W, size_t wps, const float* bias, const float* res, float* out,
-                int B, int H, int Wd, int N, int Cin, int taps, float* ws, size_t ws_floats, int force_split, hipStream_t stream);
+                int B, int H, int Wd, int N, int Cin, int taps, float* ws, size_t ws_floats, int force_split, double* gn_part, int* gn_done, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------------- layout helpers
 // (B, C, H, W) fp32 -> channel-last rows [B H W][C]
@@ -119,64 +119,107 @@ __global__ __launch_bounds__(256) void prep_planes_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------------------- AttnBlock core
 // qkv: rows [B N][3C] (q | k | v), N = H W tokens per image.  out: rows [B N][C]:
 //     out[i] = sum_j softmax_j(q_i . k_j / sqrt(C)) v_j                         basic_vae.py:92-101
-// Workgroup = 16 queries of one image, 256 threads.  Scores: thread = key (N <= 256 per pass), q broadcast from LDS;
-// output: thread = channel (C <= 768), probabilities broadcast from LDS.
-constexpr int VA_QT = 16;
-__global__ __launch_bounds__(256) void vae_attn_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, int H, int W) {
+// Workgroup = 16 queries of one image, 256 threads, fp32 FMA with 4 x 4 register blocking:
+//   scores   thread = (4 queries, 4 keys of a 256-key pass); q and k are staged through LDS in 32-channel slabs, transposed
+//            ([channel][query], [channel][key]) so that one ds_read_b128 each feeds 16 FMAs
+//   softmax  one wave per 4 queries over the [key][query] score array in LDS
+//   output   thread = (4 queries, 4 channels); v rows are read straight from global memory (coalesced), p from LDS
+constexpr int VA_QT = 16, VA_SP = VA_QT + 4;     // score rows padded to 20 floats (16-byte aligned rows)
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void vae_attn_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, int N) {
     extern __shared__ __attribute__((aligned(16))) float vsm[];
-    const int N = H * W;
-    float* qs = vsm;                 // [VA_QT][C]
-    float* ps = vsm + VA_QT * C;     // [VA_QT][N]
+    float* ks = vsm;                       // [32][256]
+    float* qs = vsm + 32 * 256;            // [32][VA_QT]
+    float* ps = qs + 32 * VA_QT;           // [N][VA_SP]
     const int b = blockIdx.y, q0 = blockIdx.x * VA_QT, tid = threadIdx.x;
-    auto row_of = [&](int tok) { return (size_t)b * N + tok; };
+    const int tq = tid >> 6, tk = tid & 63;
+    const float* base = qkv + (size_t)b * N * 3 * C;
     const float scale = 1.0f / sqrtf((float)C);
-    for (int i = tid; i < VA_QT * C; i += 256) {
-        const int qi = i / C, c = i - qi * C;
-        qs[i] = (q0 + qi < N) ? qkv[row_of(q0 + qi) * 3 * C + c] : 0.f;
-    }
-    __syncthreads();
-    for (int j = tid; j < N; j += 256) {
-        const float* kp = qkv + row_of(j) * 3 * C + C;
-        float acc[VA_QT];
+    for (int k0 = 0; k0 < N; k0 += 256) {
+        f32x2v acc[4][2];
 #pragma unroll
-        for (int qi = 0; qi < VA_QT; ++qi) acc[qi] = 0.f;
-        for (int c = 0; c < C; c += 4) {
-            const f32x4 kv = *reinterpret_cast<const f32x4*>(kp + c);
+        for (int i = 0; i < 4; ++i) { acc[i][0] = f32x2v{0.f, 0.f}; acc[i][1] = f32x2v{0.f, 0.f}; }
+        for (int c0 = 0; c0 < C; c0 += 32) {
+            __syncthreads();
 #pragma unroll
-            for (int qi = 0; qi < VA_QT; ++qi) {
-                const f32x4 qv = *reinterpret_cast<const f32x4*>(qs + qi * C + c);
-                acc[qi] += (qv[0] * kv[0] + qv[1] * kv[1]) + (qv[2] * kv[2] + qv[3] * kv[3]);
+            for (int it = 0; it < 8; ++it) {           // k slab: thread = key, 8 x float4 along the channels
+                const int key = k0 + tid;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (key < N) v = *reinterpret_cast<const f32x4*>(base + (size_t)key * 3 * C + C + c0 + 4 * it);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ks[(4 * it + e) * 256 + tid] = v[e];
+            }
+            if (tid < 128) {                          // q slab
+                const int qi = tid >> 3, c4 = tid & 7;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (q0 + qi < N) v = *reinterpret_cast<const f32x4*>(base + (size_t)(q0 + qi) * 3 * C + c0 + 4 * c4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qs[(4 * c4 + e) * VA_QT + qi] = v[e];
+            }
+            __syncthreads();
+#pragma unroll 8
+            for (int c = 0; c < 32; ++c) {
+                const f32x4 kv = *reinterpret_cast<const f32x4*>(ks + c * 256 + 4 * tk);
+                const f32x4 qv = *reinterpret_cast<const f32x4*>(qs + c * VA_QT + 4 * tq);
+                const f32x2v k01 = {kv[0], kv[1]}, k23 = {kv[2], kv[3]};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f32x2v qq = {qv[i], qv[i]};
+                    acc[i][0] = __builtin_elementwise_fma(qq, k01, acc[i][0]);
+                    acc[i][1] = __builtin_elementwise_fma(qq, k23, acc[i][1]);
+                }
             }
         }
 #pragma unroll
-        for (int qi = 0; qi < VA_QT; ++qi) ps[qi * N + j] = acc[qi] * scale;
+        for (int kk = 0; kk < 4; ++kk) {
+            const int key = k0 + 4 * tk + kk;
+            if (key < N) {
+                f32x4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = acc[i][kk >> 1][kk & 1] * scale;
+                *reinterpret_cast<f32x4*>(ps + key * VA_SP + 4 * tq) = o;
+            }
+        }
     }
     __syncthreads();
-    {   // softmax rows: wave w owns queries 4w .. 4w+3
+    {   // softmax over the keys: wave w owns queries 4w .. 4w+3
         const int lane = tid & 63, wave = tid >> 6;
         for (int qi = 4 * wave; qi < 4 * wave + 4; ++qi) {
             float m = -INFINITY;
-            for (int j = lane; j < N; j += 64) m = fmaxf(m, ps[qi * N + j]);
+            for (int j = lane; j < N; j += 64) m = fmaxf(m, ps[j * VA_SP + qi]);
             m = wave_max(m);
-            float s = 0.f;
-            for (int j = lane; j < N; j += 64) { const float e = expf(ps[qi * N + j] - m); ps[qi * N + j] = e; s += e; }
-            s = wave_sum(s);
-            const float inv = 1.0f / s;
-            for (int j = lane; j < N; j += 64) ps[qi * N + j] *= inv;
+            float sum = 0.f;
+            for (int j = lane; j < N; j += 64) { const float e = expf(ps[j * VA_SP + qi] - m); ps[j * VA_SP + qi] = e; sum += e; }
+            sum = wave_sum(sum);
+            const float inv = 1.0f / sum;
+            for (int j = lane; j < N; j += 64) ps[j * VA_SP + qi] *= inv;
         }
     }
     __syncthreads();
-    for (int c = tid; c < C; c += 256) {
-        float acc[VA_QT];
+    const int nq4 = C >> 2;                             // channel quads
+    for (int item = tid; item < 4 * nq4; item += 256) {
+        const int g = item / nq4, cq = item - g * nq4;  // query group, channel quad: consecutive threads read consecutive channels
+        f32x2v acc[4][2];
 #pragma unroll
-        for (int qi = 0; qi < VA_QT; ++qi) acc[qi] = 0.f;
+        for (int i = 0; i < 4; ++i) { acc[i][0] = f32x2v{0.f, 0.f}; acc[i][1] = f32x2v{0.f, 0.f}; }
+        const float* vp = base + 2 * C + 4 * cq;
+#pragma unroll 4
         for (int j = 0; j < N; ++j) {
-            const float v = qkv[row_of(j) * 3 * C + 2 * C + c];
+            const f32x4 vv = *reinterpret_cast<const f32x4*>(vp + (size_t)j * 3 * C);
+            const f32x4 pv = *reinterpret_cast<const f32x4*>(ps + j * VA_SP + 4 * g);
+            const f32x2v v01 = {vv[0], vv[1]}, v23 = {vv[2], vv[3]};
 #pragma unroll
-            for (int qi = 0; qi < VA_QT; ++qi) acc[qi] += ps[qi * N + j] * v;
+            for (int i = 0; i < 4; ++i) {
+                const f32x2v pp = {pv[i], pv[i]};
+                acc[i][0] = __builtin_elementwise_fma(pp, v01, acc[i][0]);
+                acc[i][1] = __builtin_elementwise_fma(pp, v23, acc[i][1]);
+            }
         }
 #pragma unroll
-        for (int qi = 0; qi < VA_QT; ++qi) if (q0 + qi < N) out[row_of(q0 + qi) * C + c] = acc[qi];
+        for (int i = 0; i < 4; ++i) {
+            const int qi = q0 + 4 * g + i;
+            if (qi < N) *reinterpret_cast<f32x4*>(out + ((size_t)b * N + qi) * C + 4 * cq) = f32x4{acc[i][0][0], acc[i][0][1], acc[i][1][0], acc[i][1][1]};
+        }
     }
 }
 
@@ -323,7 +366,7 @@ int sdvar_vae_create(const sdvar_vae_desc* desc, sdvar_vae_t** out) {
     const int Hl = v->H0 << (desc->n_mult - 1);
     if (vmalloc(&v->fa, v->f_floats) || vmalloc(&v->fb, v->f_floats) || vmalloc(&v->fc, v->f_floats) || vmalloc(&v->p1, v->p1_elems) ||
         vmalloc(&v->p2, v->p2_elems) || vmalloc(&v->ws, v->ws_floats) || vmalloc(&v->t27, (size_t)B * Hl * Hl * 28) ||
-        vmalloc(&v->stats, (size_t)B * 64) || vmalloc(&v->part, (size_t)B * 64 * 32 * 2)) {
+        vmalloc(&v->stats, (size_t)B * 64) || vmalloc(&v->part, (size_t)B * ((size_t)Hl * Hl / 256 + 64) * 32 * 2)) {
         sdvar_vae_destroy(v);
         return SDVAR_ERR_HIP;
     }
@@ -433,11 +476,21 @@ struct Runner {
     int H = 0;                               // current resolution (square)
     float *x, *h, *t;                        // residual stream, temporary, third buffer
 
+    const float* stats_src = nullptr;        // tensor whose GroupNorm partial sums the last convolution left in v->part ...
+    int stats_chunks = 0;                    // ... as this many 256-row chunks per image
+
     size_t M() const { return (size_t)B * H * H; }
     int stats_of(const float* src, int C) {
-        const int nch = H < 64 ? H : 64, rpc = (H + nch - 1) / nch, chunks = (H + rpc - 1) / rpc;
-        hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, B), dim3(320), 0, s, src, v->part, C, H, H, rpc);
-        SDVAR_LAUNCH_CHECK();
+        int chunks;
+        if (src == stats_src) {
+            chunks = stats_chunks;           // fused in the producing convolution's epilogue
+        } else {
+            const int nch = H < 64 ? H : 64, rpc = (H + nch - 1) / nch;
+            chunks = (H + rpc - 1) / rpc;
+            hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, B), dim3(320), 0, s, src, v->part, C, H, H, rpc);
+            SDVAR_LAUNCH_CHECK();
+        }
+        stats_src = nullptr;
         hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(32), 0, s, v->part, v->stats, chunks, (double)H * H * (C / 32), 1e-6);
         SDVAR_LAUNCH_CHECK();
         return SDVAR_OK;
@@ -457,7 +510,10 @@ struct Runner {
     }
     int conv(const ConvW& c, const uint16_t* xp, size_t ops, size_t rows, int G, const float* res, float* out) {
         SDVAR_CHECK_ARG(M() * c.cout <= v->f_floats, "vae: activation buffer too small");
-        return conv_bf16x3(xp, ops, rows, G, c.wp, c.wps, c.bias, res, out, B, H, H, c.cout, c.cin, c.taps, v->ws, v->ws_floats, 0, s);
+        int done = 0;
+        VAE_TRY(conv_bf16x3(xp, ops, rows, G, c.wp, c.wps, c.bias, res, out, B, H, H, c.cout, c.cin, c.taps, v->ws, v->ws_floats, 0, v->part, &done, s));
+        stats_src = done ? out : nullptr; stats_chunks = H * H / 256;
+        return SDVAR_OK;
     }
     int resblock(const ResW& r) {        // x <- shortcut(x) + conv2(silu(gn2(conv1(silu(gn1(x))))))          basic_vae.py:62-73
         size_t ops, rows; int G;
@@ -480,11 +536,12 @@ struct Runner {
         VAE_TRY(prep(x, C, &a.n, 0, 0, v->p1, v->p1_elems, &ops, &rows, &G));
         VAE_TRY(conv(a.qkv, v->p1, ops, rows, G, nullptr, h));
         const int N = H * H;
-        const size_t lds = ((size_t)VA_QT * C + (size_t)VA_QT * N) * sizeof(float);
-        SDVAR_CHECK_ARG(lds <= 160 * 1024, "vae: attention tile of %zu bytes does not fit the LDS (C=%d, %d tokens)", lds, C, N);
+        const size_t lds = ((size_t)32 * 256 + 32 * VA_QT + (size_t)N * VA_SP) * sizeof(float);
+        SDVAR_CHECK_ARG(lds <= 160 * 1024 && C % 32 == 0, "vae: attention tile of %zu bytes does not fit the LDS (C=%d, %d tokens)", lds, C, N);
         SDVAR_HIP(hipFuncSetAttribute((const void*)vae_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(vae_attn_kernel, dim3((N + VA_QT - 1) / VA_QT, B), dim3(256), lds, s, h, t, C, H, H);
+        hipLaunchKernelGGL(vae_attn_kernel, dim3((N + VA_QT - 1) / VA_QT, B), dim3(256), lds, s, h, t, C, N);
         SDVAR_LAUNCH_CHECK();
+        if (stats_src == t) stats_src = nullptr;
         VAE_TRY(prep(t, C, nullptr, 0, 0, v->p1, v->p1_elems, &ops, &rows, &G));
         VAE_TRY(conv(a.proj, v->p1, ops, rows, G, x, x));
         return SDVAR_OK;
@@ -554,7 +611,7 @@ int sdvar_op_conv_bf16x3(const uint16_t* x_planes, uint64_t x_plane_stride, uint
                          const float* bias, const float* res, float* out, int32_t B, int32_t H, int32_t W, int32_t N, int32_t Cin, int32_t taps, float* workspace,
                          uint64_t workspace_floats, int32_t force_split, void* stream) {
     return conv_bf16x3(x_planes, (size_t)x_plane_stride, (size_t)x_rows, x_row0, w_planes, (size_t)w_plane_stride, bias, res, out, B, H, W, N, Cin, taps, workspace,
-                       (size_t)workspace_floats, force_split, (hipStream_t)stream);
+                       (size_t)workspace_floats, force_split, nullptr, nullptr, (hipStream_t)stream);
 }
 
 }  // extern "C"
