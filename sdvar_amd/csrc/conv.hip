@@ -37,6 +37,8 @@ struct ConvArgs {
     const float* bias; const float* res; float* out;
     int M, N, cb, taps, ih, iw, ldo, split, k_per_split;   // cb = Cin / 32; K-steps = taps * cb; (ih, iw): image size, M = B ih iw
     double* gn_part; int cpg;                      // optional GroupNorm partial sums of the OUTPUT: [M/256][32 groups][sum, sumsq], cpg = N / 32
+    int up_phase;                                  // >= 0: fused nearest-2x up-sampling (taps = 4): blockIdx.y = output phase (py, px) = (y >> 1, y & 1)
+    size_t w_phase_stride;                         //       weight planes of phase p at W + p * w_phase_stride
 };
 
 template <int EPI>
@@ -50,6 +52,8 @@ __global__ __launch_bounds__(512, 2) void conv_bf16x3_kernel(ConvArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
+    const int phase = a.up_phase >= 0 ? (int)blockIdx.y : 0;
+    const uint16_t* Wp = a.W + (size_t)phase * a.w_phase_stride;
 
     // DMA: per plane wave w fills X rows [32w, 32w+32) (two 16-row groups) and W rows [16w, 16w+16) (+ [128 + 16w, ..) for w < 2)
     const int r16 = lane >> 2;
@@ -65,14 +69,15 @@ __global__ __launch_bounds__(512, 2) void conv_bf16x3_kernel(ConvArgs a) {
     };
     const uint16_t* sx0 = a.X + ((size_t)a.x_row0 + prow(min(m0 + xr0, a.M - 1))) * 32 + 8 * cx0;
     const uint16_t* sx1 = a.X + ((size_t)a.x_row0 + prow(min(m0 + xr1, a.M - 1))) * 32 + 8 * cx1;
-    const uint16_t* sw0 = a.W + (size_t)min(n0 + wr0, a.N - 1) * 32 + 8 * cw0;
-    const uint16_t* sw1 = a.W + (size_t)min(n0 + wr1, a.N - 1) * 32 + 8 * cw1;
+    const uint16_t* sw0 = Wp + (size_t)min(n0 + wr0, a.N - 1) * 32 + 8 * cw0;
+    const uint16_t* sw1 = Wp + (size_t)min(n0 + wr1, a.N - 1) * 32 + 8 * cw1;
     const bool two_w = wave < 2;
     // K-step t (global index kt0 + t) = (tap, channel block): X offset = (cblk x_rows + tap shift) rows, W offset = (kt0 + t) N rows
     long long xoff = 0; size_t woff = 0;
     auto set_step = [&](int t) {
         const int kb = kt0 + t, tap = kb / a.cb, c = kb - tap * a.cb;
-        const int shift = (a.taps == 9) ? (tap / 3 - 1) * w2 + (tap % 3 - 1) : 0;
+        const int shift = (a.taps == 9) ? (tap / 3 - 1) * w2 + (tap % 3 - 1)
+                        : (a.taps == 4) ? ((tap >> 1) - 1 + (phase >> 1)) * w2 + ((tap & 1) - 1 + (phase & 1)) : 0;
         xoff = ((long long)c * (long long)a.x_rows + shift) * 32;
         woff = (size_t)kb * a.N * 32;
     };
@@ -177,7 +182,12 @@ __global__ __launch_bounds__(512, 2) void conv_bf16x3_kernel(ConvArgs a) {
             if (m >= a.M) continue;
             float v = acc[j][r] + bv;
             if (EPI == CEPI_BIAS_RES) v += rv[j][r];
-            outp[(size_t)m * a.ldo + n] = v;
+            size_t orow = (size_t)m;
+            if (EPI != CEPI_PARTIAL && a.up_phase >= 0) {         // pixel (b, y, x) of the input grid -> (b, 2y + py, 2x + px) of the output grid
+                const int hw = a.ih * a.iw, b = m / hw, rem = m - b * hw, y = rem / a.iw, x = rem - y * a.iw;
+                orow = ((size_t)(b * 2 * a.ih + 2 * y + (phase >> 1)) * (2 * a.iw) + 2 * x + (phase & 1));
+            }
+            outp[orow * a.ldo + n] = v;
             acc[j][r] = v;
         }
     }
@@ -207,7 +217,7 @@ __global__ __launch_bounds__(512, 2) void conv_bf16x3_kernel(ConvArgs a) {
             double a1 = 0.0, a2 = 0.0;
             for (int w = 0; w < 8; ++w)
                 for (int c = 0; c < a.cpg; ++c) { a1 += (double)red[w * 160 + col0 + c]; a2 += (double)red[1280 + w * 160 + col0 + c]; }
-            double* o = a.gn_part + ((size_t)tm * 32 + (n0 + col0) / a.cpg) * 2;
+            double* o = a.gn_part + ((size_t)(a.up_phase >= 0 ? 4 * tm + phase : tm) * 32 + (n0 + col0) / a.cpg) * 2;
             o[0] = a1; o[1] = a2;
         }
     }
@@ -245,8 +255,33 @@ __global__ __launch_bounds__(256) void conv_weight_planes_kernel(const float* __
 }
 
 int conv_weight_planes(const float* w, uint16_t* planes, int Cout, int Cin, int taps, size_t plane_stride, hipStream_t stream) {
-    SDVAR_CHECK_ARG(w && planes && Cout > 0 && Cin % 32 == 0 && (taps == 1 || taps == 9), "conv_weight_planes: Cout=%d Cin=%d taps=%d", Cout, Cin, taps);
+    SDVAR_CHECK_ARG(w && planes && Cout > 0 && Cin % 32 == 0 && (taps == 1 || taps == 4 || taps == 9), "conv_weight_planes: Cout=%d Cin=%d taps=%d", Cout, Cin, taps);
     hipLaunchKernelGGL(conv_weight_planes_kernel, dim3(1024), dim3(256), 0, stream, w, planes, Cout, Cin, taps, plane_stride);
+    SDVAR_LAUNCH_CHECK();
+    return SDVAR_OK;
+}
+
+// Nearest-2x up-sampling followed by a 3x3 convolution (Upsample2x, basic_vae.py:24-30) = four 2x2 convolutions on the input grid, one per
+// output phase (py, px): output pixel (2y + py, 2x + px) reads input rows {y-1, y} (py = 0) or {y, y+1} (py = 1), and the 3x3 taps that land on
+// the same input pixel are summed: 16 instead of 36 multiply-adds per output pixel.  weff [4 phases][Cout][Cin][4 taps (ty, tx)].
+__global__ __launch_bounds__(256) void upconv_weight_kernel(const float* __restrict__ w, float* __restrict__ weff, int Cout, int Cin) {
+    const size_t total = (size_t)4 * Cout * Cin * 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int tap = (int)(i & 3), ty = tap >> 1, tx = tap & 1;
+        const size_t oc = (i >> 2) % ((size_t)Cout * Cin);
+        const int ph = (int)(i / ((size_t)4 * Cout * Cin)), py = ph >> 1, px = ph & 1;
+        // kernel rows (0..2 = dy -1..1) that map to input-row tap ty of phase py
+        const int y0 = py == 0 ? (ty == 0 ? 0 : 1) : (ty == 0 ? 0 : 2), y1 = py == 0 ? (ty == 0 ? 0 : 2) : (ty == 0 ? 1 : 2);
+        const int x0 = px == 0 ? (tx == 0 ? 0 : 1) : (tx == 0 ? 0 : 2), x1 = px == 0 ? (tx == 0 ? 0 : 2) : (tx == 0 ? 1 : 2);
+        float acc = 0.f;
+        for (int ky = y0; ky <= y1; ++ky)
+            for (int kx = x0; kx <= x1; ++kx) acc += w[oc * 9 + ky * 3 + kx];
+        weff[i] = acc;
+    }
+}
+
+int upconv_weights(const float* w, float* weff, int Cout, int Cin, hipStream_t stream) {
+    hipLaunchKernelGGL(upconv_weight_kernel, dim3(1024), dim3(256), 0, stream, w, weff, Cout, Cin);
     SDVAR_LAUNCH_CHECK();
     return SDVAR_OK;
 }
@@ -268,22 +303,25 @@ static int conv_choose_split(int M, int N, int nkt, size_t ws_floats) {
 }
 
 // out[B H W][N] = conv(X planes of a (B, Cin, H, W) tensor, W planes) + bias (+ res[B H W][N]).  taps = 9: 3x3, pad 1; taps = 1: 1x1.
+// up >= 0 (taps = 4, W = four phase weight sets from upconv_weights + conv_weight_planes, w_phase_stride elements apart): the convolution
+// of the nearest-2x up-sampled tensor, all four output phases in one launch, written into out[B 2H 2W][N].
 // gn_part (optional): receives the GroupNorm partial sums of the output, [B H W / 256][32][2] doubles, when the shape allows the fused
 // epilogue (no split-K, H W a multiple of 256, 32 groups that tile the 160-column workgroup tile); *gn_done tells whether it was written.
 int conv_bf16x3(const uint16_t* X, size_t xps, size_t x_rows, int x_row0, const uint16_t* W, size_t wps, const float* bias, const float* res, float* out,
-                int B, int H, int Wd, int N, int Cin, int taps, float* ws, size_t ws_floats, int force_split, double* gn_part, int* gn_done, hipStream_t stream) {
+                int B, int H, int Wd, int N, int Cin, int taps, float* ws, size_t ws_floats, int force_split, double* gn_part, int* gn_done, int up_phase,
+                size_t w_phase_stride, hipStream_t stream) {
     if (gn_done) *gn_done = 0;
     const int M = B * H * Wd, w2 = Wd + 2;
     const size_t Mp = (size_t)B * (H + 2) * w2;
     SDVAR_CHECK_ARG(X && W && out, "conv: null operand");
-    SDVAR_CHECK_ARG(M > 0 && N > 0 && Cin > 0 && Cin % 32 == 0 && (taps == 1 || taps == 9), "conv: M=%d N=%d Cin=%d taps=%d", M, N, Cin, taps);
+    SDVAR_CHECK_ARG(M > 0 && N > 0 && Cin > 0 && Cin % 32 == 0 && (taps == 1 || taps == 9 || (taps == 4 && up_phase >= 0)) && (taps == 4 || up_phase < 0), "conv: M=%d N=%d Cin=%d taps=%d", M, N, Cin, taps);
     SDVAR_CHECK_ARG(B > 0 && H > 0 && Wd > 0 && x_row0 >= w2 + 1, "conv: guard rows %d < row pitch %d + 1", x_row0, w2);
     SDVAR_CHECK_ARG(x_rows >= (size_t)x_row0 + Mp + w2 + 1, "conv: plane rows %zu too few", x_rows);
     SDVAR_CHECK_ARG(((uintptr_t)X % 16) == 0 && ((uintptr_t)W % 16) == 0 && xps % 8 == 0 && wps % 8 == 0, "conv: planes must be 16-byte aligned");
-    ConvArgs a{X, W, xps, wps, x_rows, x_row0, bias, res, out, M, N, Cin / 32, taps, H, Wd, N, 1, taps * (Cin / 32), nullptr, 1};
+    ConvArgs a{X, W, xps, wps, x_rows, x_row0, bias, res, out, M, N, Cin / 32, taps, H, Wd, N, 1, taps * (Cin / 32), nullptr, 1, up_phase, w_phase_stride};
     const int nkt = taps * (Cin / 32);
     const int tiles = ((M + CBM - 1) / CBM) * ((N + CBN - 1) / CBN);
-    int split = force_split > 0 ? force_split : conv_choose_split(M, N, nkt, ws ? ws_floats : 0);
+    int split = up_phase >= 0 ? 1 : force_split > 0 ? force_split : conv_choose_split(M, N, nkt, ws ? ws_floats : 0);
     if (split > nkt) split = nkt;
     if (split > 1) {
         SDVAR_CHECK_ARG(ws && (size_t)split * M * N <= ws_floats && N % 4 == 0, "conv: split-K workspace too small");
@@ -312,7 +350,7 @@ int conv_bf16x3(const uint16_t* X, size_t xps, size_t x_rows, int x_row0, const 
     }
     if (gn_part && N % 32 == 0 && CBN % (N / 32) == 0 && (H * Wd) % CBM == 0) { a.gn_part = gn_part; a.cpg = N / 32; if (gn_done) *gn_done = 1; }
     if (res) hipLaunchKernelGGL((conv_bf16x3_kernel<CEPI_BIAS_RES>), dim3(tiles), dim3(512), lds, stream, a);
-    else hipLaunchKernelGGL((conv_bf16x3_kernel<CEPI_BIAS>), dim3(tiles), dim3(512), lds, stream, a);
+    else hipLaunchKernelGGL((conv_bf16x3_kernel<CEPI_BIAS>), dim3(tiles, up_phase >= 0 ? 4 : 1), dim3(512), lds, stream, a);
     SDVAR_LAUNCH_CHECK();
     return SDVAR_OK;
 }

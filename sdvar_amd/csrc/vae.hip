@@ -20,7 +20,8 @@ namespace sdvar {
 
 int conv_weight_planes(const float* w, uint16_t* planes, int Cout, int Cin, int taps, size_t plane_stride, hipStream_t stream);
 int conv_bf16x3(const uint16_t* X, size_t xps, size_t x_rows, int x_row0, const uint16_t* W, size_t wps, const float* bias, const float* res, float* out,
-                int B, int H, int Wd, int N, int Cin, int taps, float* ws, size_t ws_floats, int force_split, double* gn_part, int* gn_done, hipStream_t stream);
+                int B, int H, int Wd, int N, int Cin, int taps, float* ws, size_t ws_floats, int force_split, double* gn_part, int* gn_done, int up_phase, size_t w_phase_stride, hipStream_t stream);
+int upconv_weights(const float* w, float* weff, int Cout, int Cin, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------------- layout helpers
 // (B, C, H, W) fp32 -> channel-last rows [B H W][C]
@@ -62,10 +63,15 @@ __global__ __launch_bounds__(320) void gn_partial_kernel(const float* __restrict
     }
 }
 
-__global__ void gn_finalize_kernel(const double* __restrict__ part, float* __restrict__ stats, int nchunk, double count, double eps) {
-    const int b = blockIdx.x, g = threadIdx.x;      // 32 threads
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ part, float* __restrict__ stats, int nchunk, double count, double eps) {
+    __shared__ double sm[2][8][32];
+    const int b = blockIdx.x, g = threadIdx.x & 31, sl = threadIdx.x >> 5;      // 8 slices of the chunk list per group, combined in slice order
     double a = 0.0, a2 = 0.0;
-    for (int c = 0; c < nchunk; ++c) { const double* p = part + (((size_t)b * nchunk + c) * 32 + g) * 2; a += p[0]; a2 += p[1]; }
+    for (int c = sl; c < nchunk; c += 8) { const double* p = part + (((size_t)b * nchunk + c) * 32 + g) * 2; a += p[0]; a2 += p[1]; }
+    sm[0][sl][g] = a; sm[1][sl][g] = a2;
+    __syncthreads();
+    if (sl) return;
+    for (int i = 1; i < 8; ++i) { a += sm[0][i][g]; a2 += sm[1][i][g]; }
     const double mean = a / count, var = fmax(a2 / count - mean * mean, 0.0);
     stats[((size_t)b * 32 + g) * 2] = (float)mean;
     stats[((size_t)b * 32 + g) * 2 + 1] = (float)(1.0 / sqrt(var + eps));
@@ -306,11 +312,11 @@ int vmalloc(T** p, size_t n) {
 }
 #define VAE_TRY(call) do { int rc_ = (call); if (rc_ != SDVAR_OK) return rc_; } while (0)
 
-struct ConvW { uint16_t* wp = nullptr; size_t wps = 0; const float* bias = nullptr; int cin = 0, cout = 0, taps = 0; };
+struct ConvW { uint16_t* wp = nullptr; size_t wps = 0; const float* bias = nullptr; int cin = 0, cout = 0, taps = 0; };   // taps = 4: four phase weight sets, 3 wps apart
 struct NormW { const float* gamma = nullptr; const float* beta = nullptr; int C = 0; };
 struct ResW { NormW n1, n2; ConvW c1, c2, sc; bool has_sc = false; };
 struct AttnW { NormW n; ConvW qkv, proj; };
-struct Level { std::vector<ResW> blocks; std::vector<AttnW> attns; ConvW up; bool has_up = false; };
+struct Level { std::vector<ResW> blocks; std::vector<AttnW> attns; ConvW up, up9; bool has_up = false; };   // up: 4 phase convs; up9: the plain 3x3 form
 
 }  // namespace
 
@@ -402,6 +408,22 @@ struct Binder {
         const int r = conv_weight_planes(w, p, cout, cin, taps, c.wps, s);
         if (r) rc = r;
     }
+    void upconv(ConvW& c, ConvW& c9, int ch) {          // Upsample2x conv: four 2x2 phase convolutions (conv.hip upconv_weights) + the plain 3x3 form
+        const int save = pos;
+        conv(c9, ch, ch, 9);
+        pos = save;
+        const float* w = next(); const float* b = next();
+        if (rc || !w || !b) { rc = SDVAR_ERR_ARG; return; }
+        c.cin = ch; c.cout = ch; c.taps = 4; c.bias = b;
+        c.wps = (size_t)4 * ch * ch;
+        uint16_t* p = nullptr; float* weff = nullptr;
+        if (hipMalloc((void**)&p, 4 * 3 * c.wps * sizeof(uint16_t)) != hipSuccess || hipMalloc((void**)&weff, 4 * c.wps * sizeof(float)) != hipSuccess) { rc = SDVAR_ERR_HIP; return; }
+        v->owned.push_back(p); v->owned.push_back(weff);
+        c.wp = p;
+        int r = upconv_weights(w, weff, ch, ch, s);
+        for (int ph = 0; ph < 4 && !r; ++ph) r = conv_weight_planes(weff + ph * c.wps, p + (size_t)ph * 3 * c.wps, ch, ch, 4, c.wps, s);
+        if (r) rc = r;
+    }
     void norm(NormW& nw, int C) { nw.gamma = next(); nw.beta = next(); nw.C = C; if (!nw.gamma || !nw.beta) rc = SDVAR_ERR_ARG; }
     void res(ResW& r, int cin, int cout) {
         norm(r.n1, cin); conv(r.c1, cin, cout, 9); norm(r.n2, cout); conv(r.c2, cout, cout, 9);
@@ -453,7 +475,7 @@ int sdvar_vae_bind(sdvar_vae_t* v, const float* const* tensors, int32_t n_tensor
             if (lv == d.n_mult - 1) { AttnW a; b.attn(a, c); L.attns.push_back(a); }
         }
         L.has_up = lv != 0;
-        if (L.has_up) b.conv(L.up, c, c, 9);
+        if (L.has_up) b.upconv(L.up, L.up9, c);
         v->levels.push_back(L);
     }
     b.norm(v->norm_out, cprev);
@@ -491,7 +513,7 @@ struct Runner {
             SDVAR_LAUNCH_CHECK();
         }
         stats_src = nullptr;
-        hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(32), 0, s, v->part, v->stats, chunks, (double)H * H * (C / 32), 1e-6);
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, s, v->part, v->stats, chunks, (double)H * H * (C / 32), 1e-6);
         SDVAR_LAUNCH_CHECK();
         return SDVAR_OK;
     }
@@ -511,7 +533,7 @@ struct Runner {
     int conv(const ConvW& c, const uint16_t* xp, size_t ops, size_t rows, int G, const float* res, float* out) {
         SDVAR_CHECK_ARG(M() * c.cout <= v->f_floats, "vae: activation buffer too small");
         int done = 0;
-        VAE_TRY(conv_bf16x3(xp, ops, rows, G, c.wp, c.wps, c.bias, res, out, B, H, H, c.cout, c.cin, c.taps, v->ws, v->ws_floats, 0, v->part, &done, s));
+        VAE_TRY(conv_bf16x3(xp, ops, rows, G, c.wp, c.wps, c.bias, res, out, B, H, H, c.cout, c.cin, c.taps, v->ws, v->ws_floats, 0, v->part, &done, -1, 0, s));
         stats_src = done ? out : nullptr; stats_chunks = H * H / 256;
         return SDVAR_OK;
     }
@@ -576,9 +598,20 @@ int sdvar_vae_decode(sdvar_vae_t* v, const float* f_hat, int32_t B, float* img, 
             if (i < L.attns.size()) VAE_TRY(r.attnblock(L.attns[i]));
         }
         if (L.has_up) {                                                                    // Upsample2x: conv(interpolate(x, 2, nearest))
-            VAE_TRY(r.prep(r.x, L.up.cin, nullptr, 0, 1, v->p1, v->p1_elems, &ops, &rows, &G));
-            r.H <<= 1;
-            VAE_TRY(r.conv(L.up, v->p1, ops, rows, G, nullptr, r.h));
+            const long tiles4 = 4 * (long)((r.M() + 255) / 256) * ((L.up.cout + 159) / 160);
+            if (tiles4 >= 128) {                                                           // as four 2x2 phase convolutions on the input grid, one launch
+                VAE_TRY(r.prep(r.x, L.up.cin, nullptr, 0, 0, v->p1, v->p1_elems, &ops, &rows, &G));
+                SDVAR_CHECK_ARG(4 * r.M() * L.up.cout <= v->f_floats, "vae: activation buffer too small");
+                int done = 0;
+                VAE_TRY(conv_bf16x3(v->p1, ops, rows, G, L.up.wp, L.up.wps, L.up.bias, nullptr, r.h, B, r.H, r.H, L.up.cout, L.up.cin, 4, nullptr, 0, 0, v->part, &done, 0,
+                                    3 * L.up.wps, s));
+                r.stats_src = done ? r.h : nullptr; r.stats_chunks = 4 * (r.H * r.H / 256);
+                r.H <<= 1;
+            } else {                                                                       // too few tiles: 3x3 on the up-sampled planes, split along K
+                VAE_TRY(r.prep(r.x, L.up9.cin, nullptr, 0, 1, v->p1, v->p1_elems, &ops, &rows, &G));
+                r.H <<= 1;
+                VAE_TRY(r.conv(L.up9, v->p1, ops, rows, G, nullptr, r.h));
+            }
             float* tmp = r.x; r.x = r.h; r.h = tmp;
         }
     }
@@ -611,7 +644,7 @@ int sdvar_op_conv_bf16x3(const uint16_t* x_planes, uint64_t x_plane_stride, uint
                          const float* bias, const float* res, float* out, int32_t B, int32_t H, int32_t W, int32_t N, int32_t Cin, int32_t taps, float* workspace,
                          uint64_t workspace_floats, int32_t force_split, void* stream) {
     return conv_bf16x3(x_planes, (size_t)x_plane_stride, (size_t)x_rows, x_row0, w_planes, (size_t)w_plane_stride, bias, res, out, B, H, W, N, Cin, taps, workspace,
-                       (size_t)workspace_floats, force_split, nullptr, nullptr, (hipStream_t)stream);
+                       (size_t)workspace_floats, force_split, nullptr, nullptr, -1, 0, (hipStream_t)stream);
 }
 
 }  // extern "C"
