@@ -80,8 +80,15 @@ __device__ __forceinline__ void ln_row_finish(const f32x4* v, int lane, int row,
 __device__ __forceinline__ f32x4 pending_residual(const PendingSplitK& pend, f32x4 xv, int row, int idx, int rows, int C) {
     const size_t slab = (size_t)rows * C, o = (size_t)row * C + 4 * idx;
     f32x4 acc = *reinterpret_cast<const f32x4*>(pend.ws + o);
-    for (int k = 1; k < pend.split; ++k) {
-        const f32x4 p = *reinterpret_cast<const f32x4*>(pend.ws + k * slab + o);
+    int k = 1;
+    for (; k + 3 < pend.split; k += 4) {          // four slab loads in flight, added in slice order
+        const f32x4 p0 = *reinterpret_cast<const f32x4*>(pend.ws + (size_t)k * slab + o), p1 = *reinterpret_cast<const f32x4*>(pend.ws + (size_t)(k + 1) * slab + o);
+        const f32x4 p2 = *reinterpret_cast<const f32x4*>(pend.ws + (size_t)(k + 2) * slab + o), p3 = *reinterpret_cast<const f32x4*>(pend.ws + (size_t)(k + 3) * slab + o);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = (((acc[e] + p0[e]) + p1[e]) + p2[e]) + p3[e];
+    }
+    for (; k < pend.split; ++k) {
+        const f32x4 p = *reinterpret_cast<const f32x4*>(pend.ws + (size_t)k * slab + o);
         acc[0] += p[0]; acc[1] += p[1]; acc[2] += p[2]; acc[3] += p[3];
     }
     const f32x4 bb = *reinterpret_cast<const f32x4*>(pend.bias + 4 * idx);
