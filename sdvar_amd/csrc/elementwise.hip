@@ -32,6 +32,14 @@ __device__ __forceinline__ void ln_row_finish(const f32x4* v, int lane, int row,
                                               float* __restrict__ out, uint16_t* __restrict__ outp, size_t ops, int rows, int C, int rows_per_img,
                                               int mod_stride, float eps) {
     const int nv = C >> 2;
+    // modulation vectors first: their load latency overlaps the two wave reductions (these launches are latency-bound at small M)
+    const size_t mo = (size_t)(row / rows_per_img) * mod_stride;
+    const f32x4* psc = reinterpret_cast<const f32x4*>(scale + mo);
+    const f32x4* psh = reinterpret_cast<const f32x4*>(shift + mo);
+    f32x4 scv[LN_MAX_V4], shv[LN_MAX_V4];
+#pragma unroll
+    for (int i = 0; i < LN_MAX_V4; ++i)
+        if (lane + 64 * i < nv) { scv[i] = psc[lane + 64 * i]; shv[i] = psh[lane + 64 * i]; }
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < LN_MAX_V4; ++i)
@@ -47,15 +55,12 @@ __device__ __forceinline__ void ln_row_finish(const f32x4* v, int lane, int row,
         }
     }
     const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)C + eps);
-    const size_t mo = (size_t)(row / rows_per_img) * mod_stride;
-    const f32x4* psc = reinterpret_cast<const f32x4*>(scale + mo);
-    const f32x4* psh = reinterpret_cast<const f32x4*>(shift + mo);
     f32x4* po = reinterpret_cast<f32x4*>(out + (size_t)row * C);
 #pragma unroll
     for (int i = 0; i < LN_MAX_V4; ++i) {
         const int idx = lane + 64 * i;
         if (idx < nv) {
-            const f32x4 sc = psc[idx], sh = psh[idx];
+            const f32x4 sc = scv[i], sh = shv[i];
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = ((v[i][e] - mean) * rstd) * (sc[e] + 1.0f) + sh[e];

@@ -265,6 +265,22 @@ class VaeCtx:
             d.ch_mult[i] = m
         self.desc, self.max_batch, self.latent_hw, self.z = d, max_batch, latent_hw, z
         self.out_hw = latent_hw << (len(ch_mult) - 1)
+        names = self.tensor_names(vae_sd, ch_mult, num_res_blocks)
+        self.tensors = []                                   # keeps the device copies alive: biases and GroupNorm affine stay borrowed
+        for n in names:
+            self.tensors += [_f32(vae_sd[n + ".weight"], self.device), _f32(vae_sd[n + ".bias"], self.device)]
+        want = self.lib.sdvar_vae_tensor_count(C.byref(d))
+        if want != len(self.tensors):
+            raise SdvarError(f"VQVAE decoder layout mismatch: the library expects {want} tensors, the state_dict walk found {len(self.tensors)}")
+        self.h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _check(self.lib.sdvar_vae_create(C.byref(d), C.byref(self.h)))
+            arr = (_P * len(self.tensors))(*[t.data_ptr() for t in self.tensors])
+            _check(self.lib.sdvar_vae_bind(self.h, arr, len(self.tensors), _stream()))
+
+    @staticmethod
+    def tensor_names(vae_sd, ch_mult: Sequence[int] = (1, 1, 2, 2, 4), num_res_blocks: int = 2):
+        """Module prefixes (each contributes .weight then .bias) in the order sdvar_vae_bind consumes them (include/sdvar_hip.h)."""
         names = ["post_quant_conv", "decoder.conv_in"]
         res = lambda p, sc: [p + ".norm1", p + ".conv1", p + ".norm2", p + ".conv2"] + ([p + ".nin_shortcut"] if sc else [])
         att = lambda p: [p + ".norm", p + ".qkv", p + ".proj_out"]
@@ -277,18 +293,7 @@ class VaeCtx:
                     names += att(f"decoder.up.{lv}.attn.{i}")
             if lv != 0:
                 names.append(f"decoder.up.{lv}.upsample.conv")
-        names += ["decoder.norm_out", "decoder.conv_out"]
-        self.tensors = []                                   # keeps the device copies alive: biases and GroupNorm affine stay borrowed
-        for n in names:
-            self.tensors += [_f32(vae_sd[n + ".weight"], self.device), _f32(vae_sd[n + ".bias"], self.device)]
-        want = self.lib.sdvar_vae_tensor_count(C.byref(d))
-        if want != len(self.tensors):
-            raise SdvarError(f"VQVAE decoder layout mismatch: the library expects {want} tensors, the state_dict walk found {len(self.tensors)}")
-        self.h = C.c_void_p()
-        with torch.cuda.device(self.device):
-            _check(self.lib.sdvar_vae_create(C.byref(d), C.byref(self.h)))
-            arr = (_P * len(self.tensors))(*[t.data_ptr() for t in self.tensors])
-            _check(self.lib.sdvar_vae_bind(self.h, arr, len(self.tensors), _stream()))
+        return names + ["decoder.norm_out", "decoder.conv_out"]
 
     def decode(self, f_hat: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """f_hat (B, Cvae, h, w) fp32 on the device -> image (B, 3, H, W) in [-1, 1]; runs on torch's current stream."""

@@ -54,3 +54,23 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f"{f} imports the oracle"
+
+
+def test_vae_bind_order_matches_the_state_dict_walk():
+    """sdvar_vae_tensor_count (host logic of csrc/vae.hip) == the tensors engine.VaeCtx would hand to sdvar_vae_bind, and every name
+    exists in the decoder's state_dict (the key set of vae_ch160v4096z32.pth)."""
+    import ctypes as C
+    from sdvar_amd import engine as E
+    from sdvar_amd.weights import vae_state_dict
+    lib = E.load_library()
+    for ch in (160, 32):
+        sd = vae_state_dict((1, 2, 3, 4, 5, 6, 8, 10, 13, 16), "perf", 1, ch=ch, with_encoder=False)
+        names = E.VaeCtx.tensor_names(sd)
+        assert all(n + ".weight" in sd and n + ".bias" in sd for n in names)
+        used = {n + s for n in names for s in (".weight", ".bias")}
+        assert used == {k for k in sd if k.startswith(("decoder.", "post_quant_conv."))}          # nothing of the decoder is left unbound
+        d = E._VaeDesc()
+        d.ch, d.z_channels, d.n_mult, d.num_res_blocks, d.max_batch, d.latent_hw = ch, 32, 5, 2, 1, 16
+        for i, m in enumerate((1, 1, 2, 2, 4)):
+            d.ch_mult[i] = m
+        assert lib.sdvar_vae_tensor_count(C.byref(d)) == 2 * len(names)
