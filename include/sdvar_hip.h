@@ -8,7 +8,9 @@
  * all work is enqueued on the caller's `stream` (a hipStream_t passed as void*, NULL = default stream) and returns
  * without synchronising; return value 0 = ok, otherwise see sdvar_last_error().  The library never owns caller
  * memory; the KV cache, adaLN table and workspaces it allocates itself are freed by the *_destroy calls.
- * One host thread per model object (same contract as the reference's module-attribute caches, basic_var.py:85-87).
+ * One host thread per model object (same contract as the reference's module-attribute caches, basic_var.py:85-87); different
+ * host threads may drive different objects on different streams concurrently (per-thread split-K workspaces, no shared mutable state
+ * outside the objects; the sdvar_debug_* / sdvar_prof_* switches are process-wide and meant for single-threaded tools).
  */
 #ifndef SDVAR_HIP_H
 #define SDVAR_HIP_H

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
-static float* g_ws = nullptr;                      // split-K slabs; one stream at a time per process (see sdvar_hip.h)
+static thread_local float* g_ws = nullptr;         // split-K slabs, one workspace per host thread (= per model object / stream: sdvar_hip.h)
 constexpr size_t WS_FLOATS = (size_t)24 << 20;     // 96 MiB
 
 float* splitk_workspace(size_t* floats) {          // shared with gemm_bf16x3.hip

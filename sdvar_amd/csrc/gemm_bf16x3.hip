@@ -561,7 +561,7 @@ static void choose_cfg_p(int M, int N, int K, size_t ws_floats, int* bm_out, int
     *bm_out = bbm; *split_out = bs;
 }
 
-static int* g_defer = nullptr;     // set per call by gemm_bf16x3_nt (single host thread per process uses the library)
+static thread_local int* g_defer = nullptr;     // set per call by gemm_bf16x3_nt; thread-local: host threads may drive different model objects concurrently
 static bool g_use_v2 = true;
 void debug_set_gemm_v2(int on) { g_use_v2 = on != 0; }
 

@@ -257,3 +257,42 @@ def test_sdvar_helper_methods_follow_the_reference_call_sequence(dev):
     c_o, lp_o, f_o = o.prologue(labels.cpu())
     assert torch.equal(cond.cpu(), c_o) and (lvl_pos.cpu() - lp_o).abs().max() == 0 and (first.cpu() - f_o).abs().max() <= 1e-6
     assert f0.shape == (B, 32, 16, 16) and f0.abs().sum() == 0
+
+
+def test_two_samplers_on_two_host_threads_and_streams(dev):
+    """Thread contract of include/sdvar_hip.h: different host threads may drive different model objects on different streams at the
+    same time (per-thread split-K workspaces).  Two speculative samplers + decoders run concurrently, repeatedly; each must reproduce
+    the ids and images it produces when run alone."""
+    import threading
+    pns = LADDER_256
+    sd_d, sd_v = state_dicts(2, pns, "stress", 7)
+    sd_t, _ = state_dicts(4, pns, "stress", 7)
+    sd_v = {k: v for k, v in sd_v.items()}
+    from sdvar_amd.weights import vae_state_dict
+    sd_dec = vae_state_dict(pns, "stress", 7, ch=32, with_encoder=False)
+    B = 2
+    jobs = []
+    for j in range(2):
+        dc, tc, qc = E.ModelCtx(sd_d, 2, pns, B, 1, dev, gemm_mode="bf16x3"), E.ModelCtx(sd_t, 4, pns, B, 2, dev, gemm_mode="bf16x3"), E.QuantCtx(sd_v, pns, B, dev)
+        jobs.append(dict(smp=E.Sampler(tc, qc, dc), dec=E.VaeCtx(sd_dec, B, dev), labels=torch.tensor([5 + j, 700 + j]).to(dev), seed=11 + j,
+                         stream=torch.cuda.Stream(device=dev), out=[]))
+
+    def run(job, reps):
+        with torch.cuda.stream(job["stream"]):
+            for _ in range(reps):
+                res = job["smp"].spec_decode(job["labels"], 1.5, 2, 900, 0.96, E.Noise("device", job["seed"]), thr=0.5)
+                img = job["dec"].decode(res.f_hat)
+                job["stream"].synchronize()
+                job["out"].append((res.ids.cpu().clone(), img.cpu().clone()))
+
+    for job in jobs:                       # alone
+        run(job, 1)
+    alone = [job["out"].pop() for job in jobs]
+    ts = [threading.Thread(target=run, args=(job, 4)) for job in jobs]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    for job, (ids0, img0) in zip(jobs, alone):
+        assert len(job["out"]) == 4
+        for ids, img in job["out"]:
+            assert torch.equal(ids, ids0)
+            assert torch.equal(img, img0)

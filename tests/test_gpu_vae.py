@@ -133,6 +133,16 @@ def test_decoder_reference_width_matches_pytorch(dev):
     assert float(got.min()) >= -1.0 and float(got.max()) <= 1.0
 
 
+def test_decoder_512_geometry(dev):
+    """BASELINE config P4 decodes 32x32 latents to 512^2: 1024-token attention blocks, 4x the rows everywhere."""
+    vae, ctx, f_hat = _decode_pair(dev, 32, 1, latent=32)
+    got = ctx.decode(f_hat)
+    want = vae.fhat_to_img_torch(f_hat.clone())
+    assert got.shape == want.shape == (1, 3, 512, 512)
+    err = (got - want).abs().max().item()
+    assert err <= 1e-4, err
+
+
 def test_decoder_rejects_bad_shapes(dev):
     _, ctx, f_hat = _decode_pair(dev, 32, 1)
     with pytest.raises(E.SdvarError):
