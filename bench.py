@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--no-extra-modes", action="store_true")
     ap.add_argument("--decode-high-prio", action="store_true", help="experiment: give the decode stream the higher HIP priority")
     ap.add_argument("--torch-decode", action="store_true", help="A/B: decode with the PyTorch/MIOpen reference decoder instead of the HIP decoder")
+    ap.add_argument("--no-run-ahead", action="store_true", help="keep the draft waiting for the verifier at gamma == 1 (every kernel alone on the GPU: profiling runs)")
     ap.add_argument("--serial-decode", action="store_true", help="decode on the sampling stream instead of overlapping it with the next batch")
     ap.add_argument("--gemm-mode", default=None, choices=["f32", "bf16x3"], help="default: sdvar_amd.engine.DEFAULT_GEMM_MODE")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark for the VQVAE decoder convs")
@@ -104,8 +105,9 @@ def main():
     dec_done = [None, None]
     state = {"i": 0, "img": None}
 
-    def step(mode, seed):
-        res = smp.spec_decode(labels, 1.5, args.gamma, 900, 0.96, E.Noise("device", seed, image_offset=lo), thr=thr[mode])
+    def step(mode, seed, run_ahead=None):
+        ra = (not args.no_run_ahead) if run_ahead is None else run_ahead
+        res = smp.spec_decode(labels, 1.5, args.gamma, 900, 0.96, E.Noise("device", seed, image_offset=lo), thr=thr[mode], run_ahead=ra)
         st = dict(res.stats); st["images"] = B
         if args.serial_decode:
             state["img"] = decode(res.f_hat).add_(1).mul_(0.5)                   # (B,3,256,256) in [0,1]  (var.py:215)
@@ -146,7 +148,7 @@ def main():
     def timed_nodecode(steps):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for i in range(steps):
-            smp.spec_decode(labels, 1.5, args.gamma, 900, 0.96, E.Noise("device", 2000 + i, image_offset=lo), thr=thr[args.mode])
+            smp.spec_decode(labels, 1.5, args.gamma, 900, 0.96, E.Noise("device", 2000 + i, image_offset=lo), thr=thr[args.mode], run_ahead=not args.no_run_ahead)
         torch.cuda.synchronize()
         return D.max_over_ranks(time.perf_counter() - t0, dev)
     nd_steps = max(2, args.steps // 2)
@@ -213,7 +215,7 @@ def main():
     # ---- roofline leg: HIP events around every launch of one step (launch stream = torch's current stream)
     drain(); torch.cuda.synchronize()
     E.prof_enable(True)
-    step(args.mode, 4242)
+    step(args.mode, 4242, run_ahead=False)       # per-kernel durations with each kernel alone on the GPU (no draft/verify overlap)
     drain(); torch.cuda.synchronize()
     prof = E.prof_collect()
     E.prof_enable(False)
@@ -254,12 +256,13 @@ def main():
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if tc.gemm_mode == "f32" else "f32 (GEMM operands split exactly into 3 bf16 planes, 6 bf16 MFMA products, fp32 accumulate)", "data": "synthetic (random-init weights, labels arange(B)%1000, device Philox noise)",
         "config": {"workload": f"VAR-d{args.depth_target} 256^2 B={B}/GPU, d{args.depth_draft} draft + d{args.depth_target} verify, gamma={args.gamma}, "
-                               f"cfg=1.5 top_k=900 top_p=0.96, acceptance={args.mode}, incl. VQVAE decode ({'serial' if args.serial_decode else 'overlapped with the next batch on a 2nd stream'})", "parallelism": f"{world} independent batch shards"},
+                               f"cfg=1.5 top_k=900 top_p=0.96, acceptance={args.mode}, incl. VQVAE decode ({'serial' if args.serial_decode else 'overlapped with the next batch on a 2nd stream'}); "
+                               f"verifier {'in lock-step with' if args.no_run_ahead else 'one round behind'} the draft once gamma = 1", "parallelism": f"{world} independent batch shards"},
         "mean_accepted_tokens_per_step": agg["mean_accepted_tokens_per_step"],
         "target_calls": agg["target_calls"], "draft_stage_calls": agg["draft_stage_calls"], "forced_accepts": agg["forced_accepts"],
         "images_per_s_no_decode": B * world * nd_steps / dt_nd,
         "decode_ms_per_batch": dec_ms, "decoder": "pytorch-miopen" if args.torch_decode else "hip (csrc/conv.hip, csrc/vae.hip)",
-        "modes": extra, "roofline": roofline, "roofline_verify_attention": roofline_attn, "kernel_class_ms_per_step": class_ms,
+        "modes": extra, "roofline_note": "roofline / kernel_class_ms_per_step come from one step with every kernel alone on the GPU (no draft/verify or decode overlap)", "roofline": roofline, "roofline_verify_attention": roofline_attn, "kernel_class_ms_per_step": class_ms,
     }
 
     # ---- CPU baseline (rank 0, N=1): the oracle's plain AR of the TARGET model on the host cores

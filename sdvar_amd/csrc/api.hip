@@ -17,6 +17,8 @@ int gemm_f32_nt(const float* X, int ldx, const float* W, const float* bias, floa
 struct PendingSplitK { const float* ws; const float* bias; const float* gate; int split, rows_per_gate, gate_stride; };
 int ln_modulate(float* x, const float* scale, const float* shift, float* out, uint16_t* outp, size_t ops, int rows, int C, int rows_per_img, int mod_stride, const PendingSplitK* pend, hipStream_t stream);
 float* splitk_workspace(size_t* floats);
+float* set_splitk_workspace(float* p);
+size_t splitk_workspace_floats();
 int qk_norm_append(const float* qkv, const float* scale_mul, float* q_out, void* k_cache, void* v_cache, int kv_f16, int R, int l, int H, int Lmax, int pos0, const PendingSplitK* pend, hipStream_t stream);
 int silu_rows(const float* x, float* y, int n, hipStream_t stream);
 int prologue(const long long* labels, const float* class_emb, const float* pos_start, const float* lvl_pos, float* cond, float* x0, int B, int C, int num_classes, hipStream_t stream);
@@ -69,6 +71,12 @@ struct ProfScope {
     }
 };
 
+struct WsScope {         // routes the split-K slabs of every GEMM below to the model's own workspace for the duration of a call
+    float* old;
+    explicit WsScope(float* p) : old(set_splitk_workspace(p)) {}
+    ~WsScope() { set_splitk_workspace(old); }
+};
+
 template <typename T>
 static int dmalloc(T** p, size_t n) {
     *p = nullptr;
@@ -93,6 +101,7 @@ struct sdvar_model {
     sdvar_model_desc d;
     int C, H, L, Rmax, lmax, S;
     int kv_fmt, Lkv;     // cache format handed to the kernels (0 fp32, 1 fp16, 2 planes) and its row capacity
+    float* ws_own = nullptr;   // this model's split-K slabs: two models of one host thread may run on different streams
     int lens[SDVAR_MAX_STAGES], cum[SDVAR_MAX_STAGES];
     // borrowed
     const float *class_emb, *pos_start, *word_w, *word_b, *nm_w, *nm_b, *head_w, *head_b;
@@ -199,13 +208,14 @@ int sdvar_model_create(const sdvar_model_desc* desc, sdvar_model_t** out) {
         SDVAR_HIP(hipMemset(b.kc, 0, kvb));        // the planes kernel streams whole 64-key tiles: rows past kv_len must be finite
         SDVAR_HIP(hipMemset(b.vc, 0, kvb));
     }
+    SDVAR_TRY(dmalloc(&m->ws_own, splitk_workspace_floats()));
     *out = m;
     return SDVAR_OK;
 }
 
 int sdvar_model_destroy(sdvar_model_t* m) {
     if (!m) return SDVAR_OK;
-    float* bufs[] = {m->lvl_pos, m->cond, m->cond_silu, m->x0, m->ada, m->ada_head, m->xn, m->qkv, m->qbuf, m->att, m->hid};
+    float* bufs[] = {m->lvl_pos, m->cond, m->cond_silu, m->x0, m->ada, m->ada_head, m->xn, m->qkv, m->qbuf, m->att, m->hid, m->ws_own};
     for (float* p : bufs) if (p) (void)hipFree(p);
     if (m->stage_of_tok) (void)hipFree(m->stage_of_tok);
     uint16_t* pb[] = {m->xn_p, m->att_p, m->hid_p, m->head_wp};
@@ -265,6 +275,7 @@ int sdvar_model_begin(sdvar_model_t* m, int32_t B, const int64_t* labels, void* 
     SDVAR_TRY(check_bound(m));
     SDVAR_CHECK_ARG(B >= 1 && B <= m->d.max_batch && labels, "model_begin: B=%d (max %d)", B, m->d.max_batch);
     hipStream_t s = (hipStream_t)stream;
+    WsScope wsg(m->ws_own);
     const int C = m->C, R = 2 * B;
     m->B = B; m->kv_len = 0;
     {
@@ -324,6 +335,7 @@ int sdvar_stage_forward(sdvar_model_t* m, float* x, int32_t s0, int32_t n, float
     SDVAR_CHECK_ARG(s0 >= 0 && n >= 1 && s0 + n <= m->S && n <= m->d.max_chunk_stages, "stage_forward: stages [%d,%d) invalid (S=%d, max chunk %d)", s0, s0 + n, m->S, m->d.max_chunk_stages);
     if (m->kv_len != begin_of(m, s0)) { set_error("stage_forward: KV cache holds %d keys, stage %d needs %d", m->kv_len, s0, begin_of(m, s0)); return SDVAR_ERR_STATE; }
     hipStream_t s = (hipStream_t)stream;
+    WsScope wsg(m->ws_own);
     const int C = m->C, H = m->H, R = 2 * m->B, V = m->d.vocab;
     int qbeg[SDVAR_MAX_STAGES], vis[SDVAR_MAX_STAGES], lsum = 0;
     double lk = 0;

@@ -179,8 +179,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 static thread_local float* g_ws = nullptr;         // split-K slabs, one workspace per host thread (= per model object / stream: sdvar_hip.h)
 constexpr size_t WS_FLOATS = (size_t)24 << 20;     // 96 MiB
 
+static thread_local float* g_ws_model = nullptr;   // a model object's own slabs while one of its calls is on the stack (api.hip)
+float* set_splitk_workspace(float* p) { float* old = g_ws_model; g_ws_model = p; return old; }
+size_t splitk_workspace_floats() { return WS_FLOATS; }
+
 float* splitk_workspace(size_t* floats) {          // shared with gemm_bf16x3.hip
     if (floats) *floats = WS_FLOATS;
+    if (g_ws_model) return g_ws_model;
     if (!g_ws && hipMalloc((void**)&g_ws, WS_FLOATS * sizeof(float)) != hipSuccess) { set_error("split-K workspace allocation failed"); return nullptr; }
     return g_ws;
 }
@@ -200,17 +205,18 @@ static int launch_cfg(GemmArgs a, int epi, int split, hipStream_t stream) {
     }
     const int nkt = a.K / BK;
     if (split > 1) {
-        if (!g_ws) SDVAR_HIP(hipMalloc((void**)&g_ws, WS_FLOATS * sizeof(float)));
+        float* const ws = splitk_workspace(nullptr);          // the calling model's slabs, or this thread's
+        if (!ws) return SDVAR_ERR_HIP;
         GemmArgs p = a;
-        p.out = g_ws; p.ldo = a.N; p.split = split; p.k_per_split = (nkt + split - 1) / split;
+        p.out = ws; p.ldo = a.N; p.split = split; p.k_per_split = (nkt + split - 1) / split;
         hipLaunchKernelGGL((gemm_f32_nt_kernel<BM, BN, WAVES_M, WAVES_N, EPI_PARTIAL>), dim3(tiles * split), block, lds, stream, p);
         SDVAR_LAUNCH_CHECK();
         const size_t total = (size_t)a.M * (a.N / 4);
         const int rgrid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
         switch (epi) {
-            case EPI_BIAS: hipLaunchKernelGGL(splitk_reduce_kernel<EPI_BIAS>, dim3(rgrid), block, 0, stream, g_ws, split, a.bias, a.out, a.res, a.gate, a.M, a.N, a.ldo, a.ldres, a.rows_per_gate, a.gate_stride); break;
-            case EPI_BIAS_GELU: hipLaunchKernelGGL(splitk_reduce_kernel<EPI_BIAS_GELU>, dim3(rgrid), block, 0, stream, g_ws, split, a.bias, a.out, a.res, a.gate, a.M, a.N, a.ldo, a.ldres, a.rows_per_gate, a.gate_stride); break;
-            default: hipLaunchKernelGGL(splitk_reduce_kernel<EPI_GATED_RES>, dim3(rgrid), block, 0, stream, g_ws, split, a.bias, a.out, a.res, a.gate, a.M, a.N, a.ldo, a.ldres, a.rows_per_gate, a.gate_stride); break;
+            case EPI_BIAS: hipLaunchKernelGGL(splitk_reduce_kernel<EPI_BIAS>, dim3(rgrid), block, 0, stream, ws, split, a.bias, a.out, a.res, a.gate, a.M, a.N, a.ldo, a.ldres, a.rows_per_gate, a.gate_stride); break;
+            case EPI_BIAS_GELU: hipLaunchKernelGGL(splitk_reduce_kernel<EPI_BIAS_GELU>, dim3(rgrid), block, 0, stream, ws, split, a.bias, a.out, a.res, a.gate, a.M, a.N, a.ldo, a.ldres, a.rows_per_gate, a.gate_stride); break;
+            default: hipLaunchKernelGGL(splitk_reduce_kernel<EPI_GATED_RES>, dim3(rgrid), block, 0, stream, ws, split, a.bias, a.out, a.res, a.gate, a.M, a.N, a.ldo, a.ldres, a.rows_per_gate, a.gate_stride); break;
         }
         SDVAR_LAUNCH_CHECK();
         return SDVAR_OK;

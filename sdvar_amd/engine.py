@@ -392,6 +392,8 @@ class Sampler:
         self.lmax_t = max(sum(lens[s:s + target.max_chunk]) for s in range(lad.S))
         f = dict(device=self.dev, dtype=torch.float32)
         self.x_t = torch.empty(2 * B * self.lmax_t * target.Cw, **f)
+        self._xt = [self.x_t, None]             # second target input buffer: allocated when the run-ahead path first needs it
+        self._verify_stream = None
         self.logits_t = torch.empty(2 * B * self.lmax_t * V, **f)
         if draft is not None:
             assert draft.lad.patch_nums == lad.patch_nums and draft.V == V
@@ -405,6 +407,7 @@ class Sampler:
         self.nxt = [torch.empty(B * lens[-1] * quant.Cv, **f) for _ in range(g)]
         self.nxt_cur = torch.empty(B * lens[-1] * quant.Cv, **f)
         self.counts = torch.zeros(40, device=self.dev, dtype=torch.int32)
+        self.counts_ra = torch.zeros(lad.S, 40, device=self.dev, dtype=torch.int32)
         self.counts_host = torch.zeros(40, dtype=torch.int32).pin_memory()
 
     # ---- VAR.autoregressive_infer_cfg (var.py:127-215) up to the decode
@@ -455,10 +458,11 @@ class Sampler:
         offs = [sum(st.glen[:j]) for j in range(g)]
         f_acc, f_work = self.f_acc[:B], self.f_work[:B]
         with torch.cuda.device(self.dev):
+            x_t = self._xt[st.xt_idx]
             if cur == 0:
-                d.place_first(self.x_d, lens[0]); t.place_first(self.x_t, lsum)
+                d.place_first(self.x_d, lens[0]); t.place_first(x_t, lsum)
             else:
-                d.embed_next(self.nxt_cur, cur, self.x_d, lens[cur], 0); t.embed_next(self.nxt_cur, cur, self.x_t, lsum, 0)
+                d.embed_next(self.nxt_cur, cur, self.x_d, lens[cur], 0); t.embed_next(self.nxt_cur, cur, x_t, lsum, 0)
             f_work.copy_(f_acc)
             for j in range(g):
                 s = cur + j
@@ -473,7 +477,7 @@ class Sampler:
                 self.f_snap[j][:B].copy_(f_work)
                 if j + 1 < g:
                     d.embed_next(self.nxt[j], s + 1, self.x_d, lens[s + 1], 0)
-                    t.embed_next(self.nxt[j], s + 1, self.x_t, lsum, offs[j + 1])
+                    t.embed_next(self.nxt[j], s + 1, x_t, lsum, offs[j + 1])
         st.drafted = True
         return g
 
@@ -483,7 +487,7 @@ class Sampler:
         assert st.drafted, "draft_generate_batch must run before target_verify_batch"
         lsum = sum(st.glen)
         with torch.cuda.device(self.dev):
-            self.t.forward(self.x_t, st.current_stage, st.g, self.logits_t)
+            self.t.forward(self._xt[st.xt_idx], st.current_stage, st.g, self.logits_t)
         st.stats["target_calls"] += 1
         st.target_calls += 1
         st.verified = True
@@ -526,11 +530,15 @@ class Sampler:
         st.stats["gamma_final"] = st.gamma
 
     def spec_decode(self, labels: torch.Tensor, cfg: float, gamma: int, top_k: int, top_p: float, noise: Noise, thr: float = 0.5,
-                    trace: bool = False) -> SampleResult:
-        """The whole loop with the policy of var.py:1318-1372 (gamma only decreases; forced accept at gamma == 1; never break)."""
+                    trace: bool = False, run_ahead: bool = True) -> SampleResult:
+        """The whole loop with the policy of var.py:1318-1372 (gamma only decreases; forced accept at gamma == 1; never break).
+        run_ahead: once gamma has dropped to 1 the draft no longer waits for the verifier (see _spec_run_ahead); same results."""
         st = self.spec_begin(labels, cfg, gamma, top_k, top_p, noise, thr)
         res = SampleResult(ids=self.ids[:st.B], f_hat=self.f_acc[:st.B], stats=st.stats)
         while st.current_stage < st.total_stages:
+            if run_ahead and st.gamma == 1 and st.accept_scope == "shard" and not trace:
+                self._spec_run_ahead(st)
+                break
             cur = st.current_stage
             g = self.spec_draft(st)
             lg = self.spec_verify_forward(st)
@@ -548,6 +556,51 @@ class Sampler:
             self.spec_commit(st, n_acc, forced)
         self.spec_end(st)
         return res
+
+    def _spec_run_ahead(self, st: "SpecState"):
+        """The tail of the loop at gamma == 1.  There a round always advances one stage with the DRAFT's tokens - accepted, or
+        force-accepted (var.py:1357-1364) - so the verify result only feeds the counters, and since gamma never grows again
+        this holds to the end.  The draft of stage s+1 therefore need not wait for the verification of stage s: the target
+        forwards + acceptance scans run on a second HIP stream one round behind (target input double-buffered, one counter row
+        per round, read back once at the end); the launch-bound early stages of one model fill the gaps of the other."""
+        lad, B, V = self.lad, st.B, self.t.V
+        with torch.cuda.device(self.dev):
+            D = torch.cuda.current_stream(self.dev)
+            if self._verify_stream is None:
+                self._verify_stream = torch.cuda.Stream(device=self.dev)
+                self._xt[1] = torch.empty_like(self.x_t)
+            T = self._verify_stream
+            T.wait_stream(D)                                   # earlier rounds ran the target on the caller's stream
+            t_done, meta = [], []
+            r = 0
+            while st.current_stage < st.total_stages:
+                cur = st.current_stage
+                if r >= 2:
+                    D.wait_event(t_done[r - 2])                # the target forward that last used this input buffer
+                st.xt_idx = r & 1
+                g = self.spec_draft(st)                        # gamma == 1: one stage
+                ready = torch.cuda.Event(); ready.record(D)
+                T.wait_event(ready)
+                with torch.cuda.stream(T):
+                    self.t.forward(self._xt[st.xt_idx], cur, 1, self.logits_t)
+                    verify_accept(self.logits_t, B, st.glen, V, [lad.cfg_t(st.cfg, cur)], self.ids, lad.begin(cur), lad.L, st.thr, self.counts_ra[r])
+                    ev = torch.cuda.Event(); ev.record(T); t_done.append(ev)
+                st.stats["target_calls"] += 1
+                st.target_calls += 1
+                meta.append((cur, g, list(st.glen)))
+                self.spec_commit(st, 1, forced=True)           # data movement of an accepted and of a forced stage is the same; counters below
+                r += 1
+            st.xt_idx = 0
+            D.wait_stream(T)
+            c = self.counts_ra[:r].cpu().tolist()              # the one host sync of the tail
+        for (cur, g, glen), row in zip(meta, c):
+            n_acc, matched, forced = row[16], row[:g], False
+            if n_acc == 0:
+                n_acc, forced = 1, True
+                st.stats["forced_accepts"] += 1
+            else:
+                st.stats["accepted_tokens"] += sum(glen[:n_acc])
+            st.stats["rounds"].append(dict(stage=cur, g=g, matched=matched, total=[B * n for n in glen], n_accept=n_acc, forced=forced))
 
 
 @dataclass
@@ -571,6 +624,7 @@ class SpecState:
     more_smooth: bool = False
     accept_scope: str = "shard"                   # "shard": this process decides alone; "global": all-reduce of the match counts
     draw: int = 0
+    xt_idx: int = 0                               # which target input buffer the current round uses (run-ahead double buffer)
     g: int = 0
     glen: list = field(default_factory=list)
     drafted: bool = False
