@@ -296,3 +296,18 @@ def test_two_samplers_on_two_host_threads_and_streams(dev):
         for ids, img in job["out"]:
             assert torch.equal(ids, ids0)
             assert torch.equal(img, img0)
+
+
+@pytest.mark.parametrize("gamma,thr", [(1, 0.5), (2, 0.5), (3, 2.0), (2, 0.0)])
+def test_run_ahead_equals_lock_step(dev, pair, gamma, thr):
+    """The verifier may run one round behind the draft once gamma == 1 (engine.Sampler._spec_run_ahead): ids, f_hat and every counter
+    equal the lock-step loop's."""
+    smp, _ = pair
+    labels = torch.tensor([11, 470]).to(dev)
+    a = smp.spec_decode(labels, 1.5, gamma, 900, 0.96, E.Noise("device", 5), thr=thr, run_ahead=False)
+    ids_a, f_a, st_a = a.ids.cpu().clone(), a.f_hat.cpu().clone(), dict(a.stats)
+    b = smp.spec_decode(labels, 1.5, gamma, 900, 0.96, E.Noise("device", 5), thr=thr, run_ahead=True)
+    assert torch.equal(b.ids.cpu(), ids_a) and torch.equal(b.f_hat.cpu(), f_a)
+    for k in ("target_calls", "draft_stage_calls", "forced_accepts", "accepted_tokens", "gamma_final"):
+        assert b.stats[k] == st_a[k], k
+    assert b.stats["rounds"] == st_a["rounds"]
