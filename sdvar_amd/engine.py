@@ -403,12 +403,23 @@ class Sampler:
         self.ids = torch.zeros(B, lad.L, device=self.dev, dtype=torch.int64)
         self.f_work = torch.zeros(B, quant.Cv, lad.HW, lad.HW, **f)
         self.f_acc = torch.zeros_like(self.f_work)
-        self.f_snap = [torch.zeros_like(self.f_work) for _ in range(g)]
-        self.nxt = [torch.empty(B * lens[-1] * quant.Cv, **f) for _ in range(g)]
+        self._fs = [[torch.zeros_like(self.f_work) for _ in range(g)], None]      # f_hat snapshots / next-stage inputs of a round; the second
+        self._nx = [[torch.empty(B * lens[-1] * quant.Cv, **f) for _ in range(g)], None]    # slot exists once the optimistic path runs
+        self._slot = 0
         self.nxt_cur = torch.empty(B * lens[-1] * quant.Cv, **f)
         self.counts = torch.zeros(40, device=self.dev, dtype=torch.int32)
-        self.counts_ra = torch.zeros(lad.S, 40, device=self.dev, dtype=torch.int32)
+        self.counts_ra = torch.zeros(4 * lad.S, 40, device=self.dev, dtype=torch.int32)     # one counter row per enqueued verification
+        self._counts_pin = torch.zeros(4 * lad.S, 40, dtype=torch.int32).pin_memory()
+        self._row = 0
         self.counts_host = torch.zeros(40, dtype=torch.int32).pin_memory()
+
+    @property
+    def f_snap(self):
+        return self._fs[self._slot]
+
+    @property
+    def nxt(self):
+        return self._nx[self._slot]
 
     # ---- VAR.autoregressive_infer_cfg (var.py:127-215) up to the decode
     def plain_ar(self, labels: torch.Tensor, cfg: float, top_k: int, top_p: float, noise: Noise, trace: bool = False) -> SampleResult:
@@ -442,6 +453,7 @@ class Sampler:
         with torch.cuda.device(self.dev):
             self.d.begin(labels); self.t.begin(labels)
             self.f_acc[:labels.shape[0]].zero_()
+        self._row, self._slot = 0, 0
         return SpecState(sampler=self, labels=labels, B=labels.shape[0], cfg=cfg, gamma=gamma, top_k=top_k, top_p=top_p, noise=noise, thr=thr,
                          total_stages=self.lad.S, patch_nums=self.lad.patch_nums)
 
@@ -535,10 +547,16 @@ class Sampler:
         run_ahead: once gamma has dropped to 1 the draft no longer waits for the verifier (see _spec_run_ahead); same results."""
         st = self.spec_begin(labels, cfg, gamma, top_k, top_p, noise, thr)
         res = SampleResult(ids=self.ids[:st.B], f_hat=self.f_acc[:st.B], stats=st.stats)
+        optimistic = False                     # speculate on acceptance only after a round that was accepted in full
         while st.current_stage < st.total_stages:
-            if run_ahead and st.gamma == 1 and st.accept_scope == "shard" and not trace:
-                self._spec_run_ahead(st)
-                break
+            if run_ahead and st.accept_scope == "shard" and not trace:
+                if st.gamma == 1:
+                    self._spec_run_ahead(st)
+                    break
+                if optimistic:
+                    self._spec_optimistic(st)
+                    optimistic = False
+                    continue
             cur = st.current_stage
             g = self.spec_draft(st)
             lg = self.spec_verify_forward(st)
@@ -553,9 +571,94 @@ class Sampler:
                     n_acc, forced = 1, True
                     st.stats["forced_accepts"] += 1
             st.stats["rounds"].append(dict(stage=cur, g=g, matched=matched, total=[st.B * n for n in st.glen], n_accept=n_acc, forced=forced))
+            optimistic = n_acc == g and not forced
             self.spec_commit(st, n_acc, forced)
         self.spec_end(st)
         return res
+
+    def _ensure_second_stream(self):
+        if self._verify_stream is None:
+            self._verify_stream = torch.cuda.Stream(device=self.dev)
+            self._xt[1] = torch.empty_like(self.x_t)
+        if self._fs[1] is None:
+            self._fs[1] = [torch.zeros_like(t) for t in self._fs[0]]
+            self._nx[1] = [torch.empty_like(t) for t in self._nx[0]]
+            self._f_prev = [torch.zeros_like(self.f_acc) for _ in range(2)]
+            self._nxt_prev = [torch.empty_like(self.nxt_cur) for _ in range(2)]
+        return self._verify_stream
+
+    def _spec_optimistic(self, st: "SpecState"):
+        """gamma > 1 and the previous round was accepted in full: draft the next round before the verdict on the current one is
+        known.  Every round is committed as if accepted (per-round slots keep its f_hat snapshots, next-stage inputs and the
+        state before it); the verifier runs on the second stream, its counters come back through pinned memory, and the host
+        reads the verdict of round r after it has enqueued round r+1.  A verdict short of full acceptance rolls the state back
+        to what the lock-step loop would hold (accepted prefix, gamma policy, draw counter, both KV cursors), discards the
+        speculative round and returns to lock-step.  Results and counters equal the lock-step loop's."""
+        lad, B, V, S = self.lad, st.B, self.t.V, self.lad.S
+        with torch.cuda.device(self.dev):
+            D = torch.cuda.current_stream(self.dev)
+            T = self._ensure_second_stream()
+            T.wait_stream(D)
+            t_done, pend, n = [], None, 0
+            while st.current_stage < S and st.gamma > 1:
+                slot = n & 1
+                if n >= 2:
+                    D.wait_event(t_done[n - 2])                 # last verification that read this slot's target input
+                self._slot = st.xt_idx = slot
+                self._f_prev[slot][:B].copy_(self.f_acc[:B]); self._nxt_prev[slot].copy_(self.nxt_cur)
+                cur = st.current_stage
+                g = self.spec_draft(st)
+                ready = torch.cuda.Event(); ready.record(D)
+                T.wait_event(ready)
+                row = self._row; self._row += 1
+                with torch.cuda.stream(T):
+                    self.t.forward(self._xt[slot], cur, g, self.logits_t)
+                    verify_accept(self.logits_t, B, st.glen, V, [lad.cfg_t(st.cfg, cur + j) for j in range(g)], self.ids, lad.begin(cur), lad.L, st.thr,
+                                  self.counts_ra[row])
+                    self._counts_pin[row].copy_(self.counts_ra[row], non_blocking=True)
+                    ev = torch.cuda.Event(); ev.record(T); t_done.append(ev)
+                st.stats["target_calls"] += 1
+                st.target_calls += 1
+                info = dict(cur=cur, g=g, glen=list(st.glen), slot=slot, draw_after=st.draw, row=row, ev=ev)
+                self.spec_commit(st, g, forced=True)            # optimistic: all g stages; the counters are settled by _resolve
+                n += 1
+                if pend is not None and not self._resolve(st, pend):
+                    st.stats["draft_stage_calls"] -= info["g"]  # the speculative round is discarded, as if never drafted
+                    st.stats["target_calls"] -= 1
+                    st.target_calls -= 1
+                    st.stats["discarded_speculative_rounds"] = st.stats.get("discarded_speculative_rounds", 0) + 1
+                    pend = None
+                    break
+                pend = info
+            if pend is not None:
+                self._resolve(st, pend)
+            self._slot = st.xt_idx = 0
+            D.wait_stream(T)
+
+    def _resolve(self, st: "SpecState", p: dict) -> bool:
+        """Verdict of an optimistically committed round; rolls back when it was not accepted in full.  True = accepted in full."""
+        lad, B = self.lad, st.B
+        p["ev"].synchronize()
+        c = self._counts_pin[p["row"]].tolist()
+        g, glen, n_acc, matched = p["g"], p["glen"], c[16], c[:p["g"]]
+        st.stats["accepted_tokens"] += sum(glen[:n_acc])
+        st.stats["rounds"].append(dict(stage=p["cur"], g=g, matched=matched, total=[B * m for m in glen], n_accept=n_acc, forced=False))
+        if n_acc == g:
+            return True
+        slot = p["slot"]
+        if n_acc > 0:
+            self.f_acc[:B].copy_(self._fs[slot][n_acc - 1][:B])
+            self.nxt_cur.copy_(self._nx[slot][n_acc - 1])
+        else:
+            self.f_acc[:B].copy_(self._f_prev[slot][:B]); self.nxt_cur.copy_(self._nxt_prev[slot])
+            st.gamma -= 1                                      # var.py:1353-1356 (this path only runs with gamma > 1)
+        st.accept_count -= (st.current_stage - (p["cur"] + n_acc))
+        st.current_stage = p["cur"] + n_acc
+        st.draw = p["draw_after"]
+        keep = lad.begin(st.current_stage)
+        self.d.kv_set_len(keep); self.t.kv_set_len(keep)
+        st.drafted = st.verified = False
+        return False
 
     def _spec_run_ahead(self, st: "SpecState"):
         """The tail of the loop at gamma == 1.  There a round always advances one stage with the DRAFT's tokens - accepted, or
@@ -566,11 +669,9 @@ class Sampler:
         lad, B, V = self.lad, st.B, self.t.V
         with torch.cuda.device(self.dev):
             D = torch.cuda.current_stream(self.dev)
-            if self._verify_stream is None:
-                self._verify_stream = torch.cuda.Stream(device=self.dev)
-                self._xt[1] = torch.empty_like(self.x_t)
-            T = self._verify_stream
+            T = self._ensure_second_stream()
             T.wait_stream(D)                                   # earlier rounds ran the target on the caller's stream
+            row0 = self._row
             t_done, meta = [], []
             r = 0
             while st.current_stage < st.total_stages:
@@ -583,7 +684,7 @@ class Sampler:
                 T.wait_event(ready)
                 with torch.cuda.stream(T):
                     self.t.forward(self._xt[st.xt_idx], cur, 1, self.logits_t)
-                    verify_accept(self.logits_t, B, st.glen, V, [lad.cfg_t(st.cfg, cur)], self.ids, lad.begin(cur), lad.L, st.thr, self.counts_ra[r])
+                    verify_accept(self.logits_t, B, st.glen, V, [lad.cfg_t(st.cfg, cur)], self.ids, lad.begin(cur), lad.L, st.thr, self.counts_ra[row0 + r])
                     ev = torch.cuda.Event(); ev.record(T); t_done.append(ev)
                 st.stats["target_calls"] += 1
                 st.target_calls += 1
@@ -592,7 +693,8 @@ class Sampler:
                 r += 1
             st.xt_idx = 0
             D.wait_stream(T)
-            c = self.counts_ra[:r].cpu().tolist()              # the one host sync of the tail
+            self._row = row0 + r
+            c = self.counts_ra[row0:row0 + r].cpu().tolist()   # the one host sync of the tail
         for (cur, g, glen), row in zip(meta, c):
             n_acc, matched, forced = row[16], row[:g], False
             if n_acc == 0:
