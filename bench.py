@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--mode", default="natural", choices=["natural", "accept_all", "reject_all"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-modes", action="store_true")
+    ap.add_argument("--sampler-high-prio", action="store_true", help="experiment: run the sampler's streams at the higher HIP priority, the decode at the normal one")
     ap.add_argument("--decode-high-prio", action="store_true", help="experiment: give the decode stream the higher HIP priority")
     ap.add_argument("--torch-decode", action="store_true", help="A/B: decode with the PyTorch/MIOpen reference decoder instead of the HIP decoder")
     ap.add_argument("--no-run-ahead", action="store_true", help="keep the draft waiting for the verifier at gamma == 1 (every kernel alone on the GPU: profiling runs)")
@@ -99,6 +100,8 @@ def main():
     # The VQVAE decode of batch i runs on a second HIP stream and overlaps the sampling loop of batch i+1 (whose early
     # stages leave most CUs idle); f_hat is double-buffered and every decode is finished inside the timed region.
     decode = vae.fhat_to_img_torch if args.torch_decode else vae.fhat_to_img
+    if args.sampler_high_prio:
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1))
     main_stream = torch.cuda.current_stream()
     dec_stream = torch.cuda.Stream(device=dev, priority=0 if not args.decode_high_prio else -1)
     fh_buf = [torch.zeros(B, 32, 16, 16, device=dev) for _ in range(2)]

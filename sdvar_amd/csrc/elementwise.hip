@@ -199,21 +199,21 @@ __global__ __launch_bounds__(256) void qk_norm_append_kernel(const float* __rest
 
 // Format 2 of the cache (attention_bf16x3.hip): K planes [R][H][3][Lp][64] and V^T planes [R][H][3][64][Lp] with bits 2 and 3
 // of the key position swapped inside every block of 16 keys.  Same arithmetic as above; the fp32 values are split exactly.
-// One workgroup per (64-position block of the cache, head, row): the waves normalise their tokens and write q and the K
+// One workgroup per (32-position block of the cache, head, row): the waves normalise their tokens and write q and the K
 // planes (128-byte rows), V goes through LDS and leaves as 16-byte runs of 8 cache positions per channel row (transposed
 // 2-byte stores cost 2x the whole kernel: 1.15 ms against 0.44 ms per d16 stage-9 call).
 __global__ __launch_bounds__(256) void qk_norm_append_planes_kernel(const float* __restrict__ qkv, const float* __restrict__ scale_mul,
                                                                     float* __restrict__ q_out, uint16_t* __restrict__ k_cache,
                                                                     uint16_t* __restrict__ v_cache, int R, int l, int H, int Lp, int pos0, PendingSplitK pend) {
-    __shared__ float vs[64 * 65];
+    __shared__ float vs[32 * 65];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = blockIdx.y, r = blockIdx.z;
-    const int P0 = (pos0 / 64 + blockIdx.x) * 64;
-    const int pb = max(P0, pos0), pe = min(P0 + 64, pos0 + l);
+    const int P0 = (pos0 / 32 + blockIdx.x) * 32;
+    const int pb = max(P0, pos0), pe = min(P0 + 32, pos0 + l);
     const int C = H * 64;
     const size_t head = ((size_t)r * H + h) * 3 * (size_t)Lp * 64, ps = (size_t)Lp * 64;
     const float sm = expf(fminf(scale_mul[h], 4.605170249938965f));
-    // wave w owns positions pb + w, + 4, ...; four of them are in flight at a time (their loads - up to 3 x split slab reads
+    // wave w owns positions pb + w, + 4, ... (at most 8); four of them are in flight at a time (their loads - up to 3 x split slab reads
     // each - are independent, the wave reductions are not the bottleneck)
     for (int pos4 = pb + wave; pos4 < pe; pos4 += 16) {
         float q[4], k[4], v[4];
@@ -250,9 +250,8 @@ __global__ __launch_bounds__(256) void qk_norm_append_planes_kernel(const float*
     }
     __syncthreads();
     // thread -> (channel row d, run c of 8 cache positions): positions P0 + 8c .. +7 hold keys P0 + 16 (c >> 1) + 4 (c & 1) + {0..3, 8..11}
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int d = (tid >> 3) + 32 * it, c = tid & 7;
+    {
+        const int d = tid >> 2, c = tid & 3;
         const int kb = P0 + 16 * (c >> 1) + 4 * (c & 1);
         float v[8];
         int inside = 0;
@@ -291,7 +290,7 @@ int qk_norm_append(const float* qkv, const float* scale_mul, float* q_out, void*
     SDVAR_CHECK_ARG(kv_f16 >= 0 && kv_f16 <= 2, "qk_norm_append: cache format %d (0 = fp32, 1 = fp16, 2 = bf16x3 planes)", kv_f16);
     if (kv_f16 == 2) {
         SDVAR_CHECK_ARG(Lmax % 64 == 0, "qk_norm_append: the planes KV format needs Lmax %% 64 == 0 (got %d)", Lmax);
-        hipLaunchKernelGGL(qk_norm_append_planes_kernel, dim3((unsigned)((pos0 + l + 63) / 64 - pos0 / 64), H, R), dim3(256), 0, stream, qkv, scale_mul, q_out, (uint16_t*)k_cache, (uint16_t*)v_cache, R, l, H, Lmax, pos0, pd);
+        hipLaunchKernelGGL(qk_norm_append_planes_kernel, dim3((unsigned)((pos0 + l + 31) / 32 - pos0 / 32), H, R), dim3(256), 0, stream, qkv, scale_mul, q_out, (uint16_t*)k_cache, (uint16_t*)v_cache, R, l, H, Lmax, pos0, pd);
     } else if (kv_f16) hipLaunchKernelGGL(qk_norm_append_kernel<__half>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, qkv, scale_mul, q_out, (__half*)k_cache, (__half*)v_cache, R, l, H, Lmax, pos0, pd);
     else hipLaunchKernelGGL(qk_norm_append_kernel<float>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, qkv, scale_mul, q_out, (float*)k_cache, (float*)v_cache, R, l, H, Lmax, pos0, pd);
     SDVAR_LAUNCH_CHECK();

@@ -578,7 +578,7 @@ class Sampler:
 
     def _ensure_second_stream(self):
         if self._verify_stream is None:
-            self._verify_stream = torch.cuda.Stream(device=self.dev)
+            self._verify_stream = torch.cuda.Stream(device=self.dev, priority=torch.cuda.current_stream(self.dev).priority)
             self._xt[1] = torch.empty_like(self.x_t)
         if self._fs[1] is None:
             self._fs[1] = [torch.zeros_like(t) for t in self._fs[0]]
