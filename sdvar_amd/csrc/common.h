@@ -84,6 +84,15 @@ __device__ __forceinline__ void split8_packed(const float* v, u32x4& a, u32x4& b
     }
 }
 
+// LDS-DMA of 16 bytes per lane with the address as "wave-uniform 64-bit base (SGPRs) + per-lane 32-bit byte offset (one VGPR)":
+// the __builtin_amdgcn_global_load_lds lowering always builds a 64-bit vector address (v_lshl_add_u64 + moves per instruction)
+// and reads the LDS address back through v_readfirstlane; vector ALU work does not hide under MFMAs on gfx950, so the K-loops
+// keep all of it in scalar registers.  lds_byte_addr must be wave-uniform (M0 = LDS base of the wave's 1 KB slot).
+#define SDVAR_DMA16(voff_u32, sbase_ptr, lds_byte_addr)                                                                     \
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"((uint32_t)(voff_u32)), "s"(sbase_ptr), \
+                 "s"((uint32_t)(lds_byte_addr)) : "memory")
+#define SDVAR_LDS_ADDR(p) ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(p))
+
 // Planar bf16x3 tensors are K-BLOCKED: element (row, k) of plane p of a (rows x K) matrix lives at
 //     plane_base[p] + ((k / 32) * rows + row) * 32 + (k % 32)
 // i.e. for every block of 32 k the rows are contiguous 64-byte segments, so the (tile rows) x (32 k) slab a GEMM workgroup

@@ -67,30 +67,31 @@ __global__ __launch_bounds__(512, 2) void conv_bf16x3_kernel(ConvArgs a) {
         const int hw = a.ih * a.iw, b = m / hw, rem = m - b * hw, y = rem / a.iw, x = rem - y * a.iw;
         return (size_t)(b * (a.ih + 2) + y + 1) * w2 + x + 1;
     };
-    const uint16_t* sx0 = a.X + ((size_t)a.x_row0 + prow(min(m0 + xr0, a.M - 1))) * 32 + 8 * cx0;
-    const uint16_t* sx1 = a.X + ((size_t)a.x_row0 + prow(min(m0 + xr1, a.M - 1))) * 32 + 8 * cx1;
-    const uint16_t* sw0 = Wp + (size_t)min(n0 + wr0, a.N - 1) * 32 + 8 * cw0;
-    const uint16_t* sw1 = Wp + (size_t)min(n0 + wr1, a.N - 1) * 32 + 8 * cw1;
-    const bool two_w = wave < 2;
-    // K-step t (global index kt0 + t) = (tap, channel block): X offset = (cblk x_rows + tap shift) rows, W offset = (kt0 + t) N rows
-    long long xoff = 0; size_t woff = 0;
+    // per-lane byte offsets (loop-invariant, < 4 GB inside one channel block) + wave-uniform bases per K-step (common.h SDVAR_DMA16)
+    const int swave = __builtin_amdgcn_readfirstlane(wave);
+    const uint32_t lx0 = (uint32_t)((a.x_row0 + prow(min(m0 + xr0, a.M - 1))) * 32 + 8 * cx0) * 2u;
+    const uint32_t lx1 = (uint32_t)((a.x_row0 + prow(min(m0 + xr1, a.M - 1))) * 32 + 8 * cx1) * 2u;
+    const uint32_t lw0 = (uint32_t)(min(n0 + wr0, a.N - 1) * 32 + 8 * cw0) * 2u, lw1 = (uint32_t)(min(n0 + wr1, a.N - 1) * 32 + 8 * cw1) * 2u;
+    const bool two_w = swave < 2;
+    // K-step t (global index kt0 + t) = (tap, channel block): X base = (cblk x_rows + tap shift) rows, W base = (kt0 + t) N rows
+    const char* ux = nullptr; const char* uw = nullptr;
     auto set_step = [&](int t) {
         const int kb = kt0 + t, tap = kb / a.cb, c = kb - tap * a.cb;
         const int shift = (a.taps == 9) ? (tap / 3 - 1) * w2 + (tap % 3 - 1)
                         : (a.taps == 4) ? ((tap >> 1) - 1 + (phase >> 1)) * w2 + ((tap & 1) - 1 + (phase & 1)) : 0;
-        xoff = ((long long)c * (long long)a.x_rows + shift) * 32;
-        woff = (size_t)kb * a.N * 32;
+        ux = reinterpret_cast<const char*>(a.X) + ((long long)c * (long long)a.x_rows + shift) * 64;
+        uw = reinterpret_cast<const char*>(Wp) + (size_t)kb * a.N * 64;
     };
     // DMA instruction q of the current step -> stage st: q in [0, 9): plane q / 3, kind q % 3 (X group 0, X group 1, W group 0); q in [9, 12): W group 1 of plane q - 9
     auto issue_one = [&](uint16_t* st, int q) {
         if (q < 9) {
             const int p = q / 3, kind = q % 3;
-            if (kind == 0) __builtin_amdgcn_global_load_lds((glb_ptr_t)(sx0 + xoff + p * a.xps), (lds_ptr_t)(st + p * 8192 + wave * 1024), 16, 0, 0);
-            else if (kind == 1) __builtin_amdgcn_global_load_lds((glb_ptr_t)(sx1 + xoff + p * a.xps), (lds_ptr_t)(st + p * 8192 + wave * 1024 + 512), 16, 0, 0);
-            else __builtin_amdgcn_global_load_lds((glb_ptr_t)(sw0 + woff + p * a.wps), (lds_ptr_t)(st + 3 * 8192 + p * 5120 + wave * 512), 16, 0, 0);
+            if (kind == 0) SDVAR_DMA16(lx0, ux + p * a.xps * 2, SDVAR_LDS_ADDR(st + p * 8192 + swave * 1024));
+            else if (kind == 1) SDVAR_DMA16(lx1, ux + p * a.xps * 2, SDVAR_LDS_ADDR(st + p * 8192 + swave * 1024 + 512));
+            else SDVAR_DMA16(lw0, uw + p * a.wps * 2, SDVAR_LDS_ADDR(st + 3 * 8192 + p * 5120 + swave * 512));
         } else if (two_w) {
             const int p = q - 9;
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(sw1 + woff + p * a.wps), (lds_ptr_t)(st + 3 * 8192 + p * 5120 + 4096 + wave * 512), 16, 0, 0);
+            SDVAR_DMA16(lw1, uw + p * a.wps * 2, SDVAR_LDS_ADDR(st + 3 * 8192 + p * 5120 + 4096 + swave * 512));
         }
     };
 

@@ -208,14 +208,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_v2_kernel(GemmPArgs a) {
     const int xrow = a.dbg_same_tile ? drow : min(m0 + drow, a.M - 1), wrow = a.dbg_same_tile ? drow : min(n0 + drow, a.N - 1);   // clamped: rows past the edge are never stored
     const int kt0 = ks * a.k_per_split;
     const int nk = min(a.K / PBK - kt0, a.k_per_split);
-    const uint16_t* srcx = a.X + ((size_t)kt0 * a.M + xrow) * 32 + 8 * dchunk;      // K-blocked: K-step t is the slab [t][rows][32]
-    const uint16_t* srcw = a.W + ((size_t)kt0 * a.N + wrow) * 32 + 8 * dchunk;
+    // K-blocked: K-step t is the slab [t][rows][32].  Lane offsets are loop-invariant; K-step / plane strides stay scalar (common.h SDVAR_DMA16)
+    const int swave = __builtin_amdgcn_readfirstlane(wave);
+    const uint32_t lx = (uint32_t)(xrow * 32 + 8 * dchunk) * 2u, lw = (uint32_t)(wrow * 32 + 8 * dchunk) * 2u;
+    const char* const bx = reinterpret_cast<const char*>(a.X + (size_t)kt0 * a.M * 32);
+    const char* const bw = reinterpret_cast<const char*>(a.W + (size_t)kt0 * a.N * 32);
     // DMA instruction q (0..5) of K-step t (relative) -> stage t % 3: q = 2p is X plane p, q = 2p + 1 is W plane p
     auto issue_one = [&](int t, int q) {
-        uint16_t* st = psm + (t % 3) * V2_STAGE + wave * 512;       // + sub-array * 4096 elements
+        uint16_t* st = psm + (t % 3) * V2_STAGE + swave * 512;       // + sub-array * 4096 elements
         const int p = q >> 1;
-        if (q & 1) __builtin_amdgcn_global_load_lds((glb_ptr_t)(srcw + (size_t)t * a.N * 32 + p * a.wps), (lds_ptr_t)(st + (3 + p) * 4096), 16, 0, 0);
-        else __builtin_amdgcn_global_load_lds((glb_ptr_t)(srcx + (size_t)t * a.M * 32 + p * a.xps), (lds_ptr_t)(st + p * 4096), 16, 0, 0);
+        if (q & 1) SDVAR_DMA16(lw, bw + ((size_t)t * a.N * 32 + p * a.wps) * 2, SDVAR_LDS_ADDR(st + (3 + p) * 4096));
+        else SDVAR_DMA16(lx, bx + ((size_t)t * a.M * 32 + p * a.xps) * 2, SDVAR_LDS_ADDR(st + p * 4096));
     };
     auto issue = [&](int t) {
 #pragma unroll
@@ -344,17 +347,23 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_v3_kernel(GemmPArgs a) {
     const int cx0 = (lane & 3) ^ ((xr0 >> 2) & 3), cx1 = (lane & 3) ^ ((xr1 >> 2) & 3), cw = (lane & 3) ^ ((wr >> 2) & 3);
     const int kt0 = ks * a.k_per_split;
     const int nk = min(a.K / PBK - kt0, a.k_per_split);
-    const uint16_t* sx0 = a.X + ((size_t)kt0 * a.M + min(m0 + xr0, a.M - 1)) * 32 + 8 * cx0;
-    const uint16_t* sx1 = a.X + ((size_t)kt0 * a.M + min(m0 + xr1, a.M - 1)) * 32 + 8 * cx1;
-    const uint16_t* sw0 = a.W + ((size_t)kt0 * a.N + min(n0 + wr, a.N - 1)) * 32 + 8 * cw;
+    // Per-lane byte offsets are loop-invariant 32-bit values; everything that moves with the K-step or the plane is wave-uniform and
+    // stays in scalar registers (global_load_lds takes "SGPR base + VGPR offset"), and the LDS destination is computed from a scalar
+    // wave index: the K-loop carries no vector address arithmetic (vector ALU work does not hide under MFMAs on this chip).
+    const int swave = __builtin_amdgcn_readfirstlane(wave);
+    const uint32_t lx0 = (uint32_t)(min(m0 + xr0, a.M - 1) * 32 + 8 * cx0) * 2u, lx1 = (uint32_t)(min(m0 + xr1, a.M - 1) * 32 + 8 * cx1) * 2u;
+    const uint32_t lw0 = (uint32_t)(min(n0 + wr, a.N - 1) * 32 + 8 * cw) * 2u;
+    const char* const bx = reinterpret_cast<const char*>(a.X + (size_t)kt0 * a.M * 32);
+    const char* const bw = reinterpret_cast<const char*>(a.W + (size_t)kt0 * a.N * 32);
     // DMA instruction q (0..8) of K-step t -> stage t & 1: plane p = q / 3; q % 3 = 0 / 1: X row groups, 2: W row group
     auto issue_one = [&](int t, int q) {
         uint16_t* st = psm + (t & 1) * V3_STAGE;
-        const size_t ox = (size_t)t * a.M * 32, ow = (size_t)t * a.N * 32;
         const int p = q / 3, kind = q % 3;
-        if (kind == 0) __builtin_amdgcn_global_load_lds((glb_ptr_t)(sx0 + ox + p * a.xps), (lds_ptr_t)(st + p * 8192 + wave * 1024), 16, 0, 0);
-        else if (kind == 1) __builtin_amdgcn_global_load_lds((glb_ptr_t)(sx1 + ox + p * a.xps), (lds_ptr_t)(st + p * 8192 + wave * 1024 + 512), 16, 0, 0);
-        else __builtin_amdgcn_global_load_lds((glb_ptr_t)(sw0 + ow + p * a.wps), (lds_ptr_t)(st + 3 * 8192 + p * 4096 + wave * 512), 16, 0, 0);
+        const char* ux = bx + ((size_t)t * a.M * 32 + p * a.xps) * 2;          // wave-uniform
+        const char* uw = bw + ((size_t)t * a.N * 32 + p * a.wps) * 2;
+        if (kind == 0) SDVAR_DMA16(lx0, ux, SDVAR_LDS_ADDR(st + p * 8192 + swave * 1024));
+        else if (kind == 1) SDVAR_DMA16(lx1, ux, SDVAR_LDS_ADDR(st + p * 8192 + swave * 1024 + 512));
+        else SDVAR_DMA16(lw0, uw, SDVAR_LDS_ADDR(st + 3 * 8192 + p * 4096 + swave * 512));
     };
     auto issue = [&](int t) {
 #pragma unroll
