@@ -120,14 +120,17 @@ __global__ __launch_bounds__(256, 2) void attention_bf16x3_kernel(AttnPArgs a) {
     const size_t kps = (size_t)a.Lp * 64;                    // plane stride, both operands
     const int krow = 8 * wave + (lane >> 3), kchunk = (lane & 7) ^ ((krow >> 1) & 7);
     const int vrow = 16 * wave + (lane >> 2), vchunk = (lane & 3) ^ ((vrow >> 2) & 3);
-    const uint16_t* ksrc = a.kc + head + (size_t)krow * 64 + 8 * kchunk;
-    const uint16_t* vsrc = a.vc + head + (size_t)vrow * a.Lp + 8 * vchunk;
+    // loop-invariant 32-bit lane offsets + wave-uniform bases (common.h SDVAR_DMA16): no vector address arithmetic per tile
+    const int swave = __builtin_amdgcn_readfirstlane(wave);
+    const uint32_t lk = (uint32_t)(krow * 64 + 8 * kchunk) * 2u, lv = (uint32_t)(vrow * a.Lp + 8 * vchunk) * 2u;
+    const char* const bk = reinterpret_cast<const char*>(a.kc + head);
+    const char* const bv = reinterpret_cast<const char*>(a.vc + head);
     auto issue = [&](int t) {
-        uint16_t* st = att_sm + (t % ANST) * ASTAGE + wave * 512;
+        uint16_t* st = att_sm + (t % ANST) * ASTAGE + swave * 512;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(ksrc + p * kps + (size_t)t * AKT * 64), (lds_ptr_t)(st + p * APL), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(vsrc + p * kps + t * AKT), (lds_ptr_t)(st + (3 + p) * APL), 16, 0, 0);
+            SDVAR_DMA16(lk, bk + (p * kps + (size_t)t * AKT * 64) * 2, SDVAR_LDS_ADDR(st + p * APL));
+            SDVAR_DMA16(lv, bv + (p * kps + (size_t)t * AKT) * 2, SDVAR_LDS_ADDR(st + (3 + p) * APL));
         }
     };
 
