@@ -53,11 +53,14 @@ int sdvar_model_bind_embed(sdvar_model_t* m, const float* class_emb, const float
                            const float* lvl_embed, const float* word_w, const float* word_b, void* stream);
 /* one AdaLNSelfAttn block (basic_var.py:128-159): ada_lin.1.{weight (6C,C), bias}, attn.mat_qkv.weight (3C,C),
  * attn.q_bias, attn.v_bias, attn.scale_mul_1H11 (H), attn.proj.{weight,bias}, ffn.fc1.{weight (4C,C),bias},
- * ffn.fc2.{weight (C,4C),bias}. */
+ * ffn.fc2.{weight (C,4C),bias}.  ada_w may be NULL for a shared_aln block (see sdvar_model_bind_shared_aln). */
 int sdvar_model_bind_block(sdvar_model_t* m, int32_t block, const float* ada_w, const float* ada_b, const float* qkv_w,
                            const float* q_bias, const float* v_bias, const float* scale_mul, const float* proj_w,
                            const float* proj_b, const float* fc1_w, const float* fc1_b, const float* fc2_w,
                            const float* fc2_b, void* stream);
+/* shared_aln=True models (VAR-d36-s; var.py:16-19, 81, 192): shared_ada_lin.1.{weight (6C,C), bias (6C)}; their blocks are bound with
+ * ada_w = NULL and ada_b = blocks.i.ada_gss (1,1,6,C)  (basic_var.py:143-144, 153-154). */
+int sdvar_model_bind_shared_aln(sdvar_model_t* m, const float* shared_w, const float* shared_b);
 /* head_nm.ada_lin.1.{weight (2C,C), bias}, head.{weight (V,C), bias}  (basic_var.py:165-174, var.py:116-117) */
 int sdvar_model_bind_head(sdvar_model_t* m, const float* nm_w, const float* nm_b, const float* head_w, const float* head_b, void* stream);
 

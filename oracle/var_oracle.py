@@ -77,7 +77,10 @@ class OracleVAR:
     def _block(self, i: int, x: Tensor, cond: Tensor, mask: Optional[Tensor]) -> Tensor:
         sd, C, H = self.sd, self.C, self.H
         p = f"blocks.{i}."
-        ada = F.linear(F.silu(cond), sd[p + "ada_lin.1.weight"], sd[p + "ada_lin.1.bias"]).view(-1, 1, 6, C)
+        if p + "ada_gss" in sd:      # shared_aln (var.py:81,192 + basic_var.py:153-154): per-block offset + one shared SiLU-Linear of cond
+            ada = sd[p + "ada_gss"] + F.linear(F.silu(cond), sd["shared_ada_lin.1.weight"], sd["shared_ada_lin.1.bias"]).view(-1, 1, 6, C)
+        else:
+            ada = F.linear(F.silu(cond), sd[p + "ada_lin.1.weight"], sd[p + "ada_lin.1.bias"]).view(-1, 1, 6, C)
         g1, g2, s1, s2, sh1, sh2 = ada.unbind(2)
         R, l, _ = x.shape
         h = F.layer_norm(x, (C,), eps=1e-6).mul(s1.add(1)).add_(sh1)

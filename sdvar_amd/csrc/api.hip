@@ -21,6 +21,7 @@ float* set_splitk_workspace(float* p);
 size_t splitk_workspace_floats();
 int qk_norm_append(const float* qkv, const float* scale_mul, float* q_out, void* k_cache, void* v_cache, int kv_f16, int R, int l, int H, int Lmax, int pos0, const PendingSplitK* pend, hipStream_t stream);
 int silu_rows(const float* x, float* y, int n, hipStream_t stream);
+int add_row_vector(const float* src, const float* vec, float* out, int rows, int cols, hipStream_t stream);
 int prologue(const long long* labels, const float* class_emb, const float* pos_start, const float* lvl_pos, float* cond, float* x0, int B, int C, int num_classes, hipStream_t stream);
 int build_lvl_pos(const float* lvl_embed, const float* pos, const int* stage_of_tok, float* out, int L, int C, hipStream_t stream);
 int embed_next(const float* nxt, const float* Ww, const float* bw, const float* lvl_pos, float* x, int B, int l, int C, int t0, int ltot, int tok_off, hipStream_t stream);
@@ -101,6 +102,8 @@ struct sdvar_model {
     sdvar_model_desc d;
     int C, H, L, Rmax, lmax, S;
     int kv_fmt, Lkv;     // cache format handed to the kernels (0 fp32, 1 fp16, 2 planes) and its row capacity
+    const float *shared_w = nullptr, *shared_b = nullptr;   // shared_aln=True: shared_ada_lin.1.{weight (6C,C), bias} (var.py:16-19, 81)
+    float* gss_lin = nullptr;  // owned (Rmax, 6C): shared_ada_lin(cond) of the current call
     float* ws_own = nullptr;   // this model's split-K slabs: two models of one host thread may run on different streams
     int lens[SDVAR_MAX_STAGES], cum[SDVAR_MAX_STAGES];
     // borrowed
@@ -215,7 +218,7 @@ int sdvar_model_create(const sdvar_model_desc* desc, sdvar_model_t** out) {
 
 int sdvar_model_destroy(sdvar_model_t* m) {
     if (!m) return SDVAR_OK;
-    float* bufs[] = {m->lvl_pos, m->cond, m->cond_silu, m->x0, m->ada, m->ada_head, m->xn, m->qkv, m->qbuf, m->att, m->hid, m->ws_own};
+    float* bufs[] = {m->lvl_pos, m->cond, m->cond_silu, m->x0, m->ada, m->ada_head, m->xn, m->qkv, m->qbuf, m->att, m->hid, m->ws_own, m->gss_lin};
     for (float* p : bufs) if (p) (void)hipFree(p);
     if (m->stage_of_tok) (void)hipFree(m->stage_of_tok);
     uint16_t* pb[] = {m->xn_p, m->att_p, m->hid_p, m->head_wp};
@@ -239,7 +242,8 @@ int sdvar_model_bind_block(sdvar_model_t* m, int32_t i, const float* ada_w, cons
                            const float* v_bias, const float* scale_mul, const float* proj_w, const float* proj_b, const float* fc1_w,
                            const float* fc1_b, const float* fc2_w, const float* fc2_b, void* stream) {
     SDVAR_CHECK_ARG(m && i >= 0 && i < m->d.depth, "bind_block: block index %d", i);
-    SDVAR_CHECK_ARG(ada_w && ada_b && qkv_w && q_bias && v_bias && scale_mul && proj_w && proj_b && fc1_w && fc1_b && fc2_w && fc2_b, "bind_block: null tensor");
+    // ada_w == NULL: a shared_aln block, ada_b is its ada_gss (6C) and sdvar_model_bind_shared_aln supplies the Linear
+    SDVAR_CHECK_ARG(ada_b && qkv_w && q_bias && v_bias && scale_mul && proj_w && proj_b && fc1_w && fc1_b && fc2_w && fc2_b, "bind_block: null tensor");
     BlockW& b = m->blk[i];
     b.ada_w = ada_w; b.ada_b = ada_b; b.qkv_w = qkv_w; b.scale_mul = scale_mul; b.proj_w = proj_w; b.proj_b = proj_b;
     b.fc1_w = fc1_w; b.fc1_b = fc1_b; b.fc2_w = fc2_w; b.fc2_b = fc2_b;
@@ -257,6 +261,13 @@ int sdvar_model_bind_block(sdvar_model_t* m, int32_t i, const float* ada_w, cons
     return SDVAR_OK;
 }
 
+int sdvar_model_bind_shared_aln(sdvar_model_t* m, const float* w, const float* b) {
+    SDVAR_CHECK_ARG(m && w && b, "bind_shared_aln: null argument");
+    m->shared_w = w; m->shared_b = b;
+    if (!m->gss_lin) SDVAR_TRY(dmalloc(&m->gss_lin, (size_t)m->Rmax * 6 * m->C));
+    return SDVAR_OK;
+}
+
 int sdvar_model_bind_head(sdvar_model_t* m, const float* nm_w, const float* nm_b, const float* head_w, const float* head_b, void* stream) {
     SDVAR_CHECK_ARG(m && nm_w && nm_b && head_w && head_b, "bind_head: null argument");
     m->nm_w = nm_w; m->nm_b = nm_b; m->head_w = head_w; m->head_b = head_b; m->head_bound = true;
@@ -267,7 +278,10 @@ int sdvar_model_bind_head(sdvar_model_t* m, const float* nm_w, const float* nm_b
 static int check_bound(const sdvar_model* m) {
     if (!m) { set_error("null model"); return SDVAR_ERR_ARG; }
     if (!m->embed_bound || !m->head_bound) { set_error("model weights not bound (embed=%d head=%d)", (int)m->embed_bound, (int)m->head_bound); return SDVAR_ERR_STATE; }
-    for (size_t i = 0; i < m->blk.size(); ++i) if (!m->blk[i].bound) { set_error("block %zu weights not bound", i); return SDVAR_ERR_STATE; }
+    for (size_t i = 0; i < m->blk.size(); ++i) {
+        if (!m->blk[i].bound) { set_error("block %zu weights not bound", i); return SDVAR_ERR_STATE; }
+        if (!m->blk[i].ada_w && !m->shared_w) { set_error("block %zu is a shared_aln block but shared_ada_lin is not bound", i); return SDVAR_ERR_STATE; }
+    }
     return SDVAR_OK;
 }
 
@@ -284,10 +298,15 @@ int sdvar_model_begin(sdvar_model_t* m, int32_t B, const int64_t* labels, void* 
         SDVAR_TRY(silu_rows(m->cond, m->cond_silu, R * C, s));
     }
     // adaLN parameters of every block: stage-invariant, computed once per call instead of once per stage
+    if (m->shared_w) {          // shared_aln: one Linear for all blocks (var.py:192), each block adds its ada_gss (basic_var.py:153-154)
+        ProfScope ps(0, 2.0 * R * 6.0 * C * C, 4.0 * (6.0 * C * C + R * 7.0 * C), s);
+        SDVAR_TRY(gemm_f32_nt(m->cond_silu, C, m->shared_w, m->shared_b, m->gss_lin, 6 * C, R, 6 * C, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, s));
+    }
     for (int i = 0; i < m->d.depth; ++i) {
         ProfScope ps(0, 2.0 * R * 6.0 * C * C, 4.0 * (6.0 * C * C + R * 7.0 * C), s);
-        SDVAR_TRY(gemm_f32_nt(m->cond_silu, C, m->blk[i].ada_w, m->blk[i].ada_b, m->ada + (size_t)i * m->Rmax * 6 * C, 6 * C, R, 6 * C, C, EPI_BIAS,
-                              nullptr, 0, nullptr, 0, 0, s));
+        float* dst = m->ada + (size_t)i * m->Rmax * 6 * C;
+        if (!m->blk[i].ada_w) SDVAR_TRY(add_row_vector(m->gss_lin, m->blk[i].ada_b, dst, R, 6 * C, s));
+        else SDVAR_TRY(gemm_f32_nt(m->cond_silu, C, m->blk[i].ada_w, m->blk[i].ada_b, dst, 6 * C, R, 6 * C, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, s));
     }
     {
         ProfScope ps(0, 2.0 * R * 2.0 * C * C, 4.0 * (2.0 * C * C + R * 3.0 * C), s);

@@ -309,6 +309,19 @@ int silu_rows(const float* x, float* y, int n, hipStream_t stream) {
     return SDVAR_OK;
 }
 
+// out[r][c] = vec[c] + src[r][c]  (shared adaLN: ada_gss of a block + the shared SiLU-Linear of cond, basic_var.py:153-154)
+__global__ void add_row_vector_kernel(const float* __restrict__ src, const float* __restrict__ vec, float* __restrict__ out, int rows, int cols) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (size_t)rows * cols) out[i] = vec[i % cols] + src[i];
+}
+
+int add_row_vector(const float* src, const float* vec, float* out, int rows, int cols, hipStream_t stream) {
+    const size_t n = (size_t)rows * cols;
+    hipLaunchKernelGGL(add_row_vector_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, vec, out, rows, cols);
+    SDVAR_LAUNCH_CHECK();
+    return SDVAR_OK;
+}
+
 // cond (2B, C) = class_emb[label_b] for rows < B, class_emb[num_classes] for rows >= B;  x0 (2B,1,C) = cond + pos_start + lvl_pos[0]
 __global__ void prologue_kernel(const long long* __restrict__ labels, const float* __restrict__ class_emb, const float* __restrict__ pos_start,
                                 const float* __restrict__ lvl_pos, float* __restrict__ cond, float* __restrict__ x0, int B, int C, int num_classes) {

@@ -54,6 +54,7 @@ _SIGNATURES = {
     "sdvar_model_destroy": (_I, [_P]),
     "sdvar_model_bind_embed": (_I, [_P] * 8),
     "sdvar_model_bind_block": (_I, [_P, _I] + [_P] * 13),
+    "sdvar_model_bind_shared_aln": (_I, [_P, _P, _P]),
     "sdvar_model_bind_head": (_I, [_P] * 6),
     "sdvar_model_begin": (_I, [_P, _I, _P, _P]),
     "sdvar_model_export_prologue": (_I, [_P, _P, _P, _P, _P]),
@@ -166,10 +167,14 @@ class ModelCtx:
         st = _stream()
         _check(self.lib.sdvar_model_bind_embed(self.h, w("class_emb.weight"), w("pos_start"), w("pos_1LC"), w("lvl_embed.weight"),
                                                w("word_embed.weight"), w("word_embed.bias"), st))
+        shared = "shared_ada_lin.1.weight" in sd                 # shared_aln=True checkpoints (VAR-d36-s): var.py:16-19, 81
+        if shared:
+            _check(self.lib.sdvar_model_bind_shared_aln(self.h, w("shared_ada_lin.1.weight"), w("shared_ada_lin.1.bias")))
         for i in range(self.depth):
             p = f"blocks.{i}."
             _check(self.lib.sdvar_model_bind_block(
-                self.h, i, w(p + "ada_lin.1.weight"), w(p + "ada_lin.1.bias"), w(p + "attn.mat_qkv.weight"), w(p + "attn.q_bias"),
+                self.h, i, None if shared else w(p + "ada_lin.1.weight"), w(p + "ada_gss") if shared else w(p + "ada_lin.1.bias"),
+                w(p + "attn.mat_qkv.weight"), w(p + "attn.q_bias"),
                 w(p + "attn.v_bias"), w(p + "attn.scale_mul_1H11"), w(p + "attn.proj.weight"), w(p + "attn.proj.bias"),
                 w(p + "ffn.fc1.weight"), w(p + "ffn.fc1.bias"), w(p + "ffn.fc2.weight"), w(p + "ffn.fc2.bias"), st))
         _check(self.lib.sdvar_model_bind_head(self.h, w("head_nm.ada_lin.1.weight"), w("head_nm.ada_lin.1.bias"), w("head.weight"), w("head.bias"), st))

@@ -44,10 +44,14 @@ class _FFN(nn.Module):
 
 
 class _Block(nn.Module):
-    def __init__(self, C, H):
+    def __init__(self, C, H, shared_aln=False):
         super().__init__()
         self.attn, self.ffn = _SelfAttention(C, H), _FFN(C)
-        self.ada_lin = nn.Sequential(nn.SiLU(inplace=False), nn.Linear(C, 6 * C))
+        self.shared_aln = shared_aln
+        if shared_aln:                                                   # basic_var.py:143-144
+            self.ada_gss = nn.Parameter(torch.randn(1, 1, 6, C) / C ** 0.5)
+        else:
+            self.ada_lin = nn.Sequential(nn.SiLU(inplace=False), nn.Linear(C, 6 * C))
 
 
 class _HeadNorm(nn.Module):
@@ -62,8 +66,6 @@ class VAR(nn.Module):
                  patch_nums=(1, 2, 3, 4, 5, 6, 8, 10, 13, 16), flash_if_available=True, fused_if_available=True):
         super().__init__()
         assert embed_dim % num_heads == 0
-        if shared_aln:
-            raise NotImplementedError("shared_aln=True (SharedAdaLin, var.py:16-19) is not built; no BASELINE config uses it")
         if not attn_l2_norm:
             raise NotImplementedError("attn_l2_norm=False is not built: the factories default to True (models/__init__.py:22)")
         if embed_dim != 64 * num_heads or num_heads != depth or mlp_ratio != 4.:
@@ -83,8 +85,9 @@ class VAR(nn.Module):
         self.pos_start = nn.Parameter(torch.zeros(1, self.first_l, C))
         self.pos_1LC = nn.Parameter(torch.zeros(1, self.L, C))
         self.lvl_embed = nn.Embedding(lad.S, C)
-        self.shared_ada_lin = nn.Identity()
-        self.blocks = nn.ModuleList([_Block(C, num_heads) for _ in range(depth)])
+        self.shared_aln = bool(shared_aln)
+        self.shared_ada_lin = nn.Sequential(nn.SiLU(inplace=False), nn.Linear(C, 6 * C)) if shared_aln else nn.Identity()   # var.py:81
+        self.blocks = nn.ModuleList([_Block(C, num_heads, shared_aln) for _ in range(depth)])
         lvl = torch.cat([torch.full((n,), i, dtype=torch.int64) for i, n in enumerate(lad.lens)]).view(1, self.L)
         self.register_buffer("lvl_1L", lvl)
         d = lvl.view(1, self.L, 1)
@@ -181,7 +184,7 @@ class VAR(nn.Module):
     def init_weights(self, init_adaln=0.5, init_adaln_gamma=1e-5, init_head=0.02, init_std=0.02, conv_std_or_gain=0.02, seed: int = 1234):
         """Distributions of var.py:261-311 drawn from a seeded generator (sdvar_amd.weights 'perf' init)."""
         from .weights import var_state_dict
-        sd = var_state_dict(self.depth, self.patch_nums, "perf", seed, V=self.V, Cvae=self.Cvae, num_classes=self.num_classes)
+        sd = var_state_dict(self.depth, self.patch_nums, "perf", seed, V=self.V, Cvae=self.Cvae, num_classes=self.num_classes, shared_aln=self.shared_aln)
         self.load_state_dict({k: v.to(self._device()) for k, v in sd.items()})
 
 

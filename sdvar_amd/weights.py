@@ -45,7 +45,7 @@ def _tn(g: np.random.Generator, shape, std) -> torch.Tensor:
 
 
 def var_state_dict(depth: int, patch_nums: Sequence[int], mode: str = "perf", seed: int = 1234,
-                   V: int = 4096, Cvae: int = 32, num_classes: int = 1000) -> "OrderedDict[str, torch.Tensor]":
+                   V: int = 4096, Cvae: int = 32, num_classes: int = 1000, shared_aln: bool = False) -> "OrderedDict[str, torch.Tensor]":
     lad = as_ladder(patch_nums)
     C, H, L, S = 64 * depth, depth, lad.L, lad.S
     if mode not in ("perf", "stress"):
@@ -79,6 +79,14 @@ def var_state_dict(depth: int, patch_nums: Sequence[int], mode: str = "perf", se
         w(p + "attn.proj.weight", (C, C), 1 / math.sqrt(C)).div_(math.sqrt(2 * depth)); b(p + "attn.proj.bias", (C,), 0.02)
         w(p + "ffn.fc1.weight", (4 * C, C), 1 / math.sqrt(C)); b(p + "ffn.fc1.bias", (4 * C,), 0.1)
         w(p + "ffn.fc2.weight", (C, 4 * C), 1 / math.sqrt(4 * C)).div_(math.sqrt(2 * depth)); b(p + "ffn.fc2.bias", (C,), 0.02)
+        if shared_aln:                              # SharedAdaLin (var.py:16-19, 81): one Linear for all blocks + a per-block offset (basic_var.py:143-144)
+            gss = _n(_gen(sseed, p + "ada_gss"), (1, 1, 6, C), 0.3 if stress else 1 / math.sqrt(C))
+            if stress:
+                gss[:, :, :2] += 1.0                # gamma1, gamma2 channels open
+            else:
+                gss[:, :, 2:] *= 0.5; gss[:, :, :2] *= 1e-5   # var.py:309-311
+            sd[p + "ada_gss"] = gss
+            continue
         aw = w(p + "ada_lin.1.weight", (6 * C, C), 0.5 / math.sqrt(C))
         ab = torch.zeros(6 * C)
         if stress:
@@ -86,6 +94,10 @@ def var_state_dict(depth: int, patch_nums: Sequence[int], mode: str = "perf", se
         else:
             aw[2 * C:] *= 0.5; aw[: 2 * C] *= 1e-5   # init_adaln / init_adaln_gamma (var.py:305-306)
         sd[p + "ada_lin.1.bias"] = ab
+    if shared_aln:
+        sw = w("shared_ada_lin.1.weight", (6 * C, C), 0.5 / math.sqrt(C)); b("shared_ada_lin.1.bias", (6 * C,), 0.05)
+        if not stress:
+            sw[2 * C:] *= 0.5; sw[: 2 * C] *= 1e-5   # var.py:299-302
     hw = w("head_nm.ada_lin.1.weight", (2 * C, C), 0.5 / math.sqrt(C)); b("head_nm.ada_lin.1.bias", (2 * C,), 0.1)
     hd = w("head.weight", (V, C), 2 / math.sqrt(C)); b("head.bias", (V,), 0.1)
     if not stress:

@@ -93,9 +93,9 @@ def capture_fhat(vae):
     return box, (lambda: setattr(vae, "fhat_to_img", orig))
 
 
-def build_ref(depth, patch_nums, mode, seed):
-    vae, var = ref_models.build_vae_var(device="cpu", patch_nums=patch_nums, depth=depth)
-    sd_var = var_state_dict(depth, patch_nums, mode, seed)
+def build_ref(depth, patch_nums, mode, seed, shared_aln=False):
+    vae, var = ref_models.build_vae_var(device="cpu", patch_nums=patch_nums, depth=depth, shared_aln=shared_aln)
+    sd_var = var_state_dict(depth, patch_nums, mode, seed, shared_aln=shared_aln)
     sd_vae = vae_state_dict(patch_nums, mode, seed)
     var.load_state_dict(sd_var, strict=True)       # proves the key/shape contract of sdvar_amd.weights
     vae.load_state_dict(sd_vae, strict=True)
@@ -127,9 +127,9 @@ def pick_seed(run, start=0, tries=60):
     raise RuntimeError(f"no seed with margin >= {MIN_MARGIN}: best {best}")
 
 
-def plain_ar_fixture(name, depth, patch_nums, B, labels, cfg, top_k, top_p, g_seed, mode, wseed, store_logits_rows=2):
+def plain_ar_fixture(name, depth, patch_nums, B, labels, cfg, top_k, top_p, g_seed, mode, wseed, store_logits_rows=2, shared_aln=False):
     t0 = time.time()
-    vae, var, sd_var, sd_vae = build_ref(depth, patch_nums, mode, wseed)
+    vae, var, sd_var, sd_vae = build_ref(depth, patch_nums, mode, wseed, shared_aln)
     label_B = torch.tensor(labels, dtype=torch.int64)
     V = 4096
     model = orc.OracleVAR(sd_var, depth, patch_nums)
@@ -138,7 +138,7 @@ def plain_ar_fixture(name, depth, patch_nums, B, labels, cfg, top_k, top_p, g_se
         lambda d, B_, l, V_: exponential_noise(sd_, d, B_, l, V_)), keep=False).margins), start=g_seed)
     print(f"[golden] {name}: seed {g_seed} (min margin {m0:.2e})")
     out = dict(depth=depth, patch_nums=np.array(patch_nums), B=B, labels=np.array(labels), cfg=cfg, top_k=top_k, top_p=top_p,
-               g_seed=g_seed, mode=mode, wseed=wseed,
+               g_seed=g_seed, mode=mode, wseed=wseed, shared_aln=int(shared_aln),
                w_digest=digest(sd_var["head.weight"]), vae_digest=digest(sd_vae["quantize.embedding.weight"]))
 
     # (a) the reference with its own generator on THIS host
@@ -368,6 +368,8 @@ if __name__ == "__main__":
         plain_ar_fixture("ar_d6_256_stress", 6, LADDER_256, 2, [3, 977], 1.5, 900, 0.96, 0, "stress", 1234)
         plain_ar_fixture("ar_d4_512_stress", 4, LADDER_512, 1, [417], 3.0, 900, 0.96, 1, "stress", 1234)
         plain_ar_fixture("ar_d4_256_notopkp", 4, LADDER_256, 2, [1000, 5], 1.5, 0, 0.0, 3, "stress", 1234)
+    if "all" in which or "sharedaln" in which:       # SharedAdaLin models (var.py:16-19, 81): the reference built with shared_aln=True
+        plain_ar_fixture("ar_d4_256_sharedaln", 4, LADDER_256, 2, [3, 977], 1.5, 900, 0.96, 0, "stress", 1234, shared_aln=True)
     if "all" in which or "sd" in which: sd_fixture()
     if "all" in which or "d16" in which:
         plain_ar_fixture("ar_d16_256_stress_B1", 16, LADDER_256, 1, [207], 1.5, 900, 0.96, 0, "stress", 1234)

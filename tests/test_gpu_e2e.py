@@ -30,12 +30,12 @@ def _flip_report(ids_hip, ids_ref, lad):
 
 
 @pytest.mark.parametrize("gm", GEMM_MODES)
-@pytest.mark.parametrize("name", ["ar_d4_256_stress", "ar_d6_256_stress", "ar_d4_512_stress", "ar_d4_256_notopkp"])
+@pytest.mark.parametrize("name", ["ar_d4_256_stress", "ar_d6_256_stress", "ar_d4_512_stress", "ar_d4_256_notopkp", "ar_d4_256_sharedaln"])
 def test_plain_ar_vs_reference_fixture(dev, name, gm):
     g = golden(name)
     depth, pns = int(g["depth"]), tuple(int(p) for p in g["patch_nums"])
     lad = as_ladder(pns)
-    sd_var, sd_vae = state_dicts(depth, pns, str(g["mode"]), int(g["wseed"]))
+    sd_var, sd_vae = state_dicts(depth, pns, str(g["mode"]), int(g["wseed"]), shared_aln=bool(int(g["shared_aln"])) if "shared_aln" in g else False)
     B = int(g["B"])
     ctx = E.ModelCtx(sd_var, depth, pns, B, 1, dev, gemm_mode=gm); qc = E.QuantCtx(sd_vae, pns, B, dev)
     smp = E.Sampler(ctx, qc)
@@ -311,3 +311,23 @@ def test_run_ahead_equals_lock_step(dev, pair, gamma, thr):
     for k in ("target_calls", "draft_stage_calls", "forced_accepts", "accepted_tokens", "gamma_final"):
         assert b.stats[k] == st_a[k], k
     assert b.stats["rounds"] == st_a["rounds"]
+
+
+def test_shared_aln_module_api(dev):
+    """VAR(shared_aln=True) (SharedAdaLin checkpoints such as VAR-d36-s, var.py:16-19, 81): the module container binds shared_ada_lin +
+    blocks.i.ada_gss and samples the ids of the reference fixture."""
+    from sdvar_amd.var import VAR
+    from sdvar_amd.vqvae import VQVAE
+    g = golden("ar_d4_256_sharedaln")
+    pns = tuple(int(p) for p in g["patch_nums"])
+    sd_var, sd_vae = state_dicts(4, pns, str(g["mode"]), int(g["wseed"]), shared_aln=True)
+    vae = VQVAE(vocab_size=4096, z_channels=32, ch=160, v_patch_nums=pns, with_encoder=False)
+    vae.load_state_dict(sd_vae)
+    var = VAR(vae_local=vae, depth=4, embed_dim=256, num_heads=4, shared_aln=True, attn_l2_norm=True, patch_nums=pns)
+    var.load_state_dict(sd_var)
+    vae, var = vae.to(dev), var.to(dev)
+    var.noise_kind = "host"
+    img = var.autoregressive_infer_cfg(B=int(g["B"]), label_B=torch.from_numpy(g["labels"]).long().to(dev), g_seed=int(g["g_seed"]), cfg=float(g["cfg"]),
+                                       top_k=int(g["top_k"]), top_p=float(g["top_p"]))
+    assert np.array_equal(var.last_result.ids.cpu().numpy(), g["ids"].astype(np.int64))
+    assert img.shape == (int(g["B"]), 3, 256, 256) and float(img.min()) >= 0.0 and float(img.max()) <= 1.0
