@@ -163,6 +163,25 @@ def main():
     torch.cuda.synchronize(); dec_ms = (time.perf_counter() - t0) / 5 * 1e3
     log(f"decode alone: {dec_ms:.2f} ms per batch of {B} ({'PyTorch/MIOpen' if args.torch_decode else 'HIP decoder'})")
 
+    def decoder_flops(ch=160, mult=(1, 1, 2, 2, 4), nrb=2, z=32, h0=16):
+        """Multiply-adds x 2 of decoder(post_quant_conv(f_hat)) per image (basic_vae.py:163-226), direct 3x3 convolutions."""
+        conv = lambda cin, cout, hw, k: 2.0 * hw * hw * cin * cout * k * k
+        ctop = ch * mult[-1]
+        res = lambda cin, cout, hw: conv(cin, cout, hw, 3) + conv(cout, cout, hw, 3) + (conv(cin, cout, hw, 1) if cin != cout else 0.0)
+        att = lambda c, hw: conv(c, 3 * c, hw, 1) + conv(c, c, hw, 1) + 4.0 * (hw * hw) ** 2 * c
+        f = conv(z, z, h0, 3) + conv(z, ctop, h0, 3) + 2 * res(ctop, ctop, h0) + att(ctop, h0)
+        cprev, hw = ctop, h0
+        for lv in reversed(range(len(mult))):
+            c = ch * mult[lv]
+            for _ in range(nrb + 1):
+                f += res(cprev, c, hw); cprev = c
+                if lv == len(mult) - 1:
+                    f += att(c, hw)
+            if lv != 0:
+                hw *= 2; f += conv(c, c, hw, 3)
+        return f + conv(cprev, 3, hw, 3)
+    dec_tflops = decoder_flops() * B / (dec_ms * 1e-3) / 1e12
+
     extra = {}
     if not args.no_extra_modes and rank == 0 and world == 1:
         # Two sampler pipelines per GPU (an extra, NOT `value`): a second set of model objects driven by a second host thread on its
@@ -264,7 +283,7 @@ def main():
         "mean_accepted_tokens_per_step": agg["mean_accepted_tokens_per_step"],
         "target_calls": agg["target_calls"], "draft_stage_calls": agg["draft_stage_calls"], "forced_accepts": agg["forced_accepts"],
         "images_per_s_no_decode": B * world * nd_steps / dt_nd,
-        "decode_ms_per_batch": dec_ms, "decoder": "pytorch-miopen" if args.torch_decode else "hip (csrc/conv.hip, csrc/vae.hip)",
+        "decode_ms_per_batch": dec_ms, "decoder_tflops_algorithmic": dec_tflops, "decoder": "pytorch-miopen" if args.torch_decode else "hip (csrc/conv.hip, csrc/vae.hip)",
         "modes": extra, "roofline_note": "roofline / kernel_class_ms_per_step come from one step with every kernel alone on the GPU (no draft/verify or decode overlap)", "roofline": roofline, "roofline_verify_attention": roofline_attn, "kernel_class_ms_per_step": class_ms,
     }
 
