@@ -331,3 +331,16 @@ def test_shared_aln_module_api(dev):
                                        top_k=int(g["top_k"]), top_p=float(g["top_p"]))
     assert np.array_equal(var.last_result.ids.cpu().numpy(), g["ids"].astype(np.int64))
     assert img.shape == (int(g["B"]), 3, 256, 256) and float(img.min()) >= 0.0 and float(img.max()) <= 1.0
+
+
+def test_run_ahead_partial_batch_and_repeated_calls(dev, pair):
+    """Fewer images than max_batch, alternating gammas and thresholds on ONE sampler object: the run-ahead / optimistic paths leave no state
+    behind (slots, counter rows, second stream) - every call equals the lock-step result of the same call."""
+    smp, _ = pair
+    labels = torch.tensor([901]).to(dev)                                         # B = 1 on a max_batch = 2 sampler
+    for gamma, thr, seed in [(2, 0.0, 3), (1, 0.5, 4), (3, 0.0, 5), (2, 2.0, 6), (2, 0.0, 3)]:
+        a = smp.spec_decode(labels, 1.5, gamma, 900, 0.96, E.Noise("device", seed), thr=thr, run_ahead=False)
+        ids_a, st_a = a.ids.cpu().clone(), dict(a.stats)
+        b = smp.spec_decode(labels, 1.5, gamma, 900, 0.96, E.Noise("device", seed), thr=thr, run_ahead=True)
+        assert torch.equal(b.ids.cpu(), ids_a), (gamma, thr)
+        assert b.stats["rounds"] == st_a["rounds"] and b.stats["target_calls"] == st_a["target_calls"] and b.stats["draft_stage_calls"] == st_a["draft_stage_calls"]

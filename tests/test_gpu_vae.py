@@ -159,3 +159,20 @@ def test_module_entry_point_uses_the_hip_decoder(dev):
     assert (got - vae.fhat_to_img_torch(f_hat.clone())).abs().max().item() <= 1e-4
     with pytest.raises(E.SdvarError):
         vae.fhat_to_img(f_hat.cpu())
+
+
+def test_bind_rejects_wrong_tensor_list(dev):
+    """sdvar_vae_bind checks the tensor count against the descriptor (host logic of csrc/vae.hip) and leaves the object unbound."""
+    lib = E.load_library()
+    d = E._VaeDesc()
+    d.ch, d.z_channels, d.n_mult, d.num_res_blocks, d.max_batch, d.latent_hw = 32, 32, 5, 2, 1, 16
+    for i, m in enumerate((1, 1, 2, 2, 4)):
+        d.ch_mult[i] = m
+    h = C.c_void_p()
+    E._check(lib.sdvar_vae_create(C.byref(d), C.byref(h)))
+    t = torch.zeros(16, device=dev)
+    arr = (C.c_void_p * 3)(t.data_ptr(), t.data_ptr(), t.data_ptr())
+    assert lib.sdvar_vae_bind(h, arr, 3, _st()) != 0 and b"expected" in lib.sdvar_last_error()
+    img = torch.zeros(1, 3, 256, 256, device=dev); f = torch.zeros(1, 32, 16, 16, device=dev)
+    assert lib.sdvar_vae_decode(h, _p(f), 1, _p(img), _st()) != 0 and b"not bound" in lib.sdvar_last_error()
+    lib.sdvar_vae_destroy(h)
