@@ -14,6 +14,7 @@
 // ds_read_b128 of the 8-k fragments) refilled from registers that prefetch the next K-step while the MFMAs run;
 // tiles are walked in 8-wide column groups inside each XCD's block range so that co-resident workgroups share both
 // operand panels in the per-XCD L2.  Split-K and the epilogues are those of gemm.hip.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "common.h"
@@ -40,6 +41,8 @@ struct GemmPArgs {
     int M, N, K, ldo, ldres, rows_per_gate, gate_stride, split, k_per_split;
     unsigned long long* dbg_stamps;   // diagnostic builds only: per-workgroup s_memtime at entry / loop start / loop end / exit
     int dbg_same_tile;       // timing experiment only: every workgroup streams tile (0,0) (100 % L2 hits, results wrong)
+    int tile_off, tile_cnt;  // 256-row kernel only: this launch covers tile ids [tile_off, tile_off + tile_cnt) (tile_cnt = 0: all); with
+                             // PEPI_PARTIAL the slabs are compact [split][tile_cnt][256][128]
 };
 
 template <int BM, int WAVES_M, int WAVES_N, int EPI>
@@ -330,8 +333,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_v3_kernel(GemmPArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint16_t psm[];
     constexpr int BM = 256;
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + PBN - 1) / PBN, ntile = tiles_m * tiles_n;
-    const int ks = blockIdx.x / ntile;
-    const int lid = xcd_remap(blockIdx.x - ks * ntile, ntile);
+    const int tcnt = a.tile_cnt > 0 ? a.tile_cnt : ntile;
+    const int ks = blockIdx.x / tcnt;
+    const int lid = a.tile_off + xcd_remap(blockIdx.x - ks * tcnt, tcnt);
     const int G = 8, per_group = tiles_m * G;
     const int g = lid / per_group, rem = lid - g * per_group;
     const int gw = min(G, tiles_n - g * G);
@@ -433,6 +437,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_v3_kernel(GemmPArgs a) {
         if (n >= a.N) continue;
         const float bv = (EPI != PEPI_PARTIAL && a.bias) ? a.bias[n] : 0.f;
         float* outp = (EPI == PEPI_PARTIAL) ? a.out + (size_t)ks * a.M * a.ldo : a.out;
+        if (EPI == PEPI_PARTIAL && a.tile_cnt > 0) {         // tail tiles of a hybrid launch: compact slab of this (slice, tile)
+            float* slab = a.out + ((size_t)ks * a.tile_cnt + (lid - a.tile_off)) * (256 * 128);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    slab[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 128 + wn * 64 + j * 32 + li] = acc[i][j][r];
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -482,6 +495,48 @@ __global__ __launch_bounds__(256) void splitk_reduce_p_kernel(const float* __res
                 uint2 w;
                 w.x = (uint32_t)pl[p][0] | ((uint32_t)pl[p][1] << 16); w.y = (uint32_t)pl[p][2] | ((uint32_t)pl[p][3] << 16);
                 *reinterpret_cast<uint2*>(outp + p * ops + kb_index(m, n, M)) = w;
+            }
+        }
+    }
+}
+
+// Tail tiles of a hybrid launch of the 256-row kernel (launch_v3_hybrid): out = epi( sum_s slab[s][tile] + bias ) for the tiles
+// [tile_off, tile_off + tile_cnt); 4 workgroups per tile, the tile id -> (row tile, column tile) map is the kernel's.
+template <int EPI>
+__global__ __launch_bounds__(256) void splitk_reduce_tiles_kernel(const float* __restrict__ ws, int split, GemmPArgs a) {
+    const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + PBN - 1) / PBN;
+    const int t = blockIdx.x >> 5, part = blockIdx.x & 31, lid = a.tile_off + t;       // 32 workgroups per tile, 8 rows each
+    const int G = 8, per_group = tiles_m * G;
+    const int g = lid / per_group, rem = lid - g * per_group;
+    const int gw = min(G, tiles_n - g * G);
+    const int tm = rem / gw, tn = g * G + rem % gw;
+    const int m0 = tm * 256, n0 = tn * PBN;
+    const size_t slab = (size_t)a.tile_cnt * (256 * 128);
+    {
+        const int i = threadIdx.x;                               // 8 rows x 32 float4: one per thread
+        const int row = part * 8 + (i >> 5), c4 = (i & 31) * 4;
+        const int m = m0 + row, n = n0 + c4;
+        if (m >= a.M || n >= a.N) return;
+        const float* p = ws + (size_t)t * (256 * 128) + row * 128 + c4;
+        f32x4 acc = *reinterpret_cast<const f32x4*>(p);
+        for (int s2 = 1; s2 < split; ++s2) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(p + s2 * slab);
+            acc[0] += q[0]; acc[1] += q[1]; acc[2] += q[2]; acc[3] += q[3];
+        }
+        uint16_t pl[3][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = acc[e] + (a.bias ? a.bias[n + e] : 0.f);
+            if (EPI == PEPI_BIAS_GELU_PLANES) { split3(gelu_tanh_p(v), pl[0][e], pl[1][e], pl[2][e]); continue; }
+            if (EPI == PEPI_GATED_RES) v = a.res[(size_t)m * a.ldres + n + e] + v * a.gate[(size_t)(m / a.rows_per_gate) * a.gate_stride + n + e];
+            a.out[(size_t)m * a.ldo + n + e] = v;
+        }
+        if (EPI == PEPI_BIAS_GELU_PLANES) {
+#pragma unroll
+            for (int pp = 0; pp < 3; ++pp) {
+                uint2 w;
+                w.x = (uint32_t)pl[pp][0] | ((uint32_t)pl[pp][1] << 16); w.y = (uint32_t)pl[pp][2] | ((uint32_t)pl[pp][3] << 16);
+                *reinterpret_cast<uint2*>(a.outp + pp * a.ops + kb_index(m, n, a.M)) = w;
             }
         }
     }
@@ -540,9 +595,9 @@ static int g_force_bm_p = 0, g_force_split_p = 0;
 void debug_set_gemm_cfg_p(int bm, int split) { g_force_bm_p = bm; g_force_split_p = split; }
 
 // same cost model as gemm.hip::choose_cfg with this kernel's constants: 6 MFMAs x 32 cycles per 16 k per 32x32 tile
-static void choose_cfg_p(int M, int N, int K, size_t ws_floats, int* bm_out, int* split_out) {
+static void choose_cfg_p(int M, int N, int K, size_t ws_floats, int* bm_out, int* split_out, int* tail_out, bool allow_hybrid) {
     const int nkt = K / PBK, tiles_n = (N + PBN - 1) / PBN;
-    double best = 1e30; int bbm = 128, bs = 1;
+    double best = 1e30; int bbm = 128, bs = 1, btail = 0;
     // per row-tile constants fitted to tools/gemm_bench.py --mode bf16x3 --sweep --dump (tools/fit_gemm_model.py):
     //   resident workgroups per CU, K-step cost factor over the MFMA time, slowdown when 1 / 2 / 3 workgroups share a CU
     const int bms[4] = {256, 128, 64, 32};
@@ -564,10 +619,27 @@ static void choose_cfg_p(int M, int N, int K, size_t ws_floats, int* bm_out, int
             const double l_full = (bm == 256) ? 1.0 : lat[res < 4 ? res : 4], l_rem = (bm == 256) ? 1.0 : lat[rem < 4 ? rem : 4];
             double cyc = full * res * T * l_full + (rem ? rem * T * l_rem : 0.0);
             if (split > 1) cyc += CM_RED0 + (double)(split + 1) * M * N * 4.0 / CM_REDBW;
-            if (cyc < best) { best = cyc; bbm = bm; bs = split; }
+            if (cyc < best) { best = cyc; bbm = bm; bs = split; btail = 0; }
+        }
+        // hybrid for the 256-row tile: the full rounds run unsplit, only the last, partial round is split along K so that it, too,
+        // spreads over the CUs (264 tiles = 256 + 8: the 8 cost a whole second round otherwise)
+        if (allow_hybrid && bm == 256 && tiles > 256 && tiles % 256 && N % 4 == 0) {
+            const long fullr = tiles / 256, remt = tiles % 256;
+            const double Tfull = nkt * (ktile + CM_KOVER) + CM_FIX + CM_FIXBM * bm;
+            const int cand[7] = {2, 3, 4, 6, 8, 12, 16};
+            for (int ci = 0; ci < 7; ++ci) {
+                const int ts = cand[ci];
+                if (ts > nkt / 2 || (size_t)ts * remt * (256 * 128) > ws_floats) continue;
+                const int kps = (nkt + ts - 1) / ts;
+                if ((nkt + kps - 1) / kps != ts) continue;
+                const long rounds = (remt * ts + 255) / 256;
+                // the two extra launches are not free: ~10 us of prologue / slab epilogue / launch latency for the tail kernel, ~6 us for the reduce
+                const double cyc = fullr * Tfull + rounds * (kps * (ktile + CM_KOVER) + 20000.0) + 12000.0 + (double)(ts + 1) * remt * (256.0 * 128.0) * 4.0 / CM_REDBW;
+                if (cyc < best) { best = cyc; bbm = 256; bs = 1; btail = ts; }
+            }
         }
     }
-    *bm_out = bbm; *split_out = bs;
+    *bm_out = bbm; *split_out = bs; *tail_out = btail;
 }
 
 static thread_local int* g_defer = nullptr;     // set per call by gemm_bf16x3_nt; thread-local: host threads may drive different model objects concurrently
@@ -635,6 +707,37 @@ static int launch_v3(GemmPArgs a, int epi, int split, hipStream_t stream) {
     }
 }
 
+// full rounds unsplit + the partial last round split `tail` ways along K (compact slabs) + a reduce over the tail tiles only
+static int launch_v3_hybrid(GemmPArgs a, int epi, int tail, hipStream_t stream) {
+    const int tiles = ((a.M + 255) / 256) * ((a.N + PBN - 1) / PBN), full = tiles / 256 * 256, remt = tiles - full;
+    const int nkt = a.K / PBK;
+    size_t wsf = 0;
+    float* ws = splitk_workspace(&wsf);
+    if (!ws) return SDVAR_ERR_HIP;
+    GemmPArgs f = a;
+    f.split = 1; f.k_per_split = nkt; f.tile_off = 0; f.tile_cnt = full;
+    int rc;
+    switch (epi) {
+        case PEPI_BIAS: rc = launch_v3_kernel<PEPI_BIAS>(f, full, stream); break;
+        case PEPI_BIAS_GELU_PLANES: rc = launch_v3_kernel<PEPI_BIAS_GELU_PLANES>(f, full, stream); break;
+        default: rc = launch_v3_kernel<PEPI_GATED_RES>(f, full, stream); break;
+    }
+    if (rc) return rc;
+    GemmPArgs p = a;
+    p.out = ws; p.split = tail; p.k_per_split = (nkt + tail - 1) / tail; p.tile_off = full; p.tile_cnt = remt;
+    rc = launch_v3_kernel<PEPI_PARTIAL>(p, remt * tail, stream);
+    if (rc) return rc;
+    GemmPArgs r = a;
+    r.tile_off = full; r.tile_cnt = remt;
+    switch (epi) {
+        case PEPI_BIAS: hipLaunchKernelGGL(splitk_reduce_tiles_kernel<PEPI_BIAS>, dim3(32 * remt), dim3(256), 0, stream, ws, tail, r); break;
+        case PEPI_BIAS_GELU_PLANES: hipLaunchKernelGGL(splitk_reduce_tiles_kernel<PEPI_BIAS_GELU_PLANES>, dim3(32 * remt), dim3(256), 0, stream, ws, tail, r); break;
+        default: hipLaunchKernelGGL(splitk_reduce_tiles_kernel<PEPI_GATED_RES>, dim3(32 * remt), dim3(256), 0, stream, ws, tail, r); break;
+    }
+    SDVAR_LAUNCH_CHECK();
+    return SDVAR_OK;
+}
+
 template <int BM, int WAVES_M, int WAVES_N>
 static int launch_p(GemmPArgs a, int epi, int split, hipStream_t stream) {
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + PBN - 1) / PBN);
@@ -694,12 +797,15 @@ int gemm_bf16x3_nt(const uint16_t* X, size_t xps, const uint16_t* W, size_t wps,
     SDVAR_CHECK_ARG(((uintptr_t)X % 16) == 0 && ((uintptr_t)W % 16) == 0 && xps % 8 == 0 && wps % 8 == 0, "gemm_bf16x3: planes must be 16-byte aligned");
     if (epi == PEPI_GATED_RES) SDVAR_CHECK_ARG(res && gate && rows_per_gate > 0 && ldres >= N, "gemm_bf16x3: gated-residual epilogue needs res/gate");
     GemmPArgs a{X, W, xps, wps, bias, out, outp, ops, res, gate, M, N, K, ldo, ldres, rows_per_gate > 0 ? rows_per_gate : 1, gate_stride, 1, K / PBK,
-                g_dbg_stamps, getenv("SDVAR_DEBUG_SAME_TILE") ? atoi(getenv("SDVAR_DEBUG_SAME_TILE")) : 0};
+                g_dbg_stamps, getenv("SDVAR_DEBUG_SAME_TILE") ? atoi(getenv("SDVAR_DEBUG_SAME_TILE")) : 0, 0, 0};
     size_t wsf = 0;
     (void)splitk_workspace(&wsf);
-    int bm, split;
-    choose_cfg_p(M, N, K, wsf, &bm, &split);
-    if (g_force_bm_p) bm = g_force_bm_p;
+    int bm, split, tail = 0;
+    static const bool no_hybrid = getenv("SDVAR_GEMM_NO_HYBRID") != nullptr;       // A/B runs only
+    choose_cfg_p(M, N, K, wsf, &bm, &split, &tail, !no_hybrid);
+    if (g_force_bm_p) { bm = g_force_bm_p; tail = 0; }
+    static const bool trace = getenv("SDVAR_GEMM_TRACE") != nullptr;
+    if (trace) fprintf(stderr, "[gemm_bf16x3] M=%d N=%d K=%d epi=%d -> bm=%d split=%d tail=%d\n", M, N, K, epi, bm, split, tail);
     if (g_force_split_p) {
         split = g_force_split_p;
         const int nkt = K / PBK;
@@ -708,6 +814,7 @@ int gemm_bf16x3_nt(const uint16_t* X, size_t xps, const uint16_t* W, size_t wps,
         const int kps = (nkt + split - 1) / split;
         split = (nkt + kps - 1) / kps;
     }
+    if (bm == 256 && tail > 0) return launch_v3_hybrid(a, epi, tail, stream);
     if (bm == 256) return launch_v3(a, epi, split, stream);
     if (bm == 32) return launch_p<32, 1, 4>(a, epi, split, stream);
     if (bm == 64) return launch_p<64, 2, 2>(a, epi, split, stream);

@@ -448,3 +448,25 @@ def test_gemm_bf16x3_lds_dma_kernels_forced_tile(dev, M, N, K, split, epi, bm):
         got = out.cpu().double()
     err = (got - ref).abs().max().item()
     assert err <= 2e-5 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(2704, 3072, 1024, 0), (4096, 2304, 768, 0), (2704, 4096, 1024, 1), (4096, 3072, 768, 2), (2500, 3072, 256, 0)])
+def test_gemm_bf16x3_hybrid_tail_split(dev, M, N, K, epi):
+    """Shapes whose 256 x 128 tiles do not fill whole rounds of the 256 CUs: the full rounds run unsplit, the partial last round is split along K
+    (compact slabs) and reduced per tile.  The result must equal the plain kernels' (the 128-row kernel forced) to fp32 rounding."""
+    lib = E.load_library()
+    x = rnd(1, (M, K)).to(dev); w = (rnd(2, (N, K)) / K ** 0.5).to(dev); b = rnd(3, (N,), 0.1).to(dev)
+    res = rnd(4, (M, N)).to(dev); gate = rnd(5, (4, N)).to(dev)
+    xp, wp = _planes(x, dev), _planes(w, dev)
+
+    def run(force):
+        E._check(lib.sdvar_debug_set_gemm_cfg(*force))
+        out = res.clone() if epi == 2 else torch.zeros(M, N, device=dev)
+        outp = torch.zeros(3, N // 32, M, 32, device=dev, dtype=torch.int16)
+        E._check(lib.sdvar_op_gemm_bf16x3(_p(xp), M * K, _p(wp), N * K, _p(b), _p(out), N, _p(outp), M * N, M, N, K, epi, _p(out) if epi == 2 else None, N,
+                                          _p(gate) if epi == 2 else None, (M + 3) // 4, N, _st()))
+        E._check(lib.sdvar_debug_set_gemm_cfg(0, 0))
+        return _unplanes(outp.cpu()) if epi == 1 else out.cpu().double()
+    auto, ref = run((0, 0)), run((128, 1))
+    err = (auto - ref).abs().max().item()
+    assert err <= 3e-6 * max(1.0, ref.abs().max().item()), err
