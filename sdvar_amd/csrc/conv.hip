@@ -73,14 +73,17 @@ __global__ __launch_bounds__(512, 2) void conv_bf16x3_kernel(ConvArgs a) {
     const uint32_t lx1 = (uint32_t)((a.x_row0 + prow(min(m0 + xr1, a.M - 1))) * 32 + 8 * cx1) * 2u;
     const uint32_t lw0 = (uint32_t)(min(n0 + wr0, a.N - 1) * 32 + 8 * cw0) * 2u, lw1 = (uint32_t)(min(n0 + wr1, a.N - 1) * 32 + 8 * cw1) * 2u;
     const bool two_w = swave < 2;
-    // K-step t (global index kt0 + t) = (tap, channel block): X base = (cblk x_rows + tap shift) rows, W base = (kt0 + t) N rows
+    // K-step kb = (tap, channel block): X base = (cblk x_rows + tap shift) rows, W base = kb N rows.  (tap, cblk, tap row, tap column) are
+    // advanced incrementally: a division per K-step is emulated on the vector ALU (~200 instructions, which do not hide under the MFMAs).
     const char* ux = nullptr; const char* uw = nullptr;
-    auto set_step = [&](int t) {
-        const int kb = kt0 + t, tap = kb / a.cb, c = kb - tap * a.cb;
-        const int shift = (a.taps == 9) ? (tap / 3 - 1) * w2 + (tap % 3 - 1)
-                        : (a.taps == 4) ? ((tap >> 1) - 1 + (phase >> 1)) * w2 + ((tap & 1) - 1 + (phase & 1)) : 0;
-        ux = reinterpret_cast<const char*>(a.X) + ((long long)c * (long long)a.x_rows + shift) * 64;
-        uw = reinterpret_cast<const char*>(Wp) + (size_t)kb * a.N * 64;
+    const int tw = (a.taps == 9) ? 3 : 2;                       // taps per kernel row (3x3, or the 2x2 phase kernels)
+    int sc = kt0 % a.cb, stap = kt0 / a.cb, sty = stap / tw, stx = stap - sty * tw, skb = kt0;        // state of the NEXT step to set up
+    auto set_next = [&]() {
+        const int shift = (a.taps == 9) ? (sty - 1) * w2 + (stx - 1) : (a.taps == 4) ? (sty - 1 + (phase >> 1)) * w2 + (stx - 1 + (phase & 1)) : 0;
+        ux = reinterpret_cast<const char*>(a.X) + ((long long)sc * (long long)a.x_rows + shift) * 64;
+        uw = reinterpret_cast<const char*>(Wp) + (size_t)skb * a.N * 64;
+        ++skb;
+        if (++sc == a.cb) { sc = 0; if (++stx == tw) { stx = 0; ++sty; } }
     };
     // DMA instruction q of the current step -> stage st: q in [0, 9): plane q / 3, kind q % 3 (X group 0, X group 1, W group 0); q in [9, 12): W group 1 of plane q - 9
     auto issue_one = [&](uint16_t* st, int q) {
@@ -105,14 +108,14 @@ __global__ __launch_bounds__(512, 2) void conv_bf16x3_kernel(ConvArgs a) {
     const int offa = (wave * 32 + li) * 32, offb = 3 * 8192 + li * 32;       // element offsets inside a stage
     const int ch0 = 8 * ((0 + lh) ^ sw), ch1 = 8 * ((2 + lh) ^ sw);
 
-    set_step(0);
+    set_next();
 #pragma unroll
     for (int q = 0; q < 12; ++q) issue_one(csm, q);
     for (int t = 0; t < nk; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         const bool pf = t + 1 < nk;
-        if (pf) set_step(t + 1);
+        if (pf) set_next();
         uint16_t* nst = csm + ((t + 1) & 1) * CSTAGE;
         const uint32_t sb = (uint32_t)(uintptr_t)(lds_ptr_t)(csm + (t & 1) * CSTAGE);
         const uint32_t aa0 = sb + 2 * (offa + ch0), aa1 = sb + 2 * (offa + ch1), ab0 = sb + 2 * (offb + ch0), ab1 = sb + 2 * (offb + ch1);
