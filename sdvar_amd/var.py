@@ -188,6 +188,26 @@ class VAR(nn.Module):
         self.load_state_dict({k: v.to(self._device()) for k, v in sd.items()})
 
 
+try:                                                     # optional: only the from_pretrained / save_pretrained conveniences need it
+    from huggingface_hub import PyTorchModelHubMixin as _HubMixin
+except Exception:                                        # pragma: no cover - huggingface_hub not installed
+    class _HubMixin:                                     # type: ignore[no-redef]
+        pass
+
+
+class VARHF(VAR, _HubMixin):
+    """models/var.py:513-533: VAR that builds its own VQVAE from `vae_kwargs` and carries the Hugging Face hub mixin
+    (`VARHF.from_pretrained(local_dir)` loads a `config.json` + weights directory; there is no network on the GPU boxes)."""
+
+    def __init__(self, vae_kwargs, num_classes=1000, depth=16, embed_dim=1024, num_heads=16, mlp_ratio=4., drop_rate=0., attn_drop_rate=0.,
+                 drop_path_rate=0., norm_eps=1e-6, shared_aln=False, cond_drop_rate=0.1, attn_l2_norm=False,
+                 patch_nums=(1, 2, 3, 4, 5, 6, 8, 10, 13, 16), flash_if_available=True, fused_if_available=True):
+        super().__init__(vae_local=VQVAE(**vae_kwargs), num_classes=num_classes, depth=depth, embed_dim=embed_dim, num_heads=num_heads,
+                         mlp_ratio=mlp_ratio, drop_rate=drop_rate, attn_drop_rate=attn_drop_rate, drop_path_rate=drop_path_rate, norm_eps=norm_eps,
+                         shared_aln=shared_aln, cond_drop_rate=cond_drop_rate, attn_l2_norm=attn_l2_norm, patch_nums=patch_nums,
+                         flash_if_available=flash_if_available, fused_if_available=fused_if_available)
+
+
 class SDVAR(nn.Module):
     """Speculative draft -> verify sampler over a (draft, target) VAR pair (models/var.py:535-1383)."""
 

@@ -74,3 +74,15 @@ def test_vae_bind_order_matches_the_state_dict_walk():
         for i, m in enumerate((1, 1, 2, 2, 4)):
             d.ch_mult[i] = m
         assert lib.sdvar_vae_tensor_count(C.byref(d)) == 2 * len(names)
+
+
+def test_varhf_local_round_trip(tmp_path):
+    """models/var.py:513-533: VARHF builds its VQVAE from vae_kwargs and saves / loads through the hub mixin from a LOCAL directory."""
+    import torch
+    from sdvar_amd import VARHF
+    m = VARHF(vae_kwargs=dict(vocab_size=64, ch=32, with_encoder=False), depth=2, embed_dim=128, num_heads=2, attn_l2_norm=True)
+    with torch.no_grad():
+        m.pos_start.normal_()
+    m.save_pretrained(tmp_path)
+    m2 = VARHF.from_pretrained(tmp_path)
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
