@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SDVAR_ABI_VERSION 1
+#define SDVAR_ABI_VERSION 2
 #define SDVAR_MAX_STAGES 16
 
 typedef struct sdvar_model sdvar_model_t;   /* one VAR transformer: weights (borrowed), KV cache, workspaces */
@@ -76,6 +76,9 @@ int sdvar_model_place_first(sdvar_model_t* m, float* x, int32_t ltot, void* stre
 /* KV-cache cursor: number of valid keys; set_len(n) with n <= current is the rollback after a rejected round. */
 int sdvar_kv_len(const sdvar_model_t* m);
 int sdvar_kv_set_len(sdvar_model_t* m, int32_t len);
+/* Hand-off sampler (var.py:817-824, sd_mask = 0): the target starts at stage `stage` with an EMPTY cache - it never sees the
+ * draft's prefix - so cache slot 0 holds the first token of that stage.  Needs kv_len == 0; sdvar_model_begin resets it to stage 0. */
+int sdvar_kv_set_origin(sdvar_model_t* m, int32_t stage);
 /* next-stage input embedding + CFG duplication (var.py:186-188): nxt (B, l', cvae) -> x rows b and B+b,
  * x[(r*ltot + tok_off + t)*C + :] = word_embed(nxt[b][t]) + lvl_pos[begin(s_next) + t]. */
 int sdvar_embed_next(sdvar_model_t* m, const float* nxt, int32_t s_next, float* x, int32_t ltot, int32_t tok_off, void* stream);
@@ -83,6 +86,11 @@ int sdvar_embed_next(sdvar_model_t* m, const float* nxt, int32_t s_next, float* 
  * with the mask rows of var.py:108-113 derived from the stage table).  x (R, lsum, C) is the input and is CLOBBERED
  * (it is the residual stream); logits (R, lsum, V).  Requires kv_len == begin(s0); appends lsum keys. */
 int sdvar_stage_forward(sdvar_model_t* m, float* x, int32_t s0, int32_t n_stages, float* logits, void* stream);
+
+/* Final adaLN + vocabulary projection only (VAR.get_logits, var.py:119-125; basic_var.py:172-174) on a residual-stream tensor
+ * x (R, l, C) -> logits (R, l, V); x is left untouched.  The hand-off sampler with a prefill mask takes its entry-stage logits from
+ * the INPUT token map (var.py:809-811), which is this call. */
+int sdvar_head_forward(sdvar_model_t* m, const float* x, int32_t l, float* logits, void* stream);
 
 /* ---- quantizer ----------------------------------------------------------------------------------------------- */
 int sdvar_quant_create(int32_t n_stages, const int32_t* patch_nums /*host*/, int32_t cvae, int32_t vocab, int32_t max_batch,
@@ -94,6 +102,17 @@ int sdvar_quant_bind(sdvar_quant_t* q, const float* codebook, const float* const
 /* quant.py:187-196 for stage si: f_hat (B,cvae,HW,HW) += Phi(up(codebook[ids])) in place; nxt (B, pn_{si+1}^2, cvae)
  * = area_down(f_hat) (not written for the last stage; may be NULL there).  ids[b*ids_stride + p]. */
 int sdvar_quant_next(sdvar_quant_t* q, int32_t si, const int64_t* ids, int32_t ids_stride, float* f_hat, float* nxt, int32_t B, void* stream);
+/* the same with separate input and output accumulators: f_out = f_in + Phi(up(codebook[ids])); a draft round keeps one f_hat snapshot
+ * per drafted stage (var.py:1013-1022 recomputes them) without copies */
+int sdvar_quant_next_from(sdvar_quant_t* q, int32_t si, const int64_t* ids, int32_t ids_stride, const float* f_in, float* f_out, float* nxt,
+                          int32_t B, void* stream);
+/* the same from explicit feature vectors h (B, pn_si^2, cvae) instead of token ids (more_smooth=True, var.py:206-210) */
+int sdvar_quant_next_h(sdvar_quant_t* q, int32_t si, const float* h, float* f_hat, float* nxt, int32_t B, void* stream);
+/* more_smooth=True (var.py:206-208 + helpers.py:22-36): h (B,l,cvae) = softmax((masked * (1 + ratio) + g) / tau) @ codebook,
+ * g = -log(E), E ~ Exp(1): e_noise (B,l,V) explicit, or NULL for the Philox stream at (seed, draw, image_offset).  `masked_logits`
+ * (B,l,V) are the CFG logits as sample_with_top_k_top_p_ leaves them (helpers.py:10,15 mask in place): sdvar_cfg_sample's dbg_masked. */
+int sdvar_gumbel_mix(sdvar_quant_t* q, const float* masked_logits, int32_t B, int32_t l, double ratio, double tau, const float* e_noise,
+                     uint64_t seed, uint32_t draw, uint32_t image_offset, float* h_out, void* stream);
 
 /* ---- VQVAE decoder: f_hat -> image (the caller side of the sampler) ------------------ */
 typedef struct {
@@ -132,6 +151,16 @@ int sdvar_cfg_sample(const float* logits, int32_t B, int32_t l, int32_t V, doubl
 int sdvar_verify_accept(const float* logits, int32_t B, int32_t lsum, int32_t V, int32_t n_stages, const int32_t* stage_lens /*host*/,
                         const double* t /*host*/, const int64_t* draft_ids, int32_t ids_stride, double thr, int32_t* counts,
                         int64_t* argmax_out, void* stream);
+
+/* The richer acceptance rules sketched in SDVAR.advanced_token_matching (var.py:1229-1243).  rule 0: draft id == argmax (as above);
+ * 1: draft id among the target's top `match_top_k` (fewer than k entries score strictly higher); 2: KL(softmax target || softmax draft)
+ * <= kl_thr, with the draft's raw logits of the chunk in draft_logits (stage j stored as (2B, l_j, V) at element offset 2*B*V*qbeg_j).
+ * match_out (B, lsum) u8: per-token verdict; corrected_out (B, lsum): draft id where the rule holds, the target's argmax elsewhere
+ * (token-level partial acceptance).  Any of argmax_out / match_out / corrected_out may be NULL. */
+int sdvar_verify_accept_ex(const float* logits, int32_t B, int32_t lsum, int32_t V, int32_t n_stages, const int32_t* stage_lens /*host*/,
+                           const double* t /*host*/, const int64_t* draft_ids, int32_t ids_stride, double thr, int32_t rule, int32_t match_top_k,
+                           double kl_thr, const float* draft_logits, int32_t* counts, int64_t* argmax_out, uint8_t* match_out,
+                           int64_t* corrected_out, void* stream);
 
 /* ---- single operators (kernel-level parity tests and micro-benchmarks) ---------------------------------------------- */
 /* out[M,N] = epi(X[M,K] W[N,K]^T + bias); epi 0 bias, 1 bias+GELU(tanh), 2 res + (.)*gate[row / rows_per_gate] */

@@ -16,6 +16,9 @@ Reference lines followed (all under /root/reference/models/):
   sampler             helpers.py:6-19   (multinomial == argmax(p/q), q~Exp(1): SURVEY.md F6)
   quant next-input    quant.py:187-196, 199-206, 218-226 ; var.py:186-188, 205-211
   draft round         var.py:949-1024 ; acceptance var.py:1160-1227 ; loop policy var.py:1318-1372
+  hand-off sampler    var.py:604-865 (sd_mask 0 and 3) ; more_smooth var.py:206-208 + helpers.py:22-36
+  richer acceptance   var.py:1229-1243 is a stub in the reference (it returns the basic result): top-k membership, KL threshold
+                      and token-level partial acceptance below are this build's statement of its docstring - "parity unpinned"
   decode              vqvae.py:62-63, basic_vae.py:163-226, var.py:215
 """
 from __future__ import annotations
@@ -49,6 +52,7 @@ class OracleVAR:
         self.V = self.sd["head.weight"].shape[0]
         self.Cvae = self.sd["word_embed.weight"].shape[1]
         self.kv: List[Optional[Tuple[Tensor, Tensor]]] = [None] * depth
+        self.kv_base = 0              # token position of the cache's first key (hand-off sampler with sd_mask 0: the prefix is absent)
 
     def begin(self, s: int) -> int:
         return 0 if s == 0 else int(self.cum[s - 1])
@@ -66,6 +70,7 @@ class OracleVAR:
 
     def kv_reset(self):
         self.kv = [None] * self.depth
+        self.kv_base = 0
 
     def kv_len(self) -> int:
         return 0 if self.kv[0] is None else self.kv[0][0].shape[2]
@@ -115,10 +120,15 @@ class OracleVAR:
 
     # -- all blocks + head for one call (var.py:195-197, 119-125)
     def forward(self, x: Tensor, cond: Tensor, s0: int, n_stages: int = 1) -> Tensor:
-        assert self.kv_len() == self.begin(s0), (self.kv_len(), self.begin(s0))
+        assert self.kv_len() == self.begin(s0) - self.kv_base, (self.kv_len(), self.begin(s0), self.kv_base)
         mask = self.chunk_mask(s0, n_stages)
+        assert mask is None or self.kv_base == 0
         for i in range(self.depth):
             x = self._block(i, x, cond, mask)
+        return self.head(x, cond)
+
+    def head(self, x: Tensor, cond: Tensor) -> Tensor:
+        """VAR.get_logits (var.py:119-125, basic_var.py:172-174)."""
         sd, C = self.sd, self.C
         sc, sh = F.linear(F.silu(cond), sd["head_nm.ada_lin.1.weight"], sd["head_nm.ada_lin.1.bias"]).view(-1, 1, 2, C).unbind(2)
         h = F.layer_norm(x, (C,), eps=1e-6).mul(sc.add(1)).add_(sh)
@@ -208,6 +218,55 @@ def accept_scan(draft_ids: List[Tensor], cfg_logits: List[Tensor], thr: float = 
     return n, matched, total
 
 
+@dataclass
+class MatchRule:
+    """Mirror of sdvar_amd.engine.MatchRule (the token rule of the acceptance scan)."""
+    rule: str = "top1"          # 'top1' (var.py:1199-1203) | 'topk' | 'kl'
+    top_k: int = 1
+    kl_thr: float = 0.0
+    token_level: bool = False
+
+
+def token_matches(ids: Tensor, cfg_logits: Tensor, rule: MatchRule, draft_cfg_logits: Optional[Tensor] = None) -> Tensor:
+    """(B, l) bool: does the draft token satisfy the rule against the target's CFG logits (B, l, V)."""
+    if rule.rule == "top1":
+        return ids == torch.argmax(cfg_logits, dim=-1)
+    if rule.rule == "topk":         # fewer than k vocabulary entries score strictly higher than the draft token
+        xd = cfg_logits.gather(-1, ids.unsqueeze(-1))
+        return (cfg_logits > xd).sum(-1) < rule.top_k
+    if rule.rule == "kl":           # KL(softmax target || softmax draft), evaluated in float64 from the float32 logits
+        lt = cfg_logits.double().log_softmax(-1); ld = draft_cfg_logits.double().log_softmax(-1)
+        return (lt.exp() * (lt - ld)).sum(-1) <= float(np.float32(rule.kl_thr))
+    raise ValueError(rule.rule)
+
+
+def accept_scan_ex(draft_ids: List[Tensor], cfg_logits: List[Tensor], thr: float, rule: MatchRule, draft_cfg_logits: Optional[List[Tensor]] = None):
+    """accept_scan with an arbitrary token rule; also returns the per-stage match masks and the corrected ids
+    (draft id where the rule holds, target argmax elsewhere)."""
+    matched, total, masks, corrected, n, alive = [], [], [], [], 0, True
+    for j, (ids, lg) in enumerate(zip(draft_ids, cfg_logits)):
+        m = token_matches(ids, lg, rule, None if draft_cfg_logits is None else draft_cfg_logits[j])
+        masks.append(m); corrected.append(torch.where(m, ids, torch.argmax(lg, dim=-1)))
+        matched.append(int(m.sum().item())); total.append(m.numel())
+        rate = m.float().mean().item()
+        if alive and rate >= thr:
+            n += 1
+        else:
+            alive = False
+    return n, matched, total, masks, corrected
+
+
+def gumbel_mix(masked_cfg_logits: Tensor, ratio: float, e: Tensor, codebook: Tensor) -> Tensor:
+    """var.py:206-208 + helpers.py:22-36 (rng given, hard=False): softmax((logits * (1 + ratio) + (-log E)) / tau) @ codebook -> (B, l, Cvae).
+    `masked_cfg_logits` are the logits after the sampler masked them in place (helpers.py:10,15); e ~ Exp(1), shape (B, l, V)."""
+    tau = max(0.27 * (1 - ratio * 0.95), 0.005)
+    gumbels = (masked_cfg_logits.mul(1 + ratio) + (-e.log())) / tau
+    return gumbels.softmax(-1) @ codebook.unsqueeze(0)
+
+
+GUMBEL_DRAW = 0x40000000      # noise(draw | GUMBEL_DRAW, ...) is the stage's gumbel exponential, drawn right after its multinomial
+
+
 # ------------------------------------------------------------------------------------------------ plain AR
 @dataclass
 class ARTrace:
@@ -220,8 +279,19 @@ class ARTrace:
     margins: List[float] = field(default_factory=list)      # per sampler call: min relative top-2 gap of p/q (tie detector)
 
 
+def _stage_features(quant: OracleQuant, cl: Tensor, pn: int, top_k: int, top_p: float, noise: NoiseFn, draw: int, more_smooth: bool, ratio: float,
+                    margins: Optional[list]):
+    """Sample one stage (helpers.py:6-19) and return (ids, h (B, Cvae, pn, pn)): codebook rows, or the gumbel mix when more_smooth."""
+    B, l, V = cl.shape
+    ids, masked = sample_topk_topp(cl, top_k, top_p, noise(draw, B, l, V), margins)
+    if not more_smooth:
+        return ids, quant.embed_ids(ids, pn)
+    h = gumbel_mix(masked, ratio, noise(draw | GUMBEL_DRAW, B, l, V).view(B, l, V), quant.codebook)
+    return ids, h.transpose(1, 2).reshape(B, quant.codebook.shape[1], pn, pn)
+
+
 def plain_ar(model: OracleVAR, quant: OracleQuant, label_B: Tensor, cfg: float, top_k: int, top_p: float,
-             noise: NoiseFn, keep: bool = True) -> ARTrace:
+             noise: NoiseFn, keep: bool = True, more_smooth: bool = False) -> ARTrace:
     """var.py:127-215 up to (not including) the image decode."""
     B = label_B.shape[0]
     S = model.S
@@ -233,11 +303,11 @@ def plain_ar(model: OracleVAR, quant: OracleQuant, label_B: Tensor, cfg: float, 
         logits = model.forward(x, cond, si, 1)
         t = cfg * (si / (S - 1))
         cl = cfg_combine(logits, B, t)
-        ids, _ = sample_topk_topp(cl, top_k, top_p, noise(si, B, pn * pn, model.V), tr.margins)
+        ids, h = _stage_features(quant, cl, pn, top_k, top_p, noise, si, more_smooth, si / (S - 1), tr.margins)
         if keep:
             tr.logits.append(logits); tr.cfg_logits.append(cl); tr.x_in.append(x)
         tr.ids.append(ids)
-        f_hat, nxt = quant.next_input(si, f_hat, quant.embed_ids(ids, pn))
+        f_hat, nxt = quant.next_input(si, f_hat, h)
         if si != S - 1:
             x = model.embed_next(nxt, lvl_pos, si + 1)
     model.kv_reset()
@@ -245,9 +315,59 @@ def plain_ar(model: OracleVAR, quant: OracleQuant, label_B: Tensor, cfg: float, 
     return tr
 
 
+# ------------------------------------------------------------------------------------------------ hand-off sampler
+def handoff(draft: OracleVAR, target: OracleVAR, quant: OracleQuant, label_B: Tensor, cfg: float, top_k: int, top_p: float, noise: NoiseFn,
+            entry_num: int, sd_mask: int = 0, more_smooth: bool = False) -> ARTrace:
+    """SDVAR.sdvar_autoregressive_infer_cfg_sd_test3 (var.py:604-865) for sd_mask 0 and 3, up to the decode.  The draft samples stages
+    < entry_num (var.py:669-723); the target takes over the shared f_hat.  sd_mask 0: entry stage on an empty target cache (var.py:817-824).
+    sd_mask 3: prefix + entry stage through the target blocks under the block-causal mask (var.py:789, 802-804), entry-stage logits from
+    the INPUT token map (var.py:809-811, literal).  One noise stream, draw = stage index."""
+    assert sd_mask in (0, 3)
+    B, S, pns = label_B.shape[0], draft.S, draft.patch_nums
+    tr = ARTrace()
+    d_cond, d_lvl, d_x = draft.prologue(label_B)
+    f_hat = torch.zeros(B, draft.Cvae, pns[-1], pns[-1])
+    draft.kv_reset(); target.kv_reset()
+    hub = []                                                   # draft_token_hub: the next-scale maps (B, Cvae, pn', pn') of stages 1..entry_num
+    nxt = None
+    for si in range(min(entry_num, S)):
+        lg = draft.forward(d_x, d_cond, si, 1)
+        cl = cfg_combine(lg, B, cfg * (si / (S - 1)))
+        ids, h = _stage_features(quant, cl, pns[si], top_k, top_p, noise, si, more_smooth, si / (S - 1), tr.margins)
+        tr.ids.append(ids)
+        f_hat, nxt = quant.next_input(si, f_hat, h)
+        if si != S - 1:
+            hub.append(nxt)
+            d_x = draft.embed_next(nxt, d_lvl, si + 1)
+    draft.kv_reset()
+    if entry_num < S:
+        t_cond, t_lvl, t_first = target.prologue(label_B)
+        xs = [t_first] + [target.embed_next(n, t_lvl, i + 1) for i, n in enumerate(hub)]        # target inputs of stages 0..entry_num
+        for si in range(entry_num, S):
+            if si == entry_num:
+                x = xs[entry_num]
+                if sd_mask == 0:
+                    target.kv_base = target.begin(si)           # empty cache: the entry stage only sees itself
+                    lg = target.forward(x, t_cond, si, 1)
+                else:
+                    target.forward(torch.cat(xs, dim=1), t_cond, 0, entry_num + 1)                # fills the cache; logits unused
+                    lg = target.head(x, t_cond)
+            else:
+                lg = target.forward(x, t_cond, si, 1)
+            cl = cfg_combine(lg, B, cfg * (si / (S - 1)))
+            ids, h = _stage_features(quant, cl, pns[si], top_k, top_p, noise, si, more_smooth, si / (S - 1), tr.margins)
+            tr.ids.append(ids)
+            f_hat, nxt = quant.next_input(si, f_hat, h)
+            if si != S - 1:
+                x = target.embed_next(nxt, t_lvl, si + 1)
+        target.kv_reset()
+    tr.f_hat = f_hat
+    return tr
+
+
 # ------------------------------------------------------------------------------------------------ speculative loop
 def spec_decode(draft: OracleVAR, target: OracleVAR, quant: OracleQuant, label_B: Tensor, cfg: float, gamma: int,
-                top_k: int, top_p: float, noise: NoiseFn, thr: float = 0.5, keep: bool = False) -> ARTrace:
+                top_k: int, top_p: float, noise: NoiseFn, thr: float = 0.5, keep: bool = False, match: Optional[MatchRule] = None) -> ARTrace:
     """Resolved semantics of SDVAR.sdvar_autoregressive_infer_cfg_parallel_v1: draft gamma
     stages (var.py:949-1024), ONE target forward over them under the block-causal rows (var.py:1026-1070 intent),
     batch-level acceptance (var.py:1160-1227), commit / rollback, gamma policy (var.py:1353-1367, never break)."""
@@ -265,7 +385,7 @@ def spec_decode(draft: OracleVAR, target: OracleVAR, quant: OracleQuant, label_B
     while cur < S:
         g = min(gamma, S - cur)
         # ---- draft g stages
-        ids_r, fh_r, dx_r, tx_r = [], [], [d_x], [t_x]
+        ids_r, fh_r, dx_r, tx_r, dcl_r, nx_r = [], [], [d_x], [t_x], [], []
         f = f_acc
         for j in range(g):
             s = cur + j
@@ -273,9 +393,9 @@ def spec_decode(draft: OracleVAR, target: OracleVAR, quant: OracleQuant, label_B
             st["draft_stage_calls"] += 1
             cl = cfg_combine(lg, B, cfg * (s / (S - 1)))
             ids, _ = sample_topk_topp(cl, top_k, top_p, noise(draw, B, pns[s] ** 2, draft.V), tr.margins); draw += 1
-            ids_r.append(ids)
+            ids_r.append(ids); dcl_r.append(cl)
             f, nxt = quant.next_input(s, f, quant.embed_ids(ids, pns[s]))
-            fh_r.append(f)
+            fh_r.append(f); nx_r.append(nxt)
             if s + 1 < S:
                 dx_r.append(draft.embed_next(nxt, d_lvl, s + 1)); tx_r.append(target.embed_next(nxt, t_lvl, s + 1))
         # ---- one target forward over the g stages
@@ -285,9 +405,25 @@ def spec_decode(draft: OracleVAR, target: OracleVAR, quant: OracleQuant, label_B
         for j in range(g):
             n = pns[cur + j] ** 2
             cls.append(cfg_combine(tl[:, off:off + n], B, cfg * ((cur + j) / (S - 1)))); off += n
-        n_acc, matched, total = accept_scan(ids_r, cls, thr)
-        forced = False
-        if n_acc == 0:
+        rule = match or MatchRule()
+        n_acc, matched, total, _, corrected = accept_scan_ex(ids_r, cls, thr, rule, dcl_r)
+        forced, acc_tok = False, None
+        if n_acc < g and rule.token_level:
+            # token-level partial acceptance: stage cur + n_acc keeps its matching tokens, the others take the target's argmax
+            j = n_acc
+            acc_tok = sum(pns[cur + i] ** 2 for i in range(j)) + matched[j]
+            st["corrected_tokens"] = st.get("corrected_tokens", 0) + total[j] - matched[j]
+            st["corrected_stages"] = st.get("corrected_stages", 0) + 1
+            ids_r[j] = corrected[j]
+            fh_r[j], nxt = quant.next_input(cur + j, f_acc if j == 0 else fh_r[j - 1], quant.embed_ids(ids_r[j], pns[cur + j]))
+            if cur + j + 1 < S:
+                dx, tx = draft.embed_next(nxt, d_lvl, cur + j + 1), target.embed_next(nxt, t_lvl, cur + j + 1)
+                if len(dx_r) > j + 1:
+                    dx_r[j + 1], tx_r[j + 1] = dx, tx
+                else:
+                    dx_r.append(dx); tx_r.append(tx)
+            n_acc = j + 1
+        elif n_acc == 0:
             if gamma > 1:
                 gamma -= 1
             else:
@@ -301,7 +437,7 @@ def spec_decode(draft: OracleVAR, target: OracleVAR, quant: OracleQuant, label_B
             f_acc = fh_r[n_acc - 1]
             ids_acc.extend(ids_r[:n_acc])
             if not forced:
-                st["accepted_tokens"] += sum(pns[cur + j] ** 2 for j in range(n_acc))
+                st["accepted_tokens"] += sum(pns[cur + j] ** 2 for j in range(n_acc)) if acc_tok is None else acc_tok
             cur += n_acc
             if cur < S:
                 d_x, t_x = dx_r[n_acc], tx_r[n_acc]

@@ -35,10 +35,13 @@ int cfg_sample(const float* logits, int B, int l, int V, float one_plus_t, float
                uint32_t draw, uint32_t image_offset, long long* ids, int ids_stride, float* dbg_masked, hipStream_t stream);
 int noise_fill(float* q, int B, int l, int V, uint64_t seed, uint32_t draw, uint32_t image_offset, hipStream_t stream);
 int verify_accept(const float* logits, int B, int lsum, int V, int n_chunk, const int* qbeg, const float* one_plus_t, const float* t, const long long* draft_ids,
-                  int ids_stride, double thr, int* counts, long long* argmax_out, hipStream_t stream);
+                  int ids_stride, double thr, int mode, int top_k, float kl_thr, const float* draft_logits, const long long* dl_off, int* counts,
+                  long long* argmax_out, unsigned char* match_out, long long* corrected_out, hipStream_t stream);
+int gumbel_mix(const float* masked, int B, int l, int V, float scale, float tau, const float* e, uint64_t seed, uint32_t draw, uint32_t image_offset,
+               const float* codebook, int Cv, float* h, hipStream_t stream);
 void debug_set_gemm_cfg(int bm, int split);
-int quant_next(const long long* ids, int ids_stride, const float* codebook, const float* Wup, const float* phi_w, const float* phi_b, const float* Wdn,
-               float* up_scratch, float* f_hat, float* nxt, int B, int pn, int pn_next, int HW, int Cv, int last, hipStream_t stream);
+int quant_next(const long long* ids, int ids_stride, const float* hvec, const float* codebook, const float* Wup, const float* phi_w, const float* phi_b, const float* Wdn,
+               float* up_scratch, const float* f_in, float* f_hat, float* nxt, int B, int pn, int pn_next, int HW, int Cv, int last, hipStream_t stream);
 
 enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_GATED_RES = 2 };
 
@@ -118,6 +121,7 @@ struct sdvar_model {
     int* stage_of_tok;
     // run state
     int B, kv_len;
+    int kv_origin;       // token position of the cache's first key (0 except in the hand-off sampler: sdvar_kv_set_origin)
     bool begun;
 };
 
@@ -153,11 +157,17 @@ int sdvar_model_create(const sdvar_model_desc* desc, sdvar_model_t** out) {
     SDVAR_CHECK_ARG(desc->gemm_mode == 0 || desc->gemm_mode == 1, "model_create: gemm_mode %d (0 = fp32 MFMA, 1 = bf16x3 split operands)", desc->gemm_mode);
     SDVAR_CHECK_ARG(desc->max_chunk_stages >= 1 && desc->max_chunk_stages <= SDVAR_MAX_STAGES, "model_create: max_chunk_stages %d", desc->max_chunk_stages);
     sdvar_model* m = new sdvar_model();
+    struct Guard {          // every early return below (argument error, out of memory) releases what was allocated so far
+        sdvar_model* m; bool keep = false;
+        ~Guard() { if (!keep) sdvar_model_destroy(m); }
+    } guard{m};
+    m->lvl_pos = m->cond = m->cond_silu = m->x0 = m->ada = m->ada_head = m->xn = m->qkv = m->qbuf = m->att = m->hid = nullptr;
+    m->xn_p = m->att_p = m->hid_p = m->head_wp = nullptr; m->stage_of_tok = nullptr;
     m->d = *desc;
     m->C = 64 * desc->depth; m->H = desc->depth; m->S = desc->n_stages; m->Rmax = 2 * desc->max_batch;
     int c = 0;
     for (int s = 0; s < m->S; ++s) {
-        if (desc->patch_nums[s] < 1 || desc->patch_nums[s] > 64) { delete m; set_error("model_create: patch_nums[%d]=%d", s, desc->patch_nums[s]); return SDVAR_ERR_ARG; }
+        if (desc->patch_nums[s] < 1 || desc->patch_nums[s] > 64) { set_error("model_create: patch_nums[%d]=%d", s, desc->patch_nums[s]); return SDVAR_ERR_ARG; }
         m->lens[s] = desc->patch_nums[s] * desc->patch_nums[s]; c += m->lens[s]; m->cum[s] = c;
     }
     m->L = c;
@@ -174,7 +184,7 @@ int sdvar_model_create(const sdvar_model_desc* desc, sdvar_model_t** out) {
     m->blk.resize(desc->depth);
     for (auto& b : m->blk) memset(&b, 0, sizeof(b));
     m->embed_bound = m->head_bound = m->begun = false;
-    m->B = 0; m->kv_len = 0;
+    m->B = 0; m->kv_len = 0; m->kv_origin = 0;
     const size_t C = m->C, R = m->Rmax, M = R * (size_t)m->lmax;
     std::vector<int> sot(m->L);
     for (int s = 0, t = 0; s < m->S; ++s) for (int i = 0; i < m->lens[s]; ++i) sot[t++] = s;
@@ -212,6 +222,7 @@ int sdvar_model_create(const sdvar_model_desc* desc, sdvar_model_t** out) {
         SDVAR_HIP(hipMemset(b.vc, 0, kvb));
     }
     SDVAR_TRY(dmalloc(&m->ws_own, splitk_workspace_floats()));
+    guard.keep = true;
     *out = m;
     return SDVAR_OK;
 }
@@ -291,7 +302,7 @@ int sdvar_model_begin(sdvar_model_t* m, int32_t B, const int64_t* labels, void* 
     hipStream_t s = (hipStream_t)stream;
     WsScope wsg(m->ws_own);
     const int C = m->C, R = 2 * B;
-    m->B = B; m->kv_len = 0;
+    m->B = B; m->kv_len = 0; m->kv_origin = 0;
     {
         ProfScope ps(7, 0, 0, s);
         SDVAR_TRY(prologue((const long long*)labels, m->class_emb, m->pos_start, m->lvl_pos, m->cond, m->x0, B, C, m->d.num_classes, s));
@@ -341,6 +352,13 @@ int sdvar_kv_set_len(sdvar_model_t* m, int32_t len) {
     return SDVAR_OK;
 }
 
+int sdvar_kv_set_origin(sdvar_model_t* m, int32_t stage) {
+    SDVAR_CHECK_ARG(m && m->begun && stage >= 0 && stage < m->S, "kv_set_origin: stage %d", stage);
+    SDVAR_CHECK_ARG(m->kv_len == 0, "kv_set_origin: the cache holds %d keys (only an empty cache can be re-based)", m->kv_len);
+    m->kv_origin = begin_of(m, stage);
+    return SDVAR_OK;
+}
+
 int sdvar_embed_next(sdvar_model_t* m, const float* nxt, int32_t s_next, float* x, int32_t ltot, int32_t tok_off, void* stream) {
     SDVAR_CHECK_ARG(m && m->begun && nxt && x, "embed_next: model not begun or null");
     SDVAR_CHECK_ARG(s_next >= 1 && s_next < m->S && tok_off >= 0 && tok_off + m->lens[s_next] <= ltot, "embed_next: stage %d off %d ltot %d", s_next, tok_off, ltot);
@@ -352,13 +370,13 @@ int sdvar_stage_forward(sdvar_model_t* m, float* x, int32_t s0, int32_t n, float
     SDVAR_TRY(check_bound(m));
     SDVAR_CHECK_ARG(m->begun && x && logits, "stage_forward: model not begun or null buffers");
     SDVAR_CHECK_ARG(s0 >= 0 && n >= 1 && s0 + n <= m->S && n <= m->d.max_chunk_stages, "stage_forward: stages [%d,%d) invalid (S=%d, max chunk %d)", s0, s0 + n, m->S, m->d.max_chunk_stages);
-    if (m->kv_len != begin_of(m, s0)) { set_error("stage_forward: KV cache holds %d keys, stage %d needs %d", m->kv_len, s0, begin_of(m, s0)); return SDVAR_ERR_STATE; }
+    if (m->kv_len != begin_of(m, s0) - m->kv_origin) { set_error("stage_forward: KV cache holds %d keys, stage %d needs %d", m->kv_len, s0, begin_of(m, s0) - m->kv_origin); return SDVAR_ERR_STATE; }
     hipStream_t s = (hipStream_t)stream;
     WsScope wsg(m->ws_own);
     const int C = m->C, H = m->H, R = 2 * m->B, V = m->d.vocab;
     int qbeg[SDVAR_MAX_STAGES], vis[SDVAR_MAX_STAGES], lsum = 0;
     double lk = 0;
-    for (int j = 0; j < n; ++j) { qbeg[j] = lsum; lsum += m->lens[s0 + j]; vis[j] = m->cum[s0 + j]; lk += (double)m->lens[s0 + j] * vis[j]; }
+    for (int j = 0; j < n; ++j) { qbeg[j] = lsum; lsum += m->lens[s0 + j]; vis[j] = m->cum[s0 + j] - m->kv_origin; lk += (double)m->lens[s0 + j] * vis[j]; }
     const int M = R * lsum, Ktot = m->kv_len + lsum;
     const double dM = M, dC = C;
     const bool P = m->d.gemm_mode == 1;                               // bf16x3 split-operand GEMMs: inputs travel as planes
@@ -404,6 +422,23 @@ int sdvar_stage_forward(sdvar_model_t* m, float* x, int32_t s0, int32_t n, float
       if (P) SDVAR_TRY(gemm_bf16x3_nt(m->xn_p, ps, m->head_wp, (size_t)V * C, m->head_b, logits, V, nullptr, 0, M, V, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, nullptr, s));
       else SDVAR_TRY(gemm_f32_nt(m->xn, C, m->head_w, m->head_b, logits, V, M, V, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, s)); }
     m->kv_len = Ktot;
+    return SDVAR_OK;
+}
+
+int sdvar_head_forward(sdvar_model_t* m, const float* x, int32_t l, float* logits, void* stream) {
+    SDVAR_TRY(check_bound(m));
+    SDVAR_CHECK_ARG(m->begun && x && logits && l >= 1 && l <= m->lmax, "head_forward: model not begun, null buffers or l=%d > %d", l, m->lmax);
+    hipStream_t s = (hipStream_t)stream;
+    WsScope wsg(m->ws_own);
+    const int C = m->C, R = 2 * m->B, V = m->d.vocab, M = R * l;
+    const double dM = M, dC = C;
+    const bool P = m->d.gemm_mode == 1;
+    const size_t ps = (size_t)M * C;
+    { ProfScope pp(2, 8 * dM * dC, (P ? 10 : 8) * dM * dC, s);
+      SDVAR_TRY(ln_modulate(const_cast<float*>(x), m->ada_head, m->ada_head + C, m->xn, P ? m->xn_p : nullptr, ps, M, C, l, 2 * C, nullptr, s)); }
+    { ProfScope pp(0, 2 * dM * dC * V, 4 * (dM * dC + dC * V + dM * V), s);
+      if (P) SDVAR_TRY(gemm_bf16x3_nt(m->xn_p, ps, m->head_wp, (size_t)V * C, m->head_b, logits, V, nullptr, 0, M, V, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, nullptr, s));
+      else SDVAR_TRY(gemm_f32_nt(m->xn, C, m->head_w, m->head_b, logits, V, M, V, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, s)); }
     return SDVAR_OK;
 }
 
@@ -489,13 +524,37 @@ int sdvar_quant_bind(sdvar_quant_t* q, const float* codebook, const float* const
     return SDVAR_OK;
 }
 
-int sdvar_quant_next(sdvar_quant_t* q, int32_t si, const int64_t* ids, int32_t ids_stride, float* f_hat, float* nxt, int32_t B, void* stream) {
+static int quant_next_impl(sdvar_quant_t* q, int32_t si, const int64_t* ids, int32_t ids_stride, const float* hvec, const float* f_in, float* f_hat, float* nxt,
+                           int32_t B, void* stream) {
     SDVAR_CHECK_ARG(q && q->bound, "quant_next: quantizer not bound");
-    SDVAR_CHECK_ARG(si >= 0 && si < q->S && B >= 1 && B <= q->maxB && ids && f_hat, "quant_next: stage %d B %d", si, B);
+    SDVAR_CHECK_ARG(si >= 0 && si < q->S && B >= 1 && B <= q->maxB && (ids || hvec) && f_hat, "quant_next: stage %d B %d (max %d)", si, B, q ? q->maxB : 0);
     const int last = (si == q->S - 1), k = q->phi_of[si];
     ProfScope ps(6, 2.0 * B * q->Cv * q->Cv * 9.0 * q->HW * q->HW, 4.0 * B * q->Cv * q->HW * q->HW * 4.0, (hipStream_t)stream);
-    return quant_next((const long long*)ids, ids_stride, q->codebook, q->Wup[si], q->phi_w[k], q->phi_b[k], last ? nullptr : q->Wdn[si], q->up_scratch, f_hat, nxt,
-                      B, q->pn[si], last ? 0 : q->pn[si + 1], q->HW, q->Cv, last, (hipStream_t)stream);
+    return quant_next((const long long*)ids, ids_stride, hvec, q->codebook, q->Wup[si], q->phi_w[k], q->phi_b[k], last ? nullptr : q->Wdn[si], q->up_scratch,
+                      f_in, f_hat, nxt, B, q->pn[si], last ? 0 : q->pn[si + 1], q->HW, q->Cv, last, (hipStream_t)stream);
+}
+
+int sdvar_quant_next(sdvar_quant_t* q, int32_t si, const int64_t* ids, int32_t ids_stride, float* f_hat, float* nxt, int32_t B, void* stream) {
+    return quant_next_impl(q, si, ids, ids_stride, nullptr, nullptr, f_hat, nxt, B, stream);
+}
+
+int sdvar_quant_next_from(sdvar_quant_t* q, int32_t si, const int64_t* ids, int32_t ids_stride, const float* f_in, float* f_out, float* nxt, int32_t B, void* stream) {
+    SDVAR_CHECK_ARG(f_in && ids, "quant_next_from: null operand");
+    return quant_next_impl(q, si, ids, ids_stride, nullptr, f_in, f_out, nxt, B, stream);
+}
+
+int sdvar_quant_next_h(sdvar_quant_t* q, int32_t si, const float* h, float* f_hat, float* nxt, int32_t B, void* stream) {
+    SDVAR_CHECK_ARG(h, "quant_next_h: null feature vectors");
+    return quant_next_impl(q, si, nullptr, 0, h, nullptr, f_hat, nxt, B, stream);
+}
+
+int sdvar_gumbel_mix(sdvar_quant_t* q, const float* masked_logits, int32_t B, int32_t l, double ratio, double tau, const float* e_noise, uint64_t seed,
+                     uint32_t draw, uint32_t image_offset, float* h_out, void* stream) {
+    SDVAR_CHECK_ARG(q && q->bound && masked_logits && h_out, "gumbel_mix: quantizer not bound or null operand");
+    SDVAR_CHECK_ARG(tau > 0.0, "gumbel_mix: tau %g", tau);
+    // torch evaluates logits.mul(1 + ratio) and the division by tau with the python scalars rounded to float32 (var.py:206-208, helpers.py:27)
+    ProfScope ps(4, 2.0 * B * l * q->V * q->Cv, 4.0 * B * l * q->V * (e_noise ? 2.0 : 1.0), (hipStream_t)stream);
+    return gumbel_mix(masked_logits, B, l, q->V, (float)(1.0 + ratio), (float)tau, e_noise, seed, draw, image_offset, q->codebook, q->Cv, h_out, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------------- sampling
@@ -507,14 +566,21 @@ int sdvar_cfg_sample(const float* logits, int32_t B, int32_t l, int32_t V, doubl
                       (long long*)ids_out, ids_stride, dbg_masked, (hipStream_t)stream);
 }
 
+int sdvar_verify_accept_ex(const float* logits, int32_t B, int32_t lsum, int32_t V, int32_t n, const int32_t* stage_lens, const double* t,
+                           const int64_t* draft_ids, int32_t ids_stride, double thr, int32_t rule, int32_t match_top_k, double kl_thr,
+                           const float* draft_logits, int32_t* counts, int64_t* argmax_out, uint8_t* match_out, int64_t* corrected_out, void* stream) {
+    SDVAR_CHECK_ARG(stage_lens && t && n >= 1 && n <= SDVAR_MAX_STAGES, "verify_accept: bad stage table");
+    int qbeg[SDVAR_MAX_STAGES]; float opt[SDVAR_MAX_STAGES], tf[SDVAR_MAX_STAGES]; long long dl[SDVAR_MAX_STAGES]; int acc = 0;
+    for (int j = 0; j < n; ++j) { qbeg[j] = acc; dl[j] = (long long)2 * B * V * acc; acc += stage_lens[j]; opt[j] = (float)(1.0 + t[j]); tf[j] = (float)t[j]; }
+    SDVAR_CHECK_ARG(acc == lsum, "verify_accept: stage lens sum %d != lsum %d", acc, lsum);
+    ProfScope ps(5, 0, 4.0 * 2.0 * B * lsum * V * (rule == 2 ? 2.0 : 1.0), (hipStream_t)stream);
+    return verify_accept(logits, B, lsum, V, n, qbeg, opt, tf, (const long long*)draft_ids, ids_stride, thr, rule, match_top_k, (float)kl_thr, draft_logits, dl, counts,
+                         (long long*)argmax_out, match_out, (long long*)corrected_out, (hipStream_t)stream);
+}
+
 int sdvar_verify_accept(const float* logits, int32_t B, int32_t lsum, int32_t V, int32_t n, const int32_t* stage_lens, const double* t,
                         const int64_t* draft_ids, int32_t ids_stride, double thr, int32_t* counts, int64_t* argmax_out, void* stream) {
-    SDVAR_CHECK_ARG(stage_lens && t && n >= 1 && n <= SDVAR_MAX_STAGES, "verify_accept: bad stage table");
-    int qbeg[SDVAR_MAX_STAGES]; float opt[SDVAR_MAX_STAGES], tf[SDVAR_MAX_STAGES]; int acc = 0;
-    for (int j = 0; j < n; ++j) { qbeg[j] = acc; acc += stage_lens[j]; opt[j] = (float)(1.0 + t[j]); tf[j] = (float)t[j]; }
-    SDVAR_CHECK_ARG(acc == lsum, "verify_accept: stage lens sum %d != lsum %d", acc, lsum);
-    ProfScope ps(5, 0, 4.0 * 2.0 * B * lsum * V, (hipStream_t)stream);
-    return verify_accept(logits, B, lsum, V, n, qbeg, opt, tf, (const long long*)draft_ids, ids_stride, thr, counts, (long long*)argmax_out, (hipStream_t)stream);
+    return sdvar_verify_accept_ex(logits, B, lsum, V, n, stage_lens, t, draft_ids, ids_stride, thr, 0, 0, 0.0, nullptr, counts, argmax_out, nullptr, nullptr, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------- single ops

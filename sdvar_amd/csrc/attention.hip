@@ -271,12 +271,8 @@ int attention_f32(const float* q, const void* kc, const void* vc, int kv_f16, fl
     }
     a.qbeg[n_chunk] = l;
     const size_t lds = 2 * (size_t)(KT * KSTR + KT * 64) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        SDVAR_HIP(hipFuncSetAttribute((const void*)attention_f32_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        SDVAR_HIP(hipFuncSetAttribute((const void*)attention_f32_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    static LdsOptIn opt_in;
+    SDVAR_LDS_OPT_IN(opt_in, lds, (const void*)attention_f32_kernel<false>, (const void*)attention_f32_kernel<true>);
     if (kv_f16) hipLaunchKernelGGL(attention_f32_kernel<true>, dim3((l + 127) / 128, H, R), dim3(256), lds, stream, a);
     else hipLaunchKernelGGL(attention_f32_kernel<false>, dim3((l + 127) / 128, H, R), dim3(256), lds, stream, a);
     SDVAR_LAUNCH_CHECK();

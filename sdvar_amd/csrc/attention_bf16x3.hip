@@ -303,11 +303,8 @@ int attention_bf16x3(const float* q, const void* kc, const void* vc, float* out,
     }
     a.qbeg[n_chunk] = l;
     const size_t lds = ANST * (size_t)ASTAGE * sizeof(uint16_t);
-    static bool attr_set = false;
-    if (!attr_set) {
-        SDVAR_HIP(hipFuncSetAttribute((const void*)attention_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    static LdsOptIn opt_in;
+    SDVAR_LDS_OPT_IN(opt_in, lds, (const void*)attention_bf16x3_kernel);
     hipLaunchKernelGGL(attention_bf16x3_kernel, dim3((l + 127) / 128, H, R), dim3(256), lds, stream, a);
     SDVAR_LAUNCH_CHECK();
     return SDVAR_OK;

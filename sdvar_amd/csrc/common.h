@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
+
 #define SDVAR_OK 0
 #define SDVAR_ERR_ARG 1
 #define SDVAR_ERR_HIP 2
@@ -31,6 +33,26 @@ void set_error(const char* fmt, ...);
     } while (0)
 
 #define SDVAR_LAUNCH_CHECK() SDVAR_HIP(hipGetLastError())
+
+// Opt-in to more than 64 KiB of dynamic LDS, once per (launch site, device): one bit per device in an atomic mask, so a second
+// GPU driven from the same process gets the attribute too and concurrent host threads race only on an idempotent call.
+struct LdsOptIn {
+    std::atomic<uint64_t> done[4];
+    bool pending(int* dev) {
+        if (hipGetDevice(dev) != hipSuccess) *dev = 0;
+        return !((done[(*dev >> 6) & 3].load(std::memory_order_acquire) >> (*dev & 63)) & 1ull);
+    }
+    void mark(int dev) { done[(dev >> 6) & 3].fetch_or(1ull << (dev & 63), std::memory_order_release); }
+};
+#define SDVAR_LDS_OPT_IN(flag, bytes, ...)                                                                                       \
+    do {                                                                                                                         \
+        int dev_;                                                                                                                \
+        if ((flag).pending(&dev_)) {                                                                                             \
+            const void* fns_[] = {__VA_ARGS__};                                                                                  \
+            for (const void* f_ : fns_) SDVAR_HIP(hipFuncSetAttribute(f_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))); \
+            (flag).mark(dev_);                                                                                                   \
+        }                                                                                                                        \
+    } while (0)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));

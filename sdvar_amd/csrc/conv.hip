@@ -334,13 +334,8 @@ int conv_bf16x3(const uint16_t* X, size_t xps, size_t x_rows, int x_row0, const 
         a.k_per_split = kps; a.split = split;
     }
     const size_t lds = 2 * (size_t)CSTAGE * sizeof(uint16_t);      // 156 KB
-    static bool attr_set = false;
-    if (!attr_set) {
-        SDVAR_HIP(hipFuncSetAttribute((const void*)conv_bf16x3_kernel<CEPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        SDVAR_HIP(hipFuncSetAttribute((const void*)conv_bf16x3_kernel<CEPI_BIAS_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        SDVAR_HIP(hipFuncSetAttribute((const void*)conv_bf16x3_kernel<CEPI_PARTIAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    static LdsOptIn opt_in;
+    SDVAR_LDS_OPT_IN(opt_in, lds, (const void*)conv_bf16x3_kernel<CEPI_BIAS>, (const void*)conv_bf16x3_kernel<CEPI_BIAS_RES>, (const void*)conv_bf16x3_kernel<CEPI_PARTIAL>);
     if (split > 1) {
         ConvArgs p = a;
         p.out = ws;

@@ -25,9 +25,12 @@ struct PendingSplitK {
 
 // ------------------------------------------------------------------------------------------------ ln_modulate
 // x (rows, C) ; scale/shift: row r of the CFG batch = row / rows_per_img, element stride `mod_stride` between r's.
-constexpr int LN_MAX_V4 = 8;   // up to C = 64 lanes * 8 * 4 = 2048
+// A wave holds one row as LN_MAX_V4 float4 per lane: the kernels are instantiated for 4 / 8 / 12 (C <= 1024 / 2048 / 3072; VAR-d36-s,
+// the shared_aln checkpoint of var.py:16-19, has C = 2304) so that narrow models do not pay the registers of wide ones.
+constexpr int LN_MAX_C = 3072;
 
 // LayerNorm + modulation of one row held by one wave (v[i] = float4 number lane + 64 i of the row)
+template <int LN_MAX_V4>
 __device__ __forceinline__ void ln_row_finish(const f32x4* v, int lane, int row, const float* __restrict__ scale, const float* __restrict__ shift,
                                               float* __restrict__ out, uint16_t* __restrict__ outp, size_t ops, int rows, int C, int rows_per_img,
                                               int mod_stride, float eps) {
@@ -103,6 +106,7 @@ __device__ __forceinline__ f32x4 pending_residual(const PendingSplitK& pend, f32
     return xv;
 }
 
+template <int LN_MAX_V4>
 __global__ __launch_bounds__(256) void ln_modulate_kernel(float* __restrict__ x, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, float* __restrict__ out, uint16_t* __restrict__ outp,
                                                           size_t ops, int rows, int C, int rows_per_img, int mod_stride, float eps, PendingSplitK pend) {
@@ -122,12 +126,13 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(float* __restrict__ x,
             }
         }
     }
-    ln_row_finish(v, lane, row, scale, shift, out, outp, ops, rows, C, rows_per_img, mod_stride, eps);
+    ln_row_finish<LN_MAX_V4>(v, lane, row, scale, shift, out, outp, ops, rows, C, rows_per_img, mod_stride, eps);
 }
 
 // Same result bit for bit, one WORKGROUP per row, for a pending split-K residual at small row counts: with one wave per row
 // a 16-row stage has 16 waves on the whole chip summing up to 32 slabs each (37 us measured); here 256 threads share the
 // slab sum of one row (phase 1, through LDS) and wave 0 then normalises it exactly as above.
+template <int LN_MAX_V4>
 __global__ __launch_bounds__(256) void ln_modulate_row_kernel(float* __restrict__ x, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, float* __restrict__ out, uint16_t* __restrict__ outp,
                                                               size_t ops, int rows, int C, int rows_per_img, int mod_stride, float eps, PendingSplitK pend) {
@@ -146,7 +151,7 @@ __global__ __launch_bounds__(256) void ln_modulate_row_kernel(float* __restrict_
 #pragma unroll
     for (int i = 0; i < LN_MAX_V4; ++i)
         if (tid + 64 * i < nv) v[i] = vsm[tid + 64 * i];
-    ln_row_finish(v, tid, row, scale, shift, out, outp, ops, rows, C, rows_per_img, mod_stride, eps);
+    ln_row_finish<LN_MAX_V4>(v, tid, row, scale, shift, out, outp, ops, rows, C, rows_per_img, mod_stride, eps);
 }
 
 int ln_modulate(float* x, const float* scale, const float* shift, float* out, uint16_t* outp, size_t ops, int rows, int C, int rows_per_img,
@@ -156,10 +161,18 @@ int ln_modulate(float* x, const float* scale, const float* shift, float* out, ui
         SDVAR_CHECK_ARG(pend->bias && pend->gate && pend->split >= 1 && pend->rows_per_gate > 0 && pend->gate_stride % 4 == 0, "ln_modulate: bad pending split-K descriptor");
         pd = *pend;
     }
-    SDVAR_CHECK_ARG(C % 4 == 0 && C <= 64 * 4 * LN_MAX_V4 && rows > 0 && rows_per_img > 0, "ln_modulate: bad shape rows=%d C=%d", rows, C);
+    SDVAR_CHECK_ARG(C % 4 == 0 && C <= LN_MAX_C && rows > 0 && rows_per_img > 0, "ln_modulate: bad shape rows=%d C=%d (C <= %d)", rows, C, LN_MAX_C);
     SDVAR_CHECK_ARG(mod_stride % 4 == 0, "ln_modulate: mod_stride must be a multiple of 4");
-    if (pd.ws && rows < 1024) hipLaunchKernelGGL(ln_modulate_row_kernel, dim3(rows), dim3(256), 0, stream, x, scale, shift, out, outp, ops, rows, C, rows_per_img, mod_stride, 1e-6f, pd);
-    else hipLaunchKernelGGL(ln_modulate_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, scale, shift, out, outp, ops, rows, C, rows_per_img, mod_stride, 1e-6f, pd);
+    const bool by_row = pd.ws && rows < 1024;
+#define SDVAR_LN_LAUNCH(NV4)                                                                                                                   \
+    do {                                                                                                                                       \
+        if (by_row) hipLaunchKernelGGL(ln_modulate_row_kernel<NV4>, dim3(rows), dim3(256), 0, stream, x, scale, shift, out, outp, ops, rows, C, rows_per_img, mod_stride, 1e-6f, pd); \
+        else hipLaunchKernelGGL(ln_modulate_kernel<NV4>, dim3((rows + 3) / 4), dim3(256), 0, stream, x, scale, shift, out, outp, ops, rows, C, rows_per_img, mod_stride, 1e-6f, pd);  \
+    } while (0)
+    if (C <= 1024) SDVAR_LN_LAUNCH(4);
+    else if (C <= 2048) SDVAR_LN_LAUNCH(8);
+    else SDVAR_LN_LAUNCH(12);
+#undef SDVAR_LN_LAUNCH
     SDVAR_LAUNCH_CHECK();
     return SDVAR_OK;
 }

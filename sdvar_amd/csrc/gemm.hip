@@ -195,14 +195,9 @@ static int launch_cfg(GemmArgs a, int epi, int split, hipStream_t stream) {
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     const size_t lds = 2 * (size_t)(BM + BN) * LDS_STRIDE * sizeof(float);
     dim3 block(256);
-    static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in once per kernel
-    if (!attr_set) {
-        SDVAR_HIP(hipFuncSetAttribute((const void*)gemm_f32_nt_kernel<BM, BN, WAVES_M, WAVES_N, EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        SDVAR_HIP(hipFuncSetAttribute((const void*)gemm_f32_nt_kernel<BM, BN, WAVES_M, WAVES_N, EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        SDVAR_HIP(hipFuncSetAttribute((const void*)gemm_f32_nt_kernel<BM, BN, WAVES_M, WAVES_N, EPI_GATED_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        SDVAR_HIP(hipFuncSetAttribute((const void*)gemm_f32_nt_kernel<BM, BN, WAVES_M, WAVES_N, EPI_PARTIAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    static LdsOptIn opt_in;         // > 64 KiB of dynamic LDS needs the opt-in once per kernel and device
+    SDVAR_LDS_OPT_IN(opt_in, lds, (const void*)gemm_f32_nt_kernel<BM, BN, WAVES_M, WAVES_N, EPI_BIAS>, (const void*)gemm_f32_nt_kernel<BM, BN, WAVES_M, WAVES_N, EPI_BIAS_GELU>,
+                     (const void*)gemm_f32_nt_kernel<BM, BN, WAVES_M, WAVES_N, EPI_GATED_RES>, (const void*)gemm_f32_nt_kernel<BM, BN, WAVES_M, WAVES_N, EPI_PARTIAL>);
     const int nkt = a.K / BK;
     if (split > 1) {
         float* const ws = splitk_workspace(nullptr);          // the calling model's slabs, or this thread's

@@ -649,11 +649,8 @@ void debug_set_gemm_v2(int on) { g_use_v2 = on != 0; }
 template <int EPI>
 static int launch_v2_kernel(const GemmPArgs& a, int grid, hipStream_t stream) {
     const size_t lds = 3 * (size_t)V2_STAGE * sizeof(uint16_t);      // 144 KB
-    static bool attr_set = false;
-    if (!attr_set) {
-        SDVAR_HIP(hipFuncSetAttribute((const void*)gemm_bf16x3_v2_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    static LdsOptIn opt_in;
+    SDVAR_LDS_OPT_IN(opt_in, lds, (const void*)gemm_bf16x3_v2_kernel<EPI>);
     hipLaunchKernelGGL((gemm_bf16x3_v2_kernel<EPI>), dim3(grid), dim3(512), lds, stream, a);
     SDVAR_LAUNCH_CHECK();
     return SDVAR_OK;
@@ -662,11 +659,8 @@ static int launch_v2_kernel(const GemmPArgs& a, int grid, hipStream_t stream) {
 template <int EPI>
 static int launch_v3_kernel(const GemmPArgs& a, int grid, hipStream_t stream) {
     const size_t lds = 2 * (size_t)V3_STAGE * sizeof(uint16_t);      // 144 KB
-    static bool attr_set = false;
-    if (!attr_set) {
-        SDVAR_HIP(hipFuncSetAttribute((const void*)gemm_bf16x3_v3_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    static LdsOptIn opt_in;
+    SDVAR_LDS_OPT_IN(opt_in, lds, (const void*)gemm_bf16x3_v3_kernel<EPI>);
     hipLaunchKernelGGL((gemm_bf16x3_v3_kernel<EPI>), dim3(grid), dim3(512), lds, stream, a);
     SDVAR_LAUNCH_CHECK();
     return SDVAR_OK;

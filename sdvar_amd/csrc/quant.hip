@@ -17,13 +17,17 @@ namespace sdvar {
 constexpr int QMAX_HW = 64;
 
 // up (b, c): tmp[Y][x] = sum_y Wup[Y][y] h[y][x];  out[Y][X] = sum_x tmp[Y][x] Wup[X][x]
+// hvec != null: the stage's feature vectors are given directly as (B, pn*pn, Cv) instead of token ids (more_smooth=True mixes the
+// codebook softly, models/var.py:206-208)
 __global__ __launch_bounds__(256) void quant_up_kernel(const long long* __restrict__ ids, int ids_stride, const float* __restrict__ codebook,
-                                                       const float* __restrict__ Wup, float* __restrict__ up, int pn, int HW, int Cv, int identity) {
+                                                       const float* __restrict__ hvec, const float* __restrict__ Wup, float* __restrict__ up, int pn,
+                                                       int HW, int Cv, int identity) {
     extern __shared__ float sm[];
     float* hs = sm;                  // pn*pn
     float* tmp = sm + pn * pn;       // HW*pn
     const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    for (int p = tid; p < pn * pn; p += blockDim.x) hs[p] = codebook[(size_t)ids[(size_t)b * ids_stride + p] * Cv + c];
+    if (hvec) for (int p = tid; p < pn * pn; p += blockDim.x) hs[p] = hvec[((size_t)b * pn * pn + p) * Cv + c];
+    else for (int p = tid; p < pn * pn; p += blockDim.x) hs[p] = codebook[(size_t)ids[(size_t)b * ids_stride + p] * Cv + c];
     __syncthreads();
     float* dst = up + ((size_t)b * Cv + c) * HW * HW;
     if (identity) {                  // last stage: no interpolation (quant.py:193-196)
@@ -46,8 +50,10 @@ __global__ __launch_bounds__(256) void quant_up_kernel(const long long* __restri
 }
 
 // phi (b, co): f_hat[b][co] += 0.5*up[b][co] + 0.5*(bias[co] + sum_{ci,dy,dx} w[co][ci][dy][dx] up[b][ci][Y+dy-1][X+dx-1])
+// f_out = f_in + Phi mix (f_in == f_out: the in-place form of quant.py:191; distinct buffers keep the per-stage snapshots of a draft round
+// without extra copies)
 __global__ __launch_bounds__(256) void quant_phi_kernel(const float* __restrict__ up, const float* __restrict__ w, const float* __restrict__ bias,
-                                                        float* __restrict__ f_hat, int HW, int Cv) {
+                                                        const float* f_in, float* f_hat, int HW, int Cv) {
     const int co = blockIdx.x, b = blockIdx.y;
     const float* ub = up + (size_t)b * Cv * HW * HW;
     const float* wc = w + (size_t)co * Cv * 9;
@@ -71,7 +77,8 @@ __global__ __launch_bounds__(256) void quant_phi_kernel(const float* __restrict_
         }
         const float h = ub[(size_t)co * HW * HW + e];
         const float mixed = h * 0.5f + (acc + bias[co]) * 0.5f;
-        f_hat[((size_t)b * Cv + co) * HW * HW + e] += mixed;
+        const size_t o = ((size_t)b * Cv + co) * HW * HW + e;
+        f_hat[o] = f_in[o] + mixed;
     }
 }
 
@@ -100,15 +107,15 @@ __global__ __launch_bounds__(256) void quant_down_kernel(const float* __restrict
     }
 }
 
-int quant_next(const long long* ids, int ids_stride, const float* codebook, const float* Wup, const float* phi_w, const float* phi_b,
-               const float* Wdn, float* up_scratch, float* f_hat, float* nxt, int B, int pn, int pn_next, int HW, int Cv, int last,
+int quant_next(const long long* ids, int ids_stride, const float* hvec, const float* codebook, const float* Wup, const float* phi_w, const float* phi_b,
+               const float* Wdn, float* up_scratch, const float* f_in, float* f_hat, float* nxt, int B, int pn, int pn_next, int HW, int Cv, int last,
                hipStream_t stream) {
-    SDVAR_CHECK_ARG(ids && codebook && phi_w && phi_b && up_scratch && f_hat, "quant_next: null operand");
+    SDVAR_CHECK_ARG((ids || hvec) && codebook && phi_w && phi_b && up_scratch && f_hat, "quant_next: null operand");
     SDVAR_CHECK_ARG(B > 0 && pn > 0 && pn <= HW && HW <= QMAX_HW && (!last || pn == HW), "quant_next: bad sizes pn=%d HW=%d", pn, HW);
     const size_t lds_up = (size_t)(pn * pn + HW * pn) * sizeof(float);
-    hipLaunchKernelGGL(quant_up_kernel, dim3(Cv, B), dim3(256), lds_up, stream, ids, ids_stride, codebook, Wup, up_scratch, pn, HW, Cv, last);
+    hipLaunchKernelGGL(quant_up_kernel, dim3(Cv, B), dim3(256), lds_up, stream, ids, ids_stride, codebook, hvec, Wup, up_scratch, pn, HW, Cv, last);
     SDVAR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(quant_phi_kernel, dim3(Cv, B), dim3(256), 0, stream, up_scratch, phi_w, phi_b, f_hat, HW, Cv);
+    hipLaunchKernelGGL(quant_phi_kernel, dim3(Cv, B), dim3(256), 0, stream, up_scratch, phi_w, phi_b, f_in ? f_in : f_hat, f_hat, HW, Cv);
     SDVAR_LAUNCH_CHECK();
     if (!last) {
         SDVAR_CHECK_ARG(Wdn && nxt && pn_next > 0 && pn_next <= HW, "quant_next: missing down table");

@@ -278,7 +278,100 @@ int noise_fill(float* q, int B, int l, int V, uint64_t seed, uint32_t draw, uint
     return SDVAR_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ gumbel_mix
+// more_smooth=True (models/var.py:206-208, models/helpers.py:22-36): h = softmax((masked_cfg_logits * (1 + ratio) + g) / tau) @ codebook
+// with g = -log(E), E ~ Exp(1) drawn AFTER the multinomial of the same stage (explicit (B, l, V) input or the Philox stream
+// at draw | 0x40000000).  `masked` are the CFG logits as the sampler left them (top-k / top-p entries at -inf: the reference's
+// sampler masks its argument in place, helpers.py:10,15).  One workgroup per token; fp32 like the reference.
+struct GumbelArgs {
+    const float* masked;      // (B, l, V)
+    const float* e;           // (B, l, V) Exp(1) noise or null
+    const float* codebook;    // (V, Cv)
+    float* h;                 // (B, l, Cv)
+    int B, l, V, Cv;
+    float scale, tau;         // float32(1 + ratio), float32(tau)
+    uint32_t k0, k1, draw, image_offset;
+};
+
+__global__ __launch_bounds__(256) void gumbel_mix_kernel(GumbelArgs a) {
+    __shared__ float pv[NV];
+    __shared__ float redf[8];
+    __shared__ double redd[8];
+    __shared__ float part[8][32];
+    const int tid = threadIdx.x, tok = blockIdx.x, b = blockIdx.y, V = a.V;
+    const size_t row = ((size_t)b * a.l + tok) * V;
+    float y[VPT];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int v0 = 4 * (tid + 256 * j);
+        if (v0 < V) {
+            const f32x4 m4 = *reinterpret_cast<const f32x4*>(a.masked + row + v0);
+            float ev[4];
+            if (a.e) {
+                const f32x4 t4 = *reinterpret_cast<const f32x4*>(a.e + row + v0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ev[e] = t4[e];
+            } else {
+                uint32_t r4[4];
+                philox4x32_10((uint32_t)(v0 >> 2), (uint32_t)tok, a.image_offset + (uint32_t)b, a.draw, a.k0, a.k1, r4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ev[e] = -logf(((float)(r4[e] >> 9) + 0.5f) * 1.1920928955078125e-07f);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[4 * j + e] = __fdiv_rn(__fadd_rn(__fmul_rn(m4[e], a.scale), -logf(ev[e])), a.tau);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[4 * j + e] = -INFINITY;
+        }
+    }
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) mloc = fmaxf(mloc, y[i]);
+    const float mx = block_max(mloc, redf);
+    double ps = 0.0;
+    float ev[VPT];
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) { ev[i] = expf(y[i] - mx); ps += (double)ev[i]; }
+    const float ssum = (float)block_sum_d(ps, redd);
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) { const int v = 4 * (tid + 256 * (i >> 2)) + (i & 3); pv[v] = ev[i] / ssum; }
+    __syncthreads();
+    // h[c] = sum_v p[v] codebook[v][c]: thread = (slice of V, channel); masked entries have p = 0 exactly
+    const int Cv = a.Cv, c = tid % 32, sl = tid / 32;
+    for (int c0 = 0; c0 < Cv; c0 += 32) {
+        float acc = 0.f;
+        if (c0 + c < Cv) for (int v = sl; v < V; v += 8) { const float p = pv[v]; if (p != 0.f) acc = fmaf(p, a.codebook[(size_t)v * Cv + c0 + c], acc); }
+        part[sl][c] = acc;
+        __syncthreads();
+        if (tid < 32 && c0 + tid < Cv) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += part[k][tid];
+            a.h[((size_t)b * a.l + tok) * Cv + c0 + tid] = t;
+        }
+        __syncthreads();
+    }
+}
+
+int gumbel_mix(const float* masked, int B, int l, int V, float scale, float tau, const float* e, uint64_t seed, uint32_t draw, uint32_t image_offset,
+               const float* codebook, int Cv, float* h, hipStream_t stream) {
+    SDVAR_CHECK_ARG(masked && codebook && h && B > 0 && l > 0, "gumbel_mix: null/empty");
+    SDVAR_CHECK_ARG(V > 0 && V <= NV && V % 4 == 0 && Cv >= 1, "gumbel_mix: V=%d Cv=%d unsupported", V, Cv);
+    GumbelArgs a;
+    a.masked = masked; a.e = e; a.codebook = codebook; a.h = h; a.B = B; a.l = l; a.V = V; a.Cv = Cv; a.scale = scale; a.tau = tau;
+    a.k0 = (uint32_t)(seed & 0xFFFFFFFFull); a.k1 = (uint32_t)(seed >> 32) ^ 0x5D5A17ABu; a.draw = draw; a.image_offset = image_offset;
+    hipLaunchKernelGGL(gumbel_mix_kernel, dim3(l, B), dim3(256), 0, stream, a);
+    SDVAR_LAUNCH_CHECK();
+    return SDVAR_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ verify_accept
+// Token rule (`mode`): 0 = draft id == argmax_V target (basic_token_matching, var.py:1199-1203);
+// the richer rules sketched in advanced_token_matching (var.py:1229-1243):
+//   1 = draft id among the target's top-k (fewer than k vocabulary entries score strictly higher),
+//   2 = KL(softmax target || softmax draft) of the token's two CFG distributions <= kl_thr.
+// Besides the per-stage match counts the kernel can emit the per-token verdict and the "corrected" id
+// (draft id where the rule holds, the target's argmax elsewhere) for token-level partial acceptance.
 constexpr int ACC_MAX_CHUNK = 16;
 struct AcceptArgs {
     const float* logits;            // (2B, lsum, V) target logits of the chunk
@@ -289,11 +382,18 @@ struct AcceptArgs {
     int qbeg[ACC_MAX_CHUNK + 1];
     float one_plus_t[ACC_MAX_CHUNK], t[ACC_MAX_CHUNK];
     double thr;
+    int mode, top_k;
+    float kl_thr;
+    const float* draft_logits;      // mode 2: stage j at draft_logits + dl_off[j], shaped (2B, l_j, V)
+    long long dl_off[ACC_MAX_CHUNK];
+    unsigned char* match_out;       // optional (B, lsum)
+    long long* corrected_out;       // optional (B, lsum)
 };
 
 __global__ __launch_bounds__(256) void verify_match_kernel(AcceptArgs a) {
-    __shared__ float redf[4];
+    __shared__ float redf[8];
     __shared__ int redi[4];
+    __shared__ double redd[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tok = blockIdx.x, b = blockIdx.y, V = a.V;
     int st = 0;
@@ -302,13 +402,22 @@ __global__ __launch_bounds__(256) void verify_match_kernel(AcceptArgs a) {
     const float opt = a.one_plus_t[st], tt = a.t[st];
     const float* pc = a.logits + ((size_t)b * a.lsum + tok) * V;
     const float* pu = a.logits + ((size_t)(a.B + b) * a.lsum + tok) * V;
+    float x[VPT];
     float best = -INFINITY; int besti = 0x7FFFFFFF;
-    for (int v0 = 4 * tid; v0 < V; v0 += 1024) {
-        const f32x4 c = *reinterpret_cast<const f32x4*>(pc + v0), u = *reinterpret_cast<const f32x4*>(pu + v0);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float x = __fsub_rn(__fmul_rn(opt, c[e]), __fmul_rn(tt, u[e]));
-            if (x > best || besti == 0x7FFFFFFF) { best = x; besti = v0 + e; }
+    for (int j = 0; j < 4; ++j) {
+        const int v0 = 4 * (tid + 256 * j);
+        if (v0 < V) {
+            const f32x4 c = *reinterpret_cast<const f32x4*>(pc + v0), u = *reinterpret_cast<const f32x4*>(pu + v0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xv = __fsub_rn(__fmul_rn(opt, c[e]), __fmul_rn(tt, u[e]));
+                x[4 * j + e] = xv;
+                if (xv > best || besti == 0x7FFFFFFF) { best = xv; besti = v0 + e; }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[4 * j + e] = -INFINITY;
         }
     }
 #pragma unroll
@@ -318,11 +427,60 @@ __global__ __launch_bounds__(256) void verify_match_kernel(AcceptArgs a) {
     }
     if (lane == 0) { redf[wave] = best; redi[wave] = besti; }
     __syncthreads();
+    float bb = redf[0]; int bi = redi[0];
+    for (int w = 1; w < 4; ++w) if (redf[w] > bb || (redf[w] == bb && redi[w] < bi)) { bb = redf[w]; bi = redi[w]; }
+    const long long did = a.draft_ids[(size_t)b * a.ids_stride + tok];
+    bool match;
+    if (a.mode == 1) {              // top-k membership: count entries strictly above the draft token's score
+        const float xd = __fsub_rn(__fmul_rn(opt, pc[did]), __fmul_rn(tt, pu[did]));
+        int above = 0;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) above += (x[i] > xd) ? 1 : 0;
+        const double tot = block_sum_d((double)above, redd);
+        match = tot < (double)a.top_k;
+    } else if (a.mode == 2) {       // KL(p_target || p_draft) over the two CFG distributions of this token
+        const int lj = a.qbeg[st + 1] - a.qbeg[st], ti = tok - a.qbeg[st];
+        const float* dc = a.draft_logits + a.dl_off[st] + ((size_t)b * lj + ti) * V;
+        const float* du = a.draft_logits + a.dl_off[st] + ((size_t)(a.B + b) * lj + ti) * V;
+        float xd[VPT];
+        float dmax = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int v0 = 4 * (tid + 256 * j);
+            if (v0 < V) {
+                const f32x4 c = *reinterpret_cast<const f32x4*>(dc + v0), u = *reinterpret_cast<const f32x4*>(du + v0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { xd[4 * j + e] = __fsub_rn(__fmul_rn(opt, c[e]), __fmul_rn(tt, u[e])); dmax = fmaxf(dmax, xd[4 * j + e]); }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xd[4 * j + e] = -INFINITY;
+            }
+        }
+        __syncthreads();
+        dmax = block_max(dmax, redf + 4);
+        double st_ = 0.0, sd_ = 0.0;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) { st_ += (double)expf(x[i] - bb); sd_ += (double)expf(xd[i] - dmax); }
+        const double zt = block_sum_d(st_, redd), zd = block_sum_d(sd_, redd + 4);
+        const double lzt = log(zt), lzd = log(zd);
+        double kl = 0.0;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            if (x[i] == -INFINITY) continue;
+            const double lt = (double)(x[i] - bb) - lzt, ld = (double)(xd[i] - dmax) - lzd;
+            kl += exp(lt) * (lt - ld);
+        }
+        __syncthreads();
+        kl = block_sum_d(kl, redd);
+        match = kl <= (double)a.kl_thr;
+    } else {
+        match = (long long)bi == did;
+    }
     if (tid == 0) {
-        float bb = redf[0]; int bi = redi[0];
-        for (int w = 1; w < 4; ++w) if (redf[w] > bb || (redf[w] == bb && redi[w] < bi)) { bb = redf[w]; bi = redi[w]; }
         if (a.argmax_out) a.argmax_out[(size_t)b * a.lsum + tok] = bi;
-        if ((long long)bi == a.draft_ids[(size_t)b * a.ids_stride + tok]) atomicAdd(&a.counts[st], 1);
+        if (a.match_out) a.match_out[(size_t)b * a.lsum + tok] = match ? 1 : 0;
+        if (a.corrected_out) a.corrected_out[(size_t)b * a.lsum + tok] = match ? did : (long long)bi;
+        if (match) atomicAdd(&a.counts[st], 1);
     }
 }
 
@@ -341,13 +499,18 @@ __global__ void accept_scan_kernel(AcceptArgs a) {
 }
 
 int verify_accept(const float* logits, int B, int lsum, int V, int n_chunk, const int* qbeg, const float* one_plus_t, const float* t,
-                  const long long* draft_ids, int ids_stride, double thr, int* counts, long long* argmax_out, hipStream_t stream) {
+                  const long long* draft_ids, int ids_stride, double thr, int mode, int top_k, float kl_thr, const float* draft_logits,
+                  const long long* dl_off, int* counts, long long* argmax_out, unsigned char* match_out, long long* corrected_out, hipStream_t stream) {
     SDVAR_CHECK_ARG(logits && draft_ids && counts, "verify_accept: null operand");
-    SDVAR_CHECK_ARG(n_chunk >= 1 && n_chunk <= ACC_MAX_CHUNK && V % 4 == 0, "verify_accept: bad chunk/V");
+    SDVAR_CHECK_ARG(n_chunk >= 1 && n_chunk <= ACC_MAX_CHUNK && V % 4 == 0 && V <= NV, "verify_accept: bad chunk/V");
+    SDVAR_CHECK_ARG(mode >= 0 && mode <= 2, "verify_accept: mode %d (0 top-1, 1 top-k membership, 2 KL threshold)", mode);
+    SDVAR_CHECK_ARG(mode != 1 || top_k >= 1, "verify_accept: top-k membership needs k >= 1");
+    SDVAR_CHECK_ARG(mode != 2 || (draft_logits && dl_off), "verify_accept: the KL rule needs the draft logits of the chunk");
     AcceptArgs a;
     a.logits = logits; a.draft_ids = draft_ids; a.counts = counts; a.argmax_out = argmax_out;
     a.B = B; a.lsum = lsum; a.V = V; a.ids_stride = ids_stride; a.n_chunk = n_chunk; a.thr = thr;
-    for (int j = 0; j < n_chunk; ++j) { a.qbeg[j] = qbeg[j]; a.one_plus_t[j] = one_plus_t[j]; a.t[j] = t[j]; }
+    a.mode = mode; a.top_k = top_k; a.kl_thr = kl_thr; a.draft_logits = draft_logits; a.match_out = match_out; a.corrected_out = corrected_out;
+    for (int j = 0; j < n_chunk; ++j) { a.qbeg[j] = qbeg[j]; a.one_plus_t[j] = one_plus_t[j]; a.t[j] = t[j]; a.dl_off[j] = dl_off ? dl_off[j] : 0; }
     a.qbeg[n_chunk] = lsum;
     SDVAR_HIP(hipMemsetAsync(counts, 0, 40 * sizeof(int), stream));
     hipLaunchKernelGGL(verify_match_kernel, dim3(lsum, B), dim3(256), 0, stream, a);

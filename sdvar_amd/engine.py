@@ -25,6 +25,7 @@ from .noise import exponential_noise
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsdvar_hip.so")
 MAX_STAGES = 16
+ABI_VERSION = 2
 # GEMM arithmetic of the transformer blocks: 'f32' = fp32-in/fp32-accumulate MFMA; 'bf16x3' = exact 3-way bf16 split of both
 # operands, 6 bf16 MFMA products, fp32 accumulate (fp32-accurate, 2.67x the matrix-pipe throughput).  See DESIGN.md section 4.
 DEFAULT_GEMM_MODE = "bf16x3"
@@ -61,12 +62,17 @@ _SIGNATURES = {
     "sdvar_model_place_first": (_I, [_P, _P, _I, _P]),
     "sdvar_kv_len": (_I, [_P]),
     "sdvar_kv_set_len": (_I, [_P, _I]),
+    "sdvar_kv_set_origin": (_I, [_P, _I]),
+    "sdvar_head_forward": (_I, [_P, _P, _I, _P, _P]),
     "sdvar_embed_next": (_I, [_P, _P, _I, _P, _I, _I, _P]),
     "sdvar_stage_forward": (_I, [_P, _P, _I, _I, _P, _P]),
     "sdvar_quant_create": (_I, [_I, C.POINTER(_I), _I, _I, _I, _I, C.POINTER(_P)]),
     "sdvar_quant_destroy": (_I, [_P]),
     "sdvar_quant_bind": (_I, [_P, _P, C.POINTER(_P), C.POINTER(_P)]),
     "sdvar_quant_next": (_I, [_P, _I, _P, _I, _P, _P, _I, _P]),
+    "sdvar_quant_next_from": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _P]),
+    "sdvar_quant_next_h": (_I, [_P, _I, _P, _P, _P, _I, _P]),
+    "sdvar_gumbel_mix": (_I, [_P, _P, _I, _I, _D, _D, _P, _U64, _U32, _U32, _P, _P]),
     "sdvar_vae_create": (_I, [C.POINTER(_VaeDesc), C.POINTER(_P)]),
     "sdvar_vae_destroy": (_I, [_P]),
     "sdvar_vae_tensor_count": (_I, [C.POINTER(_VaeDesc)]),
@@ -74,6 +80,7 @@ _SIGNATURES = {
     "sdvar_vae_decode": (_I, [_P, _P, _I, _P, _P]),
     "sdvar_cfg_sample": (_I, [_P, _I, _I, _I, _D, _I, _D, _P, _U64, _U32, _U32, _P, _I, _P, _P]),
     "sdvar_verify_accept": (_I, [_P, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_D), _P, _I, _D, _P, _P, _P]),
+    "sdvar_verify_accept_ex": (_I, [_P, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_D), _P, _I, _D, _I, _I, _D, _P, _P, _P, _P, _P, _P]),
     "sdvar_op_gemm": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P]),
     "sdvar_op_ln_modulate": (_I, [_P, _P, _P, _P, _P, _U64, _I, _I, _I, _I, _P]),
     "sdvar_op_split_planes": (_I, [_P, _P, _I, _I, _U64, _P]),
@@ -105,7 +112,7 @@ def load_library(path: str = LIB_PATH):
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
-    if lib.sdvar_abi_version() != 1:
+    if lib.sdvar_abi_version() != ABI_VERSION:
         raise SdvarError("libsdvar_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -207,6 +214,14 @@ class ModelCtx:
     def kv_set_len(self, n: int):
         _check(self.lib.sdvar_kv_set_len(self.h, n))
 
+    def kv_set_origin(self, stage: int):
+        """Empty cache whose first key will be the first token of `stage` (hand-off sampler, var.py:817-824)."""
+        _check(self.lib.sdvar_kv_set_origin(self.h, stage))
+
+    def head_forward(self, x: torch.Tensor, l: int, logits: torch.Tensor):
+        """VAR.get_logits (var.py:119-125) on x (2B, l, C) -> logits (2B, l, V)."""
+        _check(self.lib.sdvar_head_forward(self.h, _ptr(x), l, _ptr(logits), _stream()))
+
     def close(self):
         if self.h:
             self.lib.sdvar_model_destroy(self.h); self.h = C.c_void_p()
@@ -236,13 +251,29 @@ class QuantCtx:
         self.pb = [_f32(vae_sd[f"{prefix}quant_resi.qresi_ls.{k}.bias"], self.device) for k in range(n_phi)]
         pn = (_I * self.lad.S)(*self.lad.patch_nums)
         self.h = C.c_void_p()
+        self.max_batch = int(max_batch)
         with torch.cuda.device(self.device):
             _check(self.lib.sdvar_quant_create(self.lad.S, pn, self.Cv, self.V, max_batch, n_phi, C.byref(self.h)))
         aw = (_P * n_phi)(*[t.data_ptr() for t in self.pw]); ab = (_P * n_phi)(*[t.data_ptr() for t in self.pb])
         _check(self.lib.sdvar_quant_bind(self.h, _ptr(self.codebook), aw, ab))
 
-    def next(self, si: int, ids: torch.Tensor, ids_stride: int, f_hat: torch.Tensor, nxt: Optional[torch.Tensor], B: int):
-        _check(self.lib.sdvar_quant_next(self.h, si, C.c_void_p(ids.data_ptr()), ids_stride, _ptr(f_hat), _ptr(nxt) if nxt is not None else None, B, _stream()))
+    def next(self, si: int, ids: torch.Tensor, ids_stride: int, f_hat: torch.Tensor, nxt: Optional[torch.Tensor], B: int, f_in: Optional[torch.Tensor] = None):
+        """quant.py:187-196 for stage si.  f_in given: f_hat = f_in + Phi(...) (f_in is left untouched), else f_hat += Phi(...)."""
+        nx = _ptr(nxt) if nxt is not None else None
+        if f_in is None:
+            _check(self.lib.sdvar_quant_next(self.h, si, C.c_void_p(ids.data_ptr()), ids_stride, _ptr(f_hat), nx, B, _stream()))
+        else:
+            _check(self.lib.sdvar_quant_next_from(self.h, si, C.c_void_p(ids.data_ptr()), ids_stride, _ptr(f_in), _ptr(f_hat), nx, B, _stream()))
+
+    def next_h(self, si: int, h: torch.Tensor, f_hat: torch.Tensor, nxt: Optional[torch.Tensor], B: int):
+        """The same from feature vectors h (B, pn^2, Cvae) instead of ids (more_smooth=True, var.py:206-210)."""
+        _check(self.lib.sdvar_quant_next_h(self.h, si, _ptr(h), _ptr(f_hat), _ptr(nxt) if nxt is not None else None, B, _stream()))
+
+    def gumbel_mix(self, masked: torch.Tensor, B: int, l: int, ratio: float, tau: float, e: Optional[torch.Tensor], seed: int, draw: int, image_offset: int,
+                   h_out: torch.Tensor):
+        """var.py:206-208 + helpers.py:22-36: soft codebook mix of the masked CFG logits under gumbel noise -> h (B, l, Cvae)."""
+        _check(self.lib.sdvar_gumbel_mix(self.h, _ptr(masked), B, l, float(ratio), float(tau), _ptr(e) if e is not None else None, seed & (2**64 - 1), draw,
+                                         image_offset, _ptr(h_out), _stream()))
 
     def close(self):
         if self.h:
@@ -357,13 +388,41 @@ def cfg_sample(logits: torch.Tensor, B: int, l: int, V: int, t: float, top_k: in
                                 _ptr(dbg_masked) if dbg_masked is not None else None, _stream()))
 
 
+GUMBEL_DRAW = 0x40000000      # Philox `draw` of a stage's gumbel noise = its sampler draw | GUMBEL_DRAW (the reference draws it right after the multinomial)
+
+
+@dataclass
+class MatchRule:
+    """Token rule of the acceptance scan.  'top1' is basic_token_matching (var.py:1199-1203, what the reference's advanced_token_matching
+    stub falls back to); 'topk' / 'kl' / token_level are the rules its docstring sketches (var.py:1229-1243), reference-unpinned:
+      topk        draft id among the target's `top_k` best CFG logits
+      kl          KL(softmax target || softmax draft) of the token's two CFG distributions <= kl_thr
+      token_level the first stage that fails the batch threshold is not re-drafted: its matching tokens are kept, the others take the
+                  target's argmax, and the stage is committed (the target contributes tokens; no gamma decay, no forced accepts)."""
+    rule: str = "top1"
+    top_k: int = 1
+    kl_thr: float = 0.0
+    token_level: bool = False
+
+    @property
+    def code(self) -> int:
+        return {"top1": 0, "topk": 1, "kl": 2}[self.rule]
+
+    @property
+    def basic(self) -> bool:
+        return self.rule == "top1" and not self.token_level
+
+
 def verify_accept(logits: torch.Tensor, B: int, lens: Sequence[int], V: int, ts: Sequence[float], ids: torch.Tensor, ids_off: int, ids_stride: int,
-                  thr: float, counts: torch.Tensor, argmax_out: Optional[torch.Tensor] = None):
+                  thr: float, counts: torch.Tensor, argmax_out: Optional[torch.Tensor] = None, rule: Optional[MatchRule] = None,
+                  draft_logits: Optional[torch.Tensor] = None, match_out: Optional[torch.Tensor] = None, corrected_out: Optional[torch.Tensor] = None):
     lib = load_library()
     n = len(lens)
-    _check(lib.sdvar_verify_accept(_ptr(logits), B, int(sum(lens)), V, n, (_I * n)(*lens), (_D * n)(*[float(t) for t in ts]),
-                                   C.c_void_p(ids.data_ptr() + 8 * ids_off), ids_stride, float(thr), _ptr(counts),
-                                   _ptr(argmax_out) if argmax_out is not None else None, _stream()))
+    o = lambda t: _ptr(t) if t is not None else None
+    r = rule or MatchRule()
+    _check(lib.sdvar_verify_accept_ex(_ptr(logits), B, int(sum(lens)), V, n, (_I * n)(*lens), (_D * n)(*[float(t) for t in ts]),
+                                      C.c_void_p(ids.data_ptr() + 8 * ids_off), ids_stride, float(thr), r.code, int(r.top_k), float(r.kl_thr),
+                                      o(draft_logits), _ptr(counts), o(argmax_out), o(match_out), o(corrected_out), _stream()))
 
 
 def prof_enable(on: bool):
@@ -417,6 +476,34 @@ class Sampler:
         self._counts_pin = torch.zeros(4 * lad.S, 40, dtype=torch.int32).pin_memory()
         self._row = 0
         self.counts_host = torch.zeros(40, dtype=torch.int32).pin_memory()
+        self._lazy: Dict[str, torch.Tensor] = {}      # buffers only some paths need (more_smooth, KL rule, token-level acceptance, hand-off)
+
+    def _buf(self, name: str, numel: int, dtype=torch.float32) -> torch.Tensor:
+        t = self._lazy.get(name)
+        if t is None or t.numel() < numel or t.dtype != dtype:
+            t = self._lazy[name] = torch.empty(numel, device=self.dev, dtype=dtype)
+        return t
+
+    def _sample_stage(self, logits: torch.Tensor, B: int, si: int, cfg: float, top_k: int, top_p: float, noise: Noise, draw: int,
+                      more_smooth: bool, f_hat: torch.Tensor, nxt: Optional[torch.Tensor], f_in: Optional[torch.Tensor] = None):
+        """CFG + top-k/top-p + multinomial (var.py:199-202), then the token -> feature step (var.py:205-211): codebook rows of the sampled ids,
+        or with more_smooth=True the gumbel-softmax mix of the masked logits (var.py:206-208)."""
+        lad, V, L, qz = self.lad, self.t.V, self.lad.L, self.q
+        l = lad.lens[si]
+        q = noise.tensor(draw, B, l, V, self.dev)
+        masked = self._buf("masked", B * lad.lens[-1] * V) if more_smooth else None
+        cfg_sample(logits, B, l, V, lad.cfg_t(cfg, si), top_k, top_p, q, noise.seed, draw, noise.image_offset, self.ids, lad.begin(si), L, masked)
+        last = si == lad.S - 1
+        if not more_smooth:
+            qz.next(si, self.ids[:, lad.begin(si):], L, f_hat, None if last else nxt, B, f_in=f_in)
+            return
+        assert f_in is None
+        ratio = si / (lad.S - 1)
+        tau = max(0.27 * (1 - ratio * 0.95), 0.005)                           # var.py:207
+        e = noise.tensor(draw | GUMBEL_DRAW, B, l, V, self.dev)                # the generator's next (B, l, V) exponential draw (helpers.py:26)
+        h = self._buf("h_soft", B * lad.lens[-1] * qz.Cv)
+        qz.gumbel_mix(masked, B, l, ratio, tau, e, noise.seed, draw | GUMBEL_DRAW, noise.image_offset, h)
+        qz.next_h(si, h, f_hat, None if last else nxt, B)
 
     @property
     def f_snap(self):
@@ -427,7 +514,8 @@ class Sampler:
         return self._nx[self._slot]
 
     # ---- VAR.autoregressive_infer_cfg (var.py:127-215) up to the decode
-    def plain_ar(self, labels: torch.Tensor, cfg: float, top_k: int, top_p: float, noise: Noise, trace: bool = False) -> SampleResult:
+    def plain_ar(self, labels: torch.Tensor, cfg: float, top_k: int, top_p: float, noise: Noise, trace: bool = False,
+                 more_smooth: bool = False) -> SampleResult:
         m, qz, lad = self.t, self.q, self.lad
         B, V, S, L = labels.shape[0], m.V, lad.S, lad.L
         res = SampleResult(ids=self.ids[:B], f_hat=self.f_work[:B])
@@ -440,18 +528,75 @@ class Sampler:
                 m.forward(self.x_t, si, 1, self.logits_t)
                 if trace:
                     res.trace.setdefault("logits", []).append(self.logits_t[:2 * B * l * V].view(2 * B, l, V).clone())
-                q = noise.tensor(si, B, l, V, self.dev)
-                cfg_sample(self.logits_t, B, l, V, lad.cfg_t(cfg, si), top_k, top_p, q, noise.seed, si, noise.image_offset, self.ids, lad.begin(si), L)
-                last = si == S - 1
-                qz.next(si, self.ids[:, lad.begin(si):], L, f_hat, None if last else self.nxt[0], B)
-                if not last:
+                self._sample_stage(self.logits_t, B, si, cfg, top_k, top_p, noise, si, more_smooth, f_hat, self.nxt[0])
+                if si != S - 1:
                     m.embed_next(self.nxt[0], si + 1, self.x_t, lad.lens[si + 1], 0)
             m.kv_set_len(0)
         res.stats = dict(target_calls=S, draft_stage_calls=0, forced_accepts=0, accepted_tokens=0)
         return res
 
+    # ---- SDVAR.sdvar_autoregressive_infer_cfg_sd_test3 (var.py:604-865): the draft samples stages < entry_num, the target the rest
+    def handoff(self, labels: torch.Tensor, cfg: float, top_k: int, top_p: float, noise: Noise, entry_num: int, sd_mask: int = 0,
+                more_smooth: bool = False) -> SampleResult:
+        """sd_mask 0: the target starts at the entry stage with an empty KV cache - it does not condition on the draft's prefix
+        (var.py:817-824).  sd_mask 3: the target first runs the whole prefix + entry stage through its blocks under the block-causal
+        mask (var.py:789, 802-804: this fills its cache), then - literally as the reference does - takes the entry stage's logits from
+        the INPUT token map, not from the block output (var.py:809-811).  One noise stream: draw index = stage (var.py:642, 689, 831)."""
+        assert self.d is not None, "the hand-off sampler needs a draft model"
+        d, t, qz, lad = self.d, self.t, self.q, self.lad
+        B, V, S, L, lens = labels.shape[0], t.V, lad.S, lad.L, lad.lens
+        if not (0 <= entry_num <= S):
+            raise SdvarError(f"entry_num {entry_num} outside [0, {S}]")
+        if sd_mask not in (0, 3):
+            raise NotImplementedError("sd_mask 1, 2, 4, 5 (block-wise ablation masks of var.py:557-578) are not built; 0 and 3 are")
+        res = SampleResult(ids=self.ids[:B], f_hat=self.f_work[:B])
+        prefill = sd_mask != 0 and entry_num < S
+        pindex = lad.cum[entry_num] if entry_num < S else L
+        if prefill and t.max_chunk < entry_num + 1:
+            raise SdvarError(f"sd_mask={sd_mask} prefills stages 0..{entry_num} in one pass: the target context needs max_chunk >= {entry_num + 1}")
+        with torch.cuda.device(self.dev):
+            f_hat = self.f_work[:B]; f_hat.zero_()
+            d.begin(labels); t.begin(labels)
+            x_pre = self._buf("x_prefill", 2 * B * pindex * t.Cw) if prefill else None
+            if prefill:
+                t.place_first(x_pre, pindex)
+            d.place_first(self.x_d, lens[0])
+            for si in range(min(entry_num, S)):                                  # var.py:669-723
+                d.forward(self.x_d, si, 1, self.logits_d)
+                self._sample_stage(self.logits_d, B, si, cfg, top_k, top_p, noise, si, more_smooth, f_hat, self.nxt[0])
+                if si != S - 1:
+                    d.embed_next(self.nxt[0], si + 1, self.x_d, lens[si + 1], 0)
+                    if prefill:                                                 # draft_token_hub -> target embedding of the prefix (var.py:713, 753)
+                        t.embed_next(self.nxt[0], si + 1, x_pre, pindex, lad.begin(si + 1))
+            d.kv_set_len(0)
+            for si in range(entry_num, S):                                       # var.py:768-859
+                l = lens[si]
+                if si == entry_num:
+                    if prefill:
+                        ent = self._buf("x_entry", 2 * B * l * t.Cw)             # the entry stage's slice of the input map, kept: the forward clobbers x
+                        src = x_pre[:2 * B * pindex * t.Cw].view(2 * B, pindex, t.Cw)[:, lad.begin(si):pindex]
+                        ent[:2 * B * l * t.Cw].view(2 * B, l, t.Cw).copy_(src)
+                        t.forward(x_pre, 0, entry_num + 1, self._buf("logits_prefill", 2 * B * pindex * V))   # fills the cache; its logits are not used
+                        t.head_forward(ent, l, self.logits_t)
+                    else:
+                        t.kv_set_origin(si)
+                        if si == 0:
+                            t.place_first(self.x_t, l)
+                        else:
+                            t.embed_next(self.nxt[0], si, self.x_t, l, 0)
+                        t.forward(self.x_t, si, 1, self.logits_t)
+                else:
+                    t.forward(self.x_t, si, 1, self.logits_t)
+                self._sample_stage(self.logits_t, B, si, cfg, top_k, top_p, noise, si, more_smooth, f_hat, self.nxt[0])
+                if si != S - 1:
+                    t.embed_next(self.nxt[0], si + 1, self.x_t, lens[si + 1], 0)
+            t.kv_set_len(0)
+        res.stats = dict(target_calls=S - min(entry_num, S), draft_stage_calls=min(entry_num, S), forced_accepts=0, accepted_tokens=0, entry_num=entry_num, sd_mask=sd_mask)
+        return res
+
     # ---- speculative draft -> verify loop (SURVEY.md App. C.1), as the reference's four steps
-    def spec_begin(self, labels: torch.Tensor, cfg: float, gamma: int, top_k: int, top_p: float, noise: Noise, thr: float = 0.5) -> "SpecState":
+    def spec_begin(self, labels: torch.Tensor, cfg: float, gamma: int, top_k: int, top_p: float, noise: Noise, thr: float = 0.5,
+                   match: Optional[MatchRule] = None) -> "SpecState":
         """SDVAR._initialize_inference_state (var.py:871-947): both prologues, empty caches, counters."""
         assert self.d is not None, "the speculative loop needs a draft model"
         assert 1 <= gamma <= self.t.max_chunk, f"gamma {gamma} exceeds the engine's max_chunk {self.t.max_chunk}"
@@ -460,7 +605,7 @@ class Sampler:
             self.f_acc[:labels.shape[0]].zero_()
         self._row, self._slot = 0, 0
         return SpecState(sampler=self, labels=labels, B=labels.shape[0], cfg=cfg, gamma=gamma, top_k=top_k, top_p=top_p, noise=noise, thr=thr,
-                         total_stages=self.lad.S, patch_nums=self.lad.patch_nums)
+                         total_stages=self.lad.S, patch_nums=self.lad.patch_nums, match=match or MatchRule())
 
     def spec_draft(self, st: "SpecState") -> int:
         """SDVAR.draft_generate_batch (var.py:949-1024): g = min(gamma, S - cur) draft stages (forward, CFG, sample, quant,
@@ -473,25 +618,26 @@ class Sampler:
         st.g, st.glen = g, lens[cur:cur + g]
         lsum = sum(st.glen)
         offs = [sum(st.glen[:j]) for j in range(g)]
-        f_acc, f_work = self.f_acc[:B], self.f_work[:B]
+        keep_logits = st.match.rule == "kl"        # the KL rule compares the two models' distributions: keep the draft's logits of the round
+        dl = self._buf("draft_logits", 2 * self.t.max_batch * self.lmax_t * V) if keep_logits else None
         with torch.cuda.device(self.dev):
             x_t = self._xt[st.xt_idx]
             if cur == 0:
                 d.place_first(self.x_d, lens[0]); t.place_first(x_t, lsum)
             else:
                 d.embed_next(self.nxt_cur, cur, self.x_d, lens[cur], 0); t.embed_next(self.nxt_cur, cur, x_t, lsum, 0)
-            f_work.copy_(f_acc)
             for j in range(g):
                 s = cur + j
-                d.forward(self.x_d, s, 1, self.logits_d)
+                lg = dl[2 * B * V * offs[j]:] if keep_logits else self.logits_d
+                d.forward(self.x_d, s, 1, lg)
                 st.stats["draft_stage_calls"] += 1
                 q = st.noise.tensor(st.draw, B, lens[s], V, self.dev)
-                cfg_sample(self.logits_d, B, lens[s], V, lad.cfg_t(st.cfg, s), st.top_k, st.top_p, q, st.noise.seed, st.draw, st.noise.image_offset,
+                cfg_sample(lg, B, lens[s], V, lad.cfg_t(st.cfg, s), st.top_k, st.top_p, q, st.noise.seed, st.draw, st.noise.image_offset,
                            self.ids, lad.begin(s), L)
                 st.draw += 1
                 last = s == S - 1
-                qz.next(s, self.ids[:, lad.begin(s):], L, f_work, None if last else self.nxt[j], B)
-                self.f_snap[j][:B].copy_(f_work)
+                # f_hat snapshot j = snapshot j-1 (the accepted prefix for j = 0) + this stage: written directly, nothing is copied
+                qz.next(s, self.ids[:, lad.begin(s):], L, self.f_snap[j][:B], None if last else self.nxt[j], B, f_in=self.f_acc[:B] if j == 0 else self.f_snap[j - 1][:B])
                 if j + 1 < g:
                     d.embed_next(self.nxt[j], s + 1, self.x_d, lens[s + 1], 0)
                     t.embed_next(self.nxt[j], s + 1, x_t, lsum, offs[j + 1])
@@ -514,8 +660,11 @@ class Sampler:
         """SDVAR.basic_token_matching (var.py:1160-1227) on the verified chunk: (n_accept, matched per stage)."""
         assert st.verified
         lad, cur, g = self.lad, st.current_stage, st.g
+        mr = st.match
         with torch.cuda.device(self.dev):
-            verify_accept(self.logits_t, st.B, st.glen, self.t.V, [lad.cfg_t(st.cfg, cur + j) for j in range(g)], self.ids, lad.begin(cur), lad.L, st.thr, self.counts)
+            corr = self._buf("ids_corr", self.t.max_batch * self.lmax_t, torch.int64) if mr.token_level else None
+            verify_accept(self.logits_t, st.B, st.glen, self.t.V, [lad.cfg_t(st.cfg, cur + j) for j in range(g)], self.ids, lad.begin(cur), lad.L, st.thr, self.counts,
+                          rule=mr, draft_logits=self._lazy.get("draft_logits") if mr.rule == "kl" else None, corrected_out=corr)
             self.counts_host.copy_(self.counts, non_blocking=False)            # the one host sync of the round
         c = self.counts_host.tolist()
         if st.accept_scope == "global":            # batch-wide decision across ranks (reference-literal for one big batch)
@@ -524,7 +673,22 @@ class Sampler:
             return n, matched
         return c[16], c[:g]
 
-    def spec_commit(self, st: "SpecState", n_acc: int, forced: bool = False):
+    def spec_correct(self, st: "SpecState", n_acc: int, matched: Sequence[int]) -> int:
+        """Token-level partial acceptance (the 'partial accept / token-level rollback' item of var.py:1229-1243): stage cur + n_acc failed the
+        batch threshold; keep its tokens that satisfy the rule, give the others the target's argmax (both already chosen by the verify kernel),
+        rebuild that stage's f_hat snapshot and next-scale input from the corrected ids, and return the number of stages to commit."""
+        lad, B, cur, j = self.lad, st.B, st.current_stage, n_acc
+        s, l, lsum, off = cur + j, st.glen[j], sum(st.glen), sum(st.glen[:j])
+        with torch.cuda.device(self.dev):
+            corr = self._lazy["ids_corr"][:B * lsum].view(B, lsum)
+            self.ids[:B, lad.begin(s):lad.begin(s) + l].copy_(corr[:, off:off + l])
+            last = s == lad.S - 1
+            self.q.next(s, self.ids[:, lad.begin(s):], lad.L, self.f_snap[j][:B], None if last else self.nxt[j], B, f_in=self.f_acc[:B] if j == 0 else self.f_snap[j - 1][:B])
+        st.stats["corrected_tokens"] = st.stats.get("corrected_tokens", 0) + B * l - matched[j]
+        st.stats["corrected_stages"] = st.stats.get("corrected_stages", 0) + 1
+        return n_acc + 1
+
+    def spec_commit(self, st: "SpecState", n_acc: int, forced: bool = False, accepted_tokens: Optional[int] = None):
         """SDVAR.update_state_with_accepted_tokens (var.py:1245-1282) + `current_stage += n` (var.py:1349-1350), and the
         rollback of both KV caches to the accepted prefix (absent in the reference)."""
         lad, B, cur = self.lad, st.B, st.current_stage
@@ -532,7 +696,7 @@ class Sampler:
             if n_acc > 0:
                 self.f_acc[:B].copy_(self.f_snap[n_acc - 1][:B])
                 if not forced:
-                    st.stats["accepted_tokens"] += sum(st.glen[:n_acc])
+                    st.stats["accepted_tokens"] += sum(st.glen[:n_acc]) if accepted_tokens is None else accepted_tokens
                 if cur + n_acc < lad.S:
                     self.nxt_cur.copy_(self.nxt[n_acc - 1])
                 st.current_stage = cur = cur + n_acc
@@ -547,10 +711,13 @@ class Sampler:
         st.stats["gamma_final"] = st.gamma
 
     def spec_decode(self, labels: torch.Tensor, cfg: float, gamma: int, top_k: int, top_p: float, noise: Noise, thr: float = 0.5,
-                    trace: bool = False, run_ahead: bool = True) -> SampleResult:
+                    trace: bool = False, run_ahead: bool = True, accept_scope: str = "shard", match: Optional[MatchRule] = None) -> SampleResult:
         """The whole loop with the policy of var.py:1318-1372 (gamma only decreases; forced accept at gamma == 1; never break).
-        run_ahead: once gamma has dropped to 1 the draft no longer waits for the verifier (see _spec_run_ahead); same results."""
-        st = self.spec_begin(labels, cfg, gamma, top_k, top_p, noise, thr)
+        run_ahead: once gamma has dropped to 1 the draft no longer waits for the verifier (see _spec_run_ahead); same results.
+        accept_scope "global": the batch-wide decision is taken across ranks (one all-reduce per round), always in lock-step."""
+        st = self.spec_begin(labels, cfg, gamma, top_k, top_p, noise, thr, match)
+        st.accept_scope = accept_scope
+        run_ahead = run_ahead and st.match.basic        # the richer rules run in lock-step
         res = SampleResult(ids=self.ids[:st.B], f_hat=self.f_acc[:st.B], stats=st.stats)
         optimistic = False                     # speculate on acceptance only after a round that was accepted in full
         while st.current_stage < st.total_stages:
@@ -568,8 +735,11 @@ class Sampler:
             if trace:
                 res.trace.setdefault("target_logits", []).append((cur, g, lg.clone()))
             n_acc, matched = self.spec_accept(st)
-            forced = False
-            if n_acc == 0:                                                      # var.py:1353-1364
+            forced, acc_tok = False, None
+            if n_acc < g and st.match.token_level:
+                acc_tok = sum(st.glen[:n_acc]) + matched[n_acc]
+                n_acc = self.spec_correct(st, n_acc, matched)
+            elif n_acc == 0:                                                    # var.py:1353-1364
                 if st.gamma > 1:
                     st.gamma -= 1
                 else:
@@ -577,7 +747,7 @@ class Sampler:
                     st.stats["forced_accepts"] += 1
             st.stats["rounds"].append(dict(stage=cur, g=g, matched=matched, total=[st.B * n for n in st.glen], n_accept=n_acc, forced=forced))
             optimistic = n_acc == g and not forced
-            self.spec_commit(st, n_acc, forced)
+            self.spec_commit(st, n_acc, forced, acc_tok)
         self.spec_end(st)
         return res
 
@@ -728,7 +898,8 @@ class SpecState:
     accept_count: int = 0
     reject_count: int = 0
     target_calls: int = 0
-    more_smooth: bool = False
+    more_smooth: bool = False                     # stored and never read on the speculative path, as in the reference (var.py:1315 vs 949-1024)
+    match: "MatchRule" = field(default_factory=lambda: MatchRule())
     accept_scope: str = "shard"                   # "shard": this process decides alone; "global": all-reduce of the match counts
     draw: int = 0
     xt_idx: int = 0                               # which target input buffer the current round uses (run-ahead double buffer)

@@ -138,7 +138,11 @@ class VAR(nn.Module):
         return self._ctx
 
     def quant_ctx(self, max_batch: int) -> E.QuantCtx:
-        if self._quant is None or self._quant.lad.patch_nums != self.patch_nums or self._quant.device != self._device():
+        q = self._quant
+        if q is None or q.lad.patch_nums != self.patch_nums or q.device != self._device() or q.max_batch < max_batch:
+            if q is not None:                                  # a larger batch than the cached quantizer was sized for: rebuild it
+                q.close()
+                self._sampler = None
             sd = {"quantize." + k: v for k, v in self.vae_quant_proxy[0].state_dict().items()}
             self._quant = E.QuantCtx(sd, self.patch_nums, max(max_batch, 1), self._device())
         return self._quant
@@ -164,17 +168,16 @@ class VAR(nn.Module):
     @torch.no_grad()
     def autoregressive_infer_cfg(self, B: int, label_B: Optional[Union[int, torch.LongTensor]], g_seed: Optional[int] = None, cfg=1.5,
                                  top_k=0, top_p=0.0, more_smooth=False) -> torch.Tensor:
-        if more_smooth:
-            raise NotImplementedError("more_smooth=True (gumbel visualisation path, helpers.py:22-36) is not built")
         if g_seed is None:
             rng = None
         else:
             self.rng.manual_seed(g_seed); rng = self.rng
         labels = self._labels(B, label_B, rng)
         ctx = self.engine_ctx(B, 1)
-        if self._sampler is None or self._sampler.t is not ctx:
-            self._sampler = E.Sampler(ctx, self.quant_ctx(ctx.max_batch))
-        res = self._sampler.plain_ar(labels, cfg, top_k, top_p, self._noise(g_seed))
+        qc = self.quant_ctx(ctx.max_batch)
+        if self._sampler is None or self._sampler.t is not ctx or self._sampler.q is not qc:
+            self._sampler = E.Sampler(ctx, qc)
+        res = self._sampler.plain_ar(labels, cfg, top_k, top_p, self._noise(g_seed), more_smooth=bool(more_smooth))   # more_smooth: var.py:206-208
         self.last_result = res
         return self.vae_proxy[0].fhat_to_img(res.f_hat.clone()).add_(1).mul_(0.5)
 
@@ -182,9 +185,13 @@ class VAR(nn.Module):
         raise NotImplementedError("teacher-forced training forward (var.py:217-259) is outside the sampling hot path")
 
     def init_weights(self, init_adaln=0.5, init_adaln_gamma=1e-5, init_head=0.02, init_std=0.02, conv_std_or_gain=0.02, seed: int = 1234):
-        """Distributions of var.py:261-311 drawn from a seeded generator (sdvar_amd.weights 'perf' init)."""
+        """Distributions of var.py:261-311 drawn from a seeded generator (sdvar_amd.weights 'perf' init): trunc-normal(init_std; < 0 =
+        sqrt(1/C/3)) Linear / Embedding / positional tensors, head x init_head, head_nm and the adaLN scale/shift rows x init_adaln, the
+        adaLN gamma rows x init_adaln_gamma, proj / fc2 / sqrt(2 depth), zero biases.  conv_std_or_gain only concerns convolutions, of
+        which a VAR has none (var.py:275)."""
         from .weights import var_state_dict
-        sd = var_state_dict(self.depth, self.patch_nums, "perf", seed, V=self.V, Cvae=self.Cvae, num_classes=self.num_classes, shared_aln=self.shared_aln)
+        sd = var_state_dict(self.depth, self.patch_nums, "perf", seed, V=self.V, Cvae=self.Cvae, num_classes=self.num_classes, shared_aln=self.shared_aln,
+                            init_adaln=init_adaln, init_adaln_gamma=init_adaln_gamma, init_head=init_head, init_std=init_std)
         self.load_state_dict({k: v.to(self._device()) for k, v in sd.items()})
 
 
@@ -216,6 +223,7 @@ class SDVAR(nn.Module):
         self.draft_model, self.target_model = draft_model, target_model
         self.similarity_thresh = similarity_thresh     # stored and never read, as in the reference (var.py:546)
         self.match_threshold = 0.5                      # the constant of var.py:1215
+        self.match_rule = E.MatchRule()                 # advanced_token_matching's rule (var.py:1229-1243); the default is the reference's fall-back
         self.noise_kind = "device"
         self.accept_scope = "shard"
         self._sampler: Optional[E.Sampler] = None
@@ -233,27 +241,32 @@ class SDVAR(nn.Module):
         f_hat = cond.new_zeros(B, model.Cvae, model.patch_nums[-1], model.patch_nums[-1])
         return cond, cond, cond, lvl_pos, first, f_hat
 
-    def _get_sampler(self, B: int, gamma: int) -> E.Sampler:
+    def _get_sampler(self, B: int, chunk: int) -> E.Sampler:
         d, t = self.draft_model, self.target_model
         assert d.patch_nums == t.patch_nums                                   # var.py:877
-        dc, tc = d.engine_ctx(B, 1), t.engine_ctx(B, max(gamma, 1))
+        dc, tc = d.engine_ctx(B, 1), t.engine_ctx(B, max(chunk, 1))
+        qc = t.quant_ctx(max(tc.max_batch, dc.max_batch))
         s = self._sampler
-        if s is None or s.t is not tc or s.d is not dc:
-            self._sampler = E.Sampler(tc, t.quant_ctx(tc.max_batch), dc)
+        if s is None or s.t is not tc or s.d is not dc or s.q is not qc:
+            self._sampler = E.Sampler(tc, qc, dc)
         return self._sampler
+
+    def _prepare(self, B: int, label_B, g_seed: Optional[int], chunk: int, rng: Optional[torch.Generator] = None):
+        """Labels, sampler objects and the noise source of one call (var.py:641-656, 880-902)."""
+        t = self.target_model
+        if g_seed is not None and rng is None:
+            rng = torch.Generator(device="cpu"); rng.manual_seed(g_seed)      # var.py:882-887
+        labels = t._labels(B, label_B, rng)
+        smp = self._get_sampler(B, chunk)
+        seed = int(torch.seed() & 0x7FFFFFFFFFFFFFFF) if g_seed is None else int(g_seed)
+        noise = E.Noise("torch", seed, generator=rng) if self.noise_kind == "torch" else E.Noise(self.noise_kind, seed)
+        return labels, smp, noise
 
     def _initialize_inference_state(self, B: int, label_B, g_seed: Optional[int], cfg: float, gamma: int) -> E.SpecState:
         """var.py:871-947.  The returned state carries the reference's field names (current_stage, gamma, total_stages,
         accept_count, target_calls, patch_nums, cfg, top_k, top_p, draft_f_hat, target_f_hat)."""
-        t = self.target_model
-        rng = None
-        if g_seed is not None:
-            rng = torch.Generator(device="cpu"); rng.manual_seed(g_seed)      # var.py:882-887
-        labels = t._labels(B, label_B, rng)
-        smp = self._get_sampler(B, gamma)
-        seed = int(torch.seed() & 0x7FFFFFFFFFFFFFFF) if g_seed is None else int(g_seed)
-        noise = E.Noise("torch", seed, generator=rng) if self.noise_kind == "torch" else E.Noise(self.noise_kind, seed)
-        st = smp.spec_begin(labels, cfg, gamma, 0, 0.0, noise, thr=self.match_threshold)       # top_k / top_p set by the caller (var.py:937-938)
+        labels, smp, noise = self._prepare(B, label_B, g_seed, gamma)
+        st = smp.spec_begin(labels, cfg, gamma, 0, 0.0, noise, thr=self.match_threshold, match=self.match_rule)   # top_k / top_p set by the caller (var.py:937-938)
         st.accept_scope = self.accept_scope
         return st
 
@@ -279,22 +292,37 @@ class SDVAR(nn.Module):
             off += n
         return out, state.g
 
-    def basic_token_matching(self, draft_tokens, target_logits, state, B: int) -> int:
-        """var.py:1160-1227 on arbitrary (tokens, CFG logits) lists: leading stages whose batch match rate is >= 0.5."""
+    def _match(self, draft_tokens, target_logits, B: int, rule: E.MatchRule, draft_logits=None):
         if not draft_tokens or not target_logits or len(draft_tokens) != len(target_logits):
-            return 0
+            return 0, None
         dev = target_logits[0].device
         lens = [int(t.shape[1]) for t in draft_tokens]
         ids = torch.cat([t.to(dev) for t in draft_tokens], 1).contiguous()
         lg = torch.cat(target_logits, 1)
         lg2 = torch.cat([lg, lg], 0).contiguous()          # t = 0 makes the kernel's CFG the identity on the first B rows
+        dl = None
+        if rule.rule == "kl":
+            if draft_logits is None or len(draft_logits) != len(draft_tokens):
+                raise ValueError("the KL rule compares distributions: pass the draft's CFG logits per stage (draft_logits=[(B, pn^2, V), ...])")
+            dl = torch.cat([torch.cat([d, d], 0).reshape(-1) for d in draft_logits]).to(dev).contiguous()     # stage j as (2B, l_j, V)
         counts = torch.zeros(40, dtype=torch.int32, device=dev)
+        match = torch.zeros(B, ids.shape[1], dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
-            E.verify_accept(lg2, B, lens, lg.shape[-1], [0.0] * len(lens), ids, 0, ids.shape[1], self.match_threshold, counts)
-        return int(counts[16].item())
+            E.verify_accept(lg2, B, lens, lg.shape[-1], [0.0] * len(lens), ids, 0, ids.shape[1], self.match_threshold, counts, rule=rule, draft_logits=dl,
+                            match_out=match)
+        return int(counts[16].item()), match
 
-    def advanced_token_matching(self, draft_tokens, target_logits, state, B: int) -> int:
-        return self.basic_token_matching(draft_tokens, target_logits, state, B)       # the reference's stub does the same (var.py:1229-1243)
+    def basic_token_matching(self, draft_tokens, target_logits, state, B: int) -> int:
+        """var.py:1160-1227 on arbitrary (tokens, CFG logits) lists: leading stages whose batch match rate is >= 0.5."""
+        return self._match(draft_tokens, target_logits, B, E.MatchRule())[0]
+
+    def advanced_token_matching(self, draft_tokens, target_logits, state, B: int, draft_logits=None) -> int:
+        """var.py:1229-1243.  The reference's body is a stub that returns basic_token_matching; with the default `self.match_rule` this does
+        the same.  Setting `self.match_rule = MatchRule('topk', top_k=k)` / `MatchRule('kl', kl_thr=x)` switches on the rules its docstring
+        lists (top-k membership, KL threshold); `token_level=True` (partial acceptance) acts in the sampling loop, see
+        sdvar_amd.engine.Sampler.spec_correct.  The per-token verdicts of the last call are kept in `self.last_match`."""
+        n, self.last_match = self._match(draft_tokens, target_logits, B, self.match_rule, draft_logits)
+        return n
 
     def update_state_with_accepted_tokens(self, draft_tokens, accept_length: int, state: E.SpecState, B: int):
         """var.py:1245-1282 (+ the stage advance of var.py:1349-1350 and the KV rollback the reference lacks)."""
@@ -303,29 +331,29 @@ class SDVAR(nn.Module):
     @torch.no_grad()
     def sdvar_autoregressive_infer_cfg_parallel_v1(self, B: int, label_B: Optional[Union[int, torch.LongTensor]] = None, g_seed: Optional[int] = None,
                                                    cfg: float = 1.5, gamma: int = 2, top_k: int = 0, top_p: float = 0.0, more_smooth: bool = False) -> torch.Tensor:
-        """var.py:1284-1383 with the resolved semantics of SURVEY.md App. C.1."""
-        if more_smooth:
-            raise NotImplementedError("more_smooth=True is not built")
+        """var.py:1284-1383 with the resolved semantics of SURVEY.md App. C.1: ONE call of engine.Sampler.spec_decode, i.e. the loop the
+        step-wise helpers above spell out, with the verifier running behind / ahead of the draft where the policy allows it (same tokens,
+        same counters: tests/test_gpu_e2e.py).  more_smooth is accepted and, exactly as in the reference, has no effect on this path
+        (var.py:1315 stores it, draft_generate_batch var.py:949-1024 never reads it)."""
         t = self.target_model
-        state = self._initialize_inference_state(B, label_B, g_seed, cfg, gamma)
-        state.top_k, state.top_p = top_k, top_p                               # var.py:1313-1314
-        smp = state.sampler
-        while state.current_stage < state.total_stages:                       # var.py:1318
-            cur = state.current_stage
-            g = smp.spec_draft(state)
-            smp.spec_verify_forward(state)
-            n_acc, matched = smp.spec_accept(state)
-            forced = False
-            if n_acc == 0:                                                    # var.py:1353-1364 (and never `break`: SURVEY F2e)
-                if state.gamma > 1:
-                    state.gamma -= 1
-                else:
-                    n_acc, forced = 1, True
-                    state.stats["forced_accepts"] += 1
-            state.stats["rounds"].append(dict(stage=cur, g=g, matched=matched, total=[B * n for n in state.glen], n_accept=n_acc, forced=forced))
-            smp.spec_commit(state, n_acc, forced)
-        smp.spec_end(state)
-        res = E.SampleResult(ids=smp.ids[:B], f_hat=smp.f_acc[:B], stats=state.stats)
+        labels, smp, noise = self._prepare(B, label_B, g_seed, gamma)
+        res = smp.spec_decode(labels, cfg, gamma, top_k, top_p, noise, thr=self.match_threshold, run_ahead=True, accept_scope=self.accept_scope,
+                              match=self.match_rule)
+        self.last_result = res
+        return t.vae_proxy[0].fhat_to_img(res.f_hat.clone()).add_(1).mul_(0.5)
+
+    @torch.no_grad()
+    def sdvar_autoregressive_infer_cfg_sd_test3(self, B: int, label_B: Optional[Union[int, torch.LongTensor]], g_seed: Optional[int] = None, cfg: float = 1.5,
+                                                top_k: int = 0, top_p: float = 0.0, more_smooth: bool = False, entry_num: int = 10, sd_mask: int = 0) -> torch.Tensor:
+        """var.py:604-865: the draft samples stages 0 .. entry_num-1, the target continues from the shared f_hat.  One generator, the target
+        model's (var.py:641-642); labels as in var.py:647-656.  sd_mask 0 and 3 are built (engine.Sampler.handoff)."""
+        t = self.target_model
+        rng = None
+        if g_seed is not None:
+            t.rng.manual_seed(g_seed); rng = t.rng
+        S = len(t.patch_nums)
+        labels, smp, noise = self._prepare(B, label_B, g_seed, entry_num + 1 if (sd_mask != 0 and entry_num < S) else 1, rng=rng)
+        res = smp.handoff(labels, cfg, top_k, top_p, noise, entry_num, sd_mask, more_smooth=bool(more_smooth))
         self.last_result = res
         return t.vae_proxy[0].fhat_to_img(res.f_hat.clone()).add_(1).mul_(0.5)
 

@@ -45,7 +45,9 @@ def _tn(g: np.random.Generator, shape, std) -> torch.Tensor:
 
 
 def var_state_dict(depth: int, patch_nums: Sequence[int], mode: str = "perf", seed: int = 1234,
-                   V: int = 4096, Cvae: int = 32, num_classes: int = 1000, shared_aln: bool = False) -> "OrderedDict[str, torch.Tensor]":
+                   V: int = 4096, Cvae: int = 32, num_classes: int = 1000, shared_aln: bool = False, init_adaln: float = 0.5,
+                   init_adaln_gamma: float = 1e-5, init_head: float = 0.02, init_std: float = -1) -> "OrderedDict[str, torch.Tensor]":
+    """init_* are VAR.init_weights' arguments (var.py:261-311; factory defaults models/__init__.py:24) and shape the 'perf' init only."""
     lad = as_ladder(patch_nums)
     C, H, L, S = 64 * depth, depth, lad.L, lad.S
     if mode not in ("perf", "stress"):
@@ -53,7 +55,7 @@ def var_state_dict(depth: int, patch_nums: Sequence[int], mode: str = "perf", se
     stress = mode == "stress"
     sseed = seed * 31 + depth
     sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
-    std0 = math.sqrt(1.0 / C / 3.0)
+    std0 = math.sqrt(1.0 / C / 3.0) if init_std < 0 else float(init_std)      # var.py:262
 
     def w(name, shape, s_std):      # weight-like: stress -> N(0, s_std), perf -> trunc_normal(std0)
         g = _gen(sseed, name)
@@ -84,7 +86,7 @@ def var_state_dict(depth: int, patch_nums: Sequence[int], mode: str = "perf", se
             if stress:
                 gss[:, :, :2] += 1.0                # gamma1, gamma2 channels open
             else:
-                gss[:, :, 2:] *= 0.5; gss[:, :, :2] *= 1e-5   # var.py:309-311
+                gss[:, :, 2:] *= init_adaln; gss[:, :, :2] *= init_adaln_gamma   # var.py:309-311
             sd[p + "ada_gss"] = gss
             continue
         aw = w(p + "ada_lin.1.weight", (6 * C, C), 0.5 / math.sqrt(C))
@@ -92,16 +94,18 @@ def var_state_dict(depth: int, patch_nums: Sequence[int], mode: str = "perf", se
         if stress:
             ab[: 2 * C] = 1.0                       # gamma1, gamma2 channels open
         else:
-            aw[2 * C:] *= 0.5; aw[: 2 * C] *= 1e-5   # init_adaln / init_adaln_gamma (var.py:305-306)
+            aw[2 * C:] *= init_adaln; aw[: 2 * C] *= init_adaln_gamma   # var.py:305-306
         sd[p + "ada_lin.1.bias"] = ab
     if shared_aln:
         sw = w("shared_ada_lin.1.weight", (6 * C, C), 0.5 / math.sqrt(C)); b("shared_ada_lin.1.bias", (6 * C,), 0.05)
         if not stress:
-            sw[2 * C:] *= 0.5; sw[: 2 * C] *= 1e-5   # var.py:299-302
+            sw[2 * C:] *= init_adaln; sw[: 2 * C] *= init_adaln_gamma   # var.py:299-302
     hw = w("head_nm.ada_lin.1.weight", (2 * C, C), 0.5 / math.sqrt(C)); b("head_nm.ada_lin.1.bias", (2 * C,), 0.1)
     hd = w("head.weight", (V, C), 2 / math.sqrt(C)); b("head.bias", (V,), 0.1)
     if not stress:
-        hw *= 0.5; hd *= 0.02                        # init_adaln, init_head (var.py:283-294)
+        hw *= init_adaln                             # var.py:290-293
+        if init_head >= 0:
+            hd *= init_head                          # var.py:283-289
     # buffers (models/var.py:108-113)
     lvl = torch.cat([torch.full((n,), i, dtype=torch.int64) for i, n in enumerate(lad.lens)]).view(1, L)
     sd["lvl_1L"] = lvl

@@ -193,8 +193,57 @@ def test_api_surface_drop_in(dev):
     for blk in target.blocks: blk.attn.kv_caching(False)
     img4 = draft.autoregressive_infer_cfg(B=1, label_B=None, g_seed=3)
     assert img4.shape == (1, 3, 256, 256)
-    with pytest.raises(NotImplementedError):
-        target.autoregressive_infer_cfg(B=1, label_B=0, more_smooth=True)
+
+
+def test_engine_objects_grow_with_the_batch(dev):
+    """One VAR / SDVAR object called with a small batch first and a larger one later: the model context AND the quantizer context are
+    rebuilt (the quantizer used to keep its first max_batch and fail with 'quant_next: stage 0 B ...'); ids equal a fresh object's."""
+    import sdvar_amd
+    vae, draft, target, sd = sdvar_amd.build_vae_var_speculative_decoding(device=dev, depth_draft=2, depth_target=4)
+    lab = lambda B: torch.arange(B, device=dev) + 3
+    target.autoregressive_infer_cfg(B=1, label_B=lab(1), g_seed=0, cfg=1.5, top_k=900, top_p=0.96)
+    target.autoregressive_infer_cfg(B=4, label_B=lab(4), g_seed=0, cfg=1.5, top_k=900, top_p=0.96)
+    ids_grown = target.last_result.ids.clone()
+    sd.sdvar_autoregressive_infer_cfg_parallel_v1(B=2, label_B=lab(2), g_seed=1, cfg=1.5, gamma=2, top_k=900, top_p=0.96)
+    sd.sdvar_autoregressive_infer_cfg_parallel_v1(B=6, label_B=lab(6), g_seed=1, cfg=1.5, gamma=2, top_k=900, top_p=0.96)
+    ids_sd = sd.last_result.ids.clone()
+    target.autoregressive_infer_cfg(B=3, label_B=lab(3), g_seed=0, cfg=1.5, top_k=900, top_p=0.96)      # back to a smaller batch on the grown objects
+    vae2, draft2, target2, sd2 = sdvar_amd.build_vae_var_speculative_decoding(device=dev, depth_draft=2, depth_target=4)
+    target2.autoregressive_infer_cfg(B=4, label_B=lab(4), g_seed=0, cfg=1.5, top_k=900, top_p=0.96)
+    assert torch.equal(ids_grown, target2.last_result.ids)
+    sd2.sdvar_autoregressive_infer_cfg_parallel_v1(B=6, label_B=lab(6), g_seed=1, cfg=1.5, gamma=2, top_k=900, top_p=0.96)
+    assert torch.equal(ids_sd, sd2.last_result.ids)
+
+
+def test_public_api_runs_the_benched_loop(dev):
+    """SDVAR.sdvar_autoregressive_infer_cfg_parallel_v1 IS Sampler.spec_decode(run_ahead=True) (what bench.py times): its ids, f_hat and
+    counters equal the lock-step loop's and the step-wise helper methods', for an accepting and a rejecting configuration."""
+    import sdvar_amd
+    vae, draft, target, sd = sdvar_amd.build_vae_var_speculative_decoding(device=dev, depth_draft=2, depth_target=4)
+    for m in (draft, target):
+        sdm, _ = state_dicts(m.depth, LADDER_256)
+        m.load_state_dict({k: v.to(dev) for k, v in sdm.items()})
+    B, labels = 2, torch.tensor([11, 700], device=dev)
+    for thr, gamma in ((0.5, 2), (0.0, 3), (2.0, 3)):
+        sd.match_threshold = thr
+        sd.sdvar_autoregressive_infer_cfg_parallel_v1(B=B, label_B=labels, g_seed=9, cfg=1.5, gamma=gamma, top_k=900, top_p=0.96, more_smooth=True)   # flag is inert here, as in the reference
+        res = sd.last_result
+        ids, f, st = res.ids.clone(), res.f_hat.clone(), {k: v for k, v in res.stats.items()}
+        state = sd._initialize_inference_state(B, labels, 9, 1.5, gamma)
+        state.top_k, state.top_p = 900, 0.96
+        while state.current_stage < state.total_stages:                            # the reference's loop body (var.py:1318-1367)
+            toks = sd.draft_generate_batch(state, B)
+            logits, g = sd.target_verify_batch(toks, state, B)
+            n = sd.basic_token_matching(toks, logits, state, B)
+            if n == 0:
+                if state.gamma > 1:
+                    state.gamma -= 1
+                else:
+                    n = 1
+            sd.update_state_with_accepted_tokens(toks, n, state, B)
+        state.sampler.spec_end(state)
+        assert torch.equal(state.sampler.ids[:B], ids) and torch.equal(state.draft_f_hat, f), (thr, gamma)
+        assert state.target_calls == st["target_calls"]
 
 
 def test_fp16_kv_cache_vs_oracle(dev):

@@ -120,3 +120,80 @@ def test_P4_d30_512_fp16_kv_cfg3(dev):
     scale = ref32.trace["logits"][0].abs().max().item()
     assert 0 < d0 <= 5e-2 * scale, (d0, scale)
     _close(objs32)
+
+
+def test_P1_d12_draft_d16_verify_B8(dev):
+    """BASELINE.json configs[1], the configuration bench.py is quoted on: d12 draft + d16 verify, 256^2, B = 8 - determinism, reject_all ==
+    plain draft AR on the consumed draws (I3/I4), run-ahead == lock-step for every gamma x threshold, chunk-verify == stage-wise logits at
+    the first and last chunk, and the decoded images (HIP decoder finite and within 1e-4 of the PyTorch decoder)."""
+    from sdvar_amd.vqvae import VQVAE
+    B, pns = 8, LADDER_256
+    smp, objs = _pair(dev, 12, 16, pns, B, 3)
+    lad = smp.lad
+    labels = torch.arange(B, device=dev) % 1000
+    run = lambda gamma, thr, ra, seed=7: smp.spec_decode(labels, 1.5, gamma, 900, 0.96, E.Noise("device", seed), thr=thr, run_ahead=ra)
+    # determinism of the benched call (gamma 2, natural threshold, run-ahead)
+    a = run(2, 0.5, True); ids_a, f_a, st_a = a.ids.clone(), a.f_hat.clone(), {k: v for k, v in a.stats.items()}
+    b = run(2, 0.5, True)
+    assert torch.equal(b.ids, ids_a) and torch.equal(b.f_hat, f_a) and b.stats["rounds"] == st_a["rounds"]
+    assert st_a["target_calls"] == 11 and st_a["draft_stage_calls"] == 12 and st_a["forced_accepts"] == 10       # what the bench's `natural` mode runs
+    # run-ahead == lock-step: ids, f_hat, every counter
+    for gamma in (1, 2, 3):
+        for thr in (0.0, 0.5, 2.0):
+            x = run(gamma, thr, False); ids_x, f_x, st_x = x.ids.clone(), x.f_hat.clone(), {k: v for k, v in x.stats.items()}
+            y = run(gamma, thr, True)
+            assert torch.equal(y.ids, ids_x) and torch.equal(y.f_hat, f_x), (gamma, thr)
+            for k in ("target_calls", "draft_stage_calls", "forced_accepts", "accepted_tokens", "gamma_final"):
+                assert y.stats[k] == st_x[k], (gamma, thr, k)
+            assert y.stats["rounds"] == st_x["rounds"], (gamma, thr)
+            if thr == 0.0:
+                assert st_x["target_calls"] == -(-10 // gamma) and st_x["accepted_tokens"] == 680
+    # reject_all: the committed ids are the plain draft AR ids on the draws of the committed stages (rollback leaves no trace)
+    res = run(2, 2.0, True, seed=11)
+    draws, d = [], 0
+    for r in res.stats["rounds"]:
+        if r["n_accept"]:
+            draws.append(d)
+        d += r["g"]
+    m, qz = objs[0], objs[2]
+    s2 = E.Sampler(m, qz)
+    ids = torch.zeros_like(res.ids)
+    m.begin(labels); f = torch.zeros(B, 32, 16, 16, device=dev); m.place_first(s2.x_t, 1)
+    for si in range(10):
+        m.forward(s2.x_t, si, 1, s2.logits_t)
+        E.cfg_sample(s2.logits_t, B, lad.lens[si], 4096, lad.cfg_t(1.5, si), 900, 0.96, None, 11, draws[si], 0, ids, lad.begin(si), lad.L)
+        qz.next(si, ids[:, lad.begin(si):], lad.L, f, None if si == 9 else s2.nxt[0], B)
+        if si < 9:
+            m.embed_next(s2.nxt[0], si + 1, s2.x_t, lad.lens[si + 1], 0)
+    m.kv_set_len(0)
+    assert torch.equal(ids, res.ids) and (f - res.f_hat).abs().max().item() == 0.0
+    # chunk verify == stage-wise at the first and the last gamma = 2 chunk
+    _chunk_vs_stagewise(smp, labels, 0, 2)
+    _chunk_vs_stagewise(smp, labels, 8, 2)
+    # decode: HIP decoder vs the PyTorch decoder on the sampled f_hat
+    sd_v = vae_state_dict(pns, "stress", with_encoder=False)
+    vae = VQVAE(vocab_size=4096, z_channels=32, ch=160, v_patch_nums=pns, with_encoder=False)
+    vae.load_state_dict(sd_v); vae = vae.to(dev)
+    img = vae.fhat_to_img(f_a.clone())
+    ref = vae.fhat_to_img_torch(f_a.clone())
+    assert torch.isfinite(img).all() and img.shape == (B, 3, 256, 256)
+    assert (img - ref).abs().max().item() <= 1e-4
+    _close(objs)
+
+
+def test_d36_shared_aln_width(dev):
+    """VAR-d36-s, the upstream shared_aln checkpoint (var.py:16-19, 81; README model zoo): C = 2304 is wider than every other model.  Shape /
+    property test at B = 1 on random weights: two stages run, logits finite, deterministic, chunk == stage-wise."""
+    from sdvar_amd.weights import var_state_dict
+    pns, B, depth = LADDER_256, 1, 36
+    sd = {k: v.to(dev) for k, v in var_state_dict(depth, pns, "stress", 5, shared_aln=True).items()}
+    sd_v = vae_state_dict(pns, "stress", with_encoder=False)
+    tc, qc = E.ModelCtx(sd, depth, pns, B, 2, dev), E.QuantCtx(sd_v, pns, B, dev)
+    smp = E.Sampler(tc, qc)
+    labels = torch.tensor([207], device=dev)
+    a = smp.plain_ar(labels, 1.5, 900, 0.96, E.Noise("device", 1), trace=True)
+    ids_a, lg_a = a.ids.clone(), a.trace["logits"][3].clone()
+    b = smp.plain_ar(labels, 1.5, 900, 0.96, E.Noise("device", 1), trace=True)
+    assert torch.equal(ids_a, b.ids) and torch.equal(lg_a, b.trace["logits"][3]) and torch.isfinite(lg_a).all() and lg_a.std().item() > 0.1
+    _chunk_vs_stagewise(smp, labels, 2, 2)
+    tc.close(); qc.close(); torch.cuda.empty_cache()
