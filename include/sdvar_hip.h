@@ -38,7 +38,9 @@ typedef struct {
     int32_t max_chunk_stages;               /* largest number of stages one forward may cover (gamma) */
     int32_t kv_dtype;                       /* KV-cache storage: 0 = fp32 (reference CPU path), 1 = fp16 (BASELINE config P4) */
     int32_t gemm_mode;                      /* 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = bf16x3 split operands on the bf16 MFMA
-                                               (fp32-accurate: x = x1+x2+x3 exactly, 6 of 9 plane products, fp32 accumulate) */
+                                               (fp32-accurate: x = x1+x2+x3 exactly, 6 of 9 plane products, fp32 accumulate), 2 = f16x2 split
+                                               operands on the f16 MFMA (x ~ xh + xl to 2^-22, 3 of 4 plane products, weights scaled by a power of
+                                               two per tensor, activations saturate at +-65504: csrc/gemm_f16x2.hip) */
 } sdvar_model_desc;
 
 int sdvar_abi_version(void);
@@ -169,18 +171,24 @@ int sdvar_op_gemm(const float* X, int32_t ldx, const float* W, const float* bias
 /* bf16x3 plane tensors are K-blocked: element (row, k) of plane p is at p*plane_stride + ((k/32)*rows + row)*32 + k%32.
  * out (fp32) or out_planes (planes of the (rows, C) result, plane stride in elements) */
 int sdvar_op_ln_modulate(const float* x, const float* scale, const float* shift, float* out, uint16_t* out_planes, uint64_t plane_stride,
-                         int32_t rows, int32_t C, int32_t rows_per_img, int32_t mod_stride, void* stream);
+                         int32_t plane_format /* 3 = bf16x3, 2 = f16x2 */, int32_t rows, int32_t C, int32_t rows_per_img, int32_t mod_stride, void* stream);
 /* fp32 (rows, cols) row-major -> three K-blocked bf16 planes of 8 significand bits each, x == p0 + p1 + p2 exactly */
 int sdvar_op_split_planes(const float* x, uint16_t* planes, int32_t rows, int32_t cols, uint64_t plane_stride, void* stream);
 /* the bf16x3 split-operand GEMM on K-blocked planes of X (M,K) and W (N,K); epi 0 bias -> out, 1 bias+GELU -> out_planes of (M,N), 2 gated residual -> out */
 int sdvar_op_gemm_bf16x3(const uint16_t* Xp, uint64_t x_plane_stride, const uint16_t* Wp, uint64_t w_plane_stride, const float* bias, float* out,
                          int32_t ldo, uint16_t* out_planes, uint64_t out_plane_stride, int32_t M, int32_t N, int32_t K, int32_t epilogue,
                          const float* res, int32_t ldres, const float* gate, int32_t rows_per_gate, int32_t gate_stride, void* stream);
+/* f16x2 operands: fp32 (rows, cols) -> two K-blocked fp16 planes of x * 2^S; scale (4 device floats, may be NULL = no scaling) receives
+ * {2^S, 2^-S, scratch, -} with max|x| 2^S in (2^12, 2^13] (weights); the GEMM takes the same pointer and undoes the scale in its epilogue */
+int sdvar_op_split_planes_f16(const float* x, uint16_t* planes, int32_t rows, int32_t cols, uint64_t plane_stride, float* scale, void* stream);
+int sdvar_op_gemm_f16x2(const uint16_t* Xp, uint64_t x_plane_stride, const uint16_t* Wp, uint64_t w_plane_stride, const float* w_scale, const float* bias, float* out,
+                        int32_t ldo, uint16_t* out_planes, uint64_t out_plane_stride, int32_t M, int32_t N, int32_t K, int32_t epilogue,
+                        const float* res, int32_t ldres, const float* gate, int32_t rows_per_gate, int32_t gate_stride, void* stream);
 int sdvar_op_qk_norm_append(const float* qkv, const float* scale_mul, float* q_out, void* k_cache, void* v_cache, int32_t kv_f16, int32_t R,
                             int32_t l, int32_t H, int32_t Lmax, int32_t pos0, void* stream);
 /* q (R,H,l,64), caches (R,H,Lmax,64) fp32 or fp16 (kv_f16) with Ktot valid keys, out (R,l,H*64); queries >= qbeg[j] see keys < vis[j] */
 int sdvar_op_attention(const float* q, const void* k_cache, const void* v_cache, int32_t kv_f16, float* out, uint16_t* out_planes, uint64_t plane_stride,
-                       int32_t R, int32_t H, int32_t l, int32_t Lmax, int32_t Ktot, int32_t n_stages, const int32_t* qbeg /*host*/,
+                       int32_t plane_format, int32_t R, int32_t H, int32_t l, int32_t Lmax, int32_t Ktot, int32_t n_stages, const int32_t* qbeg /*host*/,
                        const int32_t* vis /*host*/, void* stream);
 int sdvar_op_noise_fill(float* q, int32_t B, int32_t l, int32_t V, uint64_t seed, uint32_t draw, uint32_t image_offset, void* stream);
 
@@ -203,10 +211,11 @@ int sdvar_debug_set_gemm_cfg(int32_t bm, int32_t split);
 int sdvar_debug_set_gemm_stamps(uint64_t* stamps);
 
 /* ---- per-kernel-class timing with HIP events on the launch stream (bench.py roofline leg) ----------------------------- */
-#define SDVAR_PROF_CLASSES 8   /* 0 gemm, 1 attention, 2 ln_modulate, 3 qk_norm_append, 4 sampler, 5 verify, 6 quant, 7 embed/misc */
+#define SDVAR_PROF_CLASSES 9   /* 0 gemm, 1 attention with more than 36 queries per (row, head) (matrix-pipe bound), 2 ln_modulate, 3 qk_norm_append,
+                                  4 sampler, 5 verify, 6 quant, 7 embed/misc, 8 attention with <= 36 queries (stages 0-5: HBM / latency bound) */
 int sdvar_prof_enable(int32_t on);
 /* synchronises the recorded events and accumulates: ms, launches, algorithmic flops, algorithmic bytes per class */
-int sdvar_prof_collect(double* ms /*host[8]*/, int64_t* launches /*host[8]*/, double* flops /*host[8]*/, double* bytes /*host[8]*/);
+int sdvar_prof_collect(double* ms /*host[SDVAR_PROF_CLASSES]*/, int64_t* launches, double* flops, double* bytes);
 
 #ifdef __cplusplus
 }

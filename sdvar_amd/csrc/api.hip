@@ -15,7 +15,7 @@ namespace sdvar {
 int gemm_f32_nt(const float* X, int ldx, const float* W, const float* bias, float* out, int ldo, int M, int N, int K, int epi,
                 const float* res, int ldres, const float* gate, int rows_per_gate, int gate_stride, hipStream_t stream);
 struct PendingSplitK { const float* ws; const float* bias; const float* gate; int split, rows_per_gate, gate_stride; };
-int ln_modulate(float* x, const float* scale, const float* shift, float* out, uint16_t* outp, size_t ops, int rows, int C, int rows_per_img, int mod_stride, const PendingSplitK* pend, hipStream_t stream);
+int ln_modulate(float* x, const float* scale, const float* shift, float* out, uint16_t* outp, size_t ops, int rows, int C, int rows_per_img, int mod_stride, const PendingSplitK* pend, int pfmt, hipStream_t stream);
 float* splitk_workspace(size_t* floats);
 float* set_splitk_workspace(float* p);
 size_t splitk_workspace_floats();
@@ -25,10 +25,15 @@ int add_row_vector(const float* src, const float* vec, float* out, int rows, int
 int prologue(const long long* labels, const float* class_emb, const float* pos_start, const float* lvl_pos, float* cond, float* x0, int B, int C, int num_classes, hipStream_t stream);
 int build_lvl_pos(const float* lvl_embed, const float* pos, const int* stage_of_tok, float* out, int L, int C, hipStream_t stream);
 int embed_next(const float* nxt, const float* Ww, const float* bw, const float* lvl_pos, float* x, int B, int l, int C, int t0, int ltot, int tok_off, hipStream_t stream);
-int attention_f32(const float* q, const void* kc, const void* vc, int kv_f16, float* out, uint16_t* outp, size_t ops, int R, int H, int l, int Lmax, int Ktot, int n_chunk, const int* qbeg, const int* vis, hipStream_t stream);
+int attention_f32(const float* q, const void* kc, const void* vc, int kv_f16, float* out, uint16_t* outp, size_t ops, int pfmt, int R, int H, int l, int Lmax, int Ktot, int n_chunk, const int* qbeg, const int* vis, hipStream_t stream);
 int gemm_bf16x3_nt(const uint16_t* X, size_t xps, const uint16_t* W, size_t wps, const float* bias, float* out, int ldo, uint16_t* outp, size_t ops,
                    int M, int N, int K, int epi, const float* res, int ldres, const float* gate, int rows_per_gate, int gate_stride, int* defer, hipStream_t stream);
 int split_planes(const float* x, uint16_t* planes, int rows, int cols, size_t plane_stride, hipStream_t stream);
+int gemm_f16x2_nt(const uint16_t* X, size_t xps, const uint16_t* W, size_t wps, const float* wsi, const float* bias, float* out, int ldo, uint16_t* outp, size_t ops,
+                  int M, int N, int K, int epi, const float* res, int ldres, const float* gate, int rows_per_gate, int gate_stride, int* defer, hipStream_t stream);
+int split_planes_f16(const float* x, uint16_t* planes, int rows, int cols, size_t plane_stride, const float* scale, hipStream_t stream);
+int weight_scale_f16(const float* w, size_t n, float* sc, hipStream_t stream);
+void debug_set_gemm_cfg_h(int bm, int split);
 void debug_set_gemm_cfg_p(int bm, int split);
 void debug_set_gemm_stamps(unsigned long long* p);
 int cfg_sample(const float* logits, int B, int l, int V, float one_plus_t, float t, int top_k, int use_top_p, float top_p_thr, const float* q, uint64_t seed,
@@ -93,7 +98,8 @@ struct BlockW {
     const float *ada_w, *ada_b, *qkv_w, *scale_mul, *proj_w, *proj_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
     float* qkv_bias;     // owned: [q_bias, 0, v_bias]  (basic_var.py:93)
     void *kc, *vc;       // owned KV cache: (Rmax, H, L, 64) fp32 or fp16 (desc.kv_dtype), or the bf16x3 planes of attention_bf16x3.hip (kv_fmt 2)
-    uint16_t *qkv_wp, *proj_wp, *fc1_wp, *fc2_wp;   // owned bf16x3 planes of the weights (desc.gemm_mode == 1)
+    uint16_t *qkv_wp, *proj_wp, *fc1_wp, *fc2_wp;   // owned operand planes of the weights (desc.gemm_mode 1: 3 bf16 planes, 2: 2 fp16 planes)
+    float* wsc;          // owned, gemm_mode 2: per weight {2^S, 2^-S, scratch, -} x {qkv, proj, fc1, fc2}, the power-of-two weight scales of gemm_f16x2.hip
     bool bound;
 };
 
@@ -116,7 +122,8 @@ struct sdvar_model {
     // owned
     float *lvl_pos, *cond, *cond_silu, *x0, *ada, *ada_head;
     float *xn, *qkv, *qbuf, *att, *hid;
-    uint16_t *xn_p, *att_p, *hid_p, *head_wp;     // bf16x3 planes of the GEMM inputs (desc.gemm_mode == 1)
+    uint16_t *xn_p, *att_p, *hid_p, *head_wp;     // operand planes of the GEMM inputs (desc.gemm_mode >= 1)
+    float* head_wsc = nullptr;                    // gemm_mode 2: weight scale of the head
     size_t act_ps;                                // plane stride of xn_p / att_p (elements); hid_p uses 4x
     int* stage_of_tok;
     // run state
@@ -140,6 +147,14 @@ struct sdvar_quant {
 
 static inline int begin_of(const sdvar_model* m, int s) { return s == 0 ? 0 : m->cum[s - 1]; }
 
+// the split-operand GEMM of the model's mode: bf16x3 (six bf16 products) or f16x2 (three fp16 products, weights scaled by 2^S: wsc -> {2^S, 2^-S})
+static int plane_gemm(const sdvar_model* m, const uint16_t* X, size_t xps, const uint16_t* W, size_t wps, const float* wsc, const float* bias, float* out, int ldo,
+                      uint16_t* outp, size_t ops, int M, int N, int K, int epi, const float* res, int ldres, const float* gate, int rows_per_gate, int gate_stride,
+                      int* defer, hipStream_t s) {
+    if (m->d.gemm_mode == 2) return gemm_f16x2_nt(X, xps, W, wps, wsc + 1, bias, out, ldo, outp, ops, M, N, K, epi, res, ldres, gate, rows_per_gate, gate_stride, defer, s);
+    return gemm_bf16x3_nt(X, xps, W, wps, bias, out, ldo, outp, ops, M, N, K, epi, res, ldres, gate, rows_per_gate, gate_stride, defer, s);
+}
+
 extern "C" {
 
 int sdvar_abi_version(void) { return SDVAR_ABI_VERSION; }
@@ -154,7 +169,7 @@ int sdvar_model_create(const sdvar_model_desc* desc, sdvar_model_t** out) {
     SDVAR_CHECK_ARG(desc->cvae == 32, "model_create: cvae must be 32 (got %d)", desc->cvae);
     SDVAR_CHECK_ARG(desc->max_batch >= 1 && desc->num_classes >= 1, "model_create: batch/classes");
     SDVAR_CHECK_ARG(desc->kv_dtype == 0 || desc->kv_dtype == 1, "model_create: kv_dtype %d (0 = fp32, 1 = fp16)", desc->kv_dtype);
-    SDVAR_CHECK_ARG(desc->gemm_mode == 0 || desc->gemm_mode == 1, "model_create: gemm_mode %d (0 = fp32 MFMA, 1 = bf16x3 split operands)", desc->gemm_mode);
+    SDVAR_CHECK_ARG(desc->gemm_mode >= 0 && desc->gemm_mode <= 2, "model_create: gemm_mode %d (0 = fp32 MFMA, 1 = bf16x3, 2 = f16x2 split operands)", desc->gemm_mode);
     SDVAR_CHECK_ARG(desc->max_chunk_stages >= 1 && desc->max_chunk_stages <= SDVAR_MAX_STAGES, "model_create: max_chunk_stages %d", desc->max_chunk_stages);
     sdvar_model* m = new sdvar_model();
     struct Guard {          // every early return below (argument error, out of memory) releases what was allocated so far
@@ -172,7 +187,7 @@ int sdvar_model_create(const sdvar_model_desc* desc, sdvar_model_t** out) {
     }
     m->L = c;
     // the split-operand GEMM mode keeps an fp32 cache as exact bf16 planes so that attention runs on the bf16 matrix cores too
-    m->kv_fmt = (desc->kv_dtype == 0 && desc->gemm_mode == 1 && !getenv("SDVAR_ATTN_F32")) ? 2 : desc->kv_dtype;   // env: A/B runs only
+    m->kv_fmt = (desc->kv_dtype == 0 && desc->gemm_mode >= 1 && !getenv("SDVAR_ATTN_F32")) ? 2 : desc->kv_dtype;   // env: A/B runs only
     m->Lkv = (m->kv_fmt == 2) ? (c + 63) / 64 * 64 : c;
     // the largest chunk is a window of max_chunk_stages consecutive stages; stage lengths are non-decreasing
     m->lmax = 0;
@@ -201,18 +216,21 @@ int sdvar_model_create(const sdvar_model_desc* desc, sdvar_model_t** out) {
     SDVAR_TRY(dmalloc(&m->qbuf, M * C));
     SDVAR_TRY(dmalloc(&m->att, M * C));
     m->xn_p = m->att_p = m->hid_p = m->head_wp = nullptr; m->act_ps = M * C;
-    if (desc->gemm_mode == 1) {
-        SDVAR_TRY(dmalloc(&m->xn_p, 3 * M * C));
-        SDVAR_TRY(dmalloc(&m->att_p, 3 * M * C));
-        SDVAR_TRY(dmalloc(&m->hid_p, 3 * M * 4 * C));
-        SDVAR_TRY(dmalloc(&m->head_wp, 3 * (size_t)desc->vocab * C));
+    const size_t NPL = desc->gemm_mode == 2 ? 2 : 3;                  // planes per operand
+    if (desc->gemm_mode >= 1) {
+        SDVAR_TRY(dmalloc(&m->xn_p, NPL * M * C));
+        SDVAR_TRY(dmalloc(&m->att_p, NPL * M * C));
+        SDVAR_TRY(dmalloc(&m->hid_p, NPL * M * 4 * C));
+        SDVAR_TRY(dmalloc(&m->head_wp, NPL * (size_t)desc->vocab * C));
+        if (desc->gemm_mode == 2) SDVAR_TRY(dmalloc(&m->head_wsc, (size_t)4));
     } else {
         SDVAR_TRY(dmalloc(&m->hid, M * 4 * C));
     }
     for (auto& b : m->blk) {
-        if (desc->gemm_mode == 1) {
-            SDVAR_TRY(dmalloc(&b.qkv_wp, 3 * 3 * C * C)); SDVAR_TRY(dmalloc(&b.proj_wp, 3 * C * C));
-            SDVAR_TRY(dmalloc(&b.fc1_wp, 3 * 4 * C * C)); SDVAR_TRY(dmalloc(&b.fc2_wp, 3 * 4 * C * C));
+        if (desc->gemm_mode >= 1) {
+            SDVAR_TRY(dmalloc(&b.qkv_wp, NPL * 3 * C * C)); SDVAR_TRY(dmalloc(&b.proj_wp, NPL * C * C));
+            SDVAR_TRY(dmalloc(&b.fc1_wp, NPL * 4 * C * C)); SDVAR_TRY(dmalloc(&b.fc2_wp, NPL * 4 * C * C));
+            if (desc->gemm_mode == 2) SDVAR_TRY(dmalloc(&b.wsc, (size_t)16));
         }
         SDVAR_TRY(dmalloc(&b.qkv_bias, 3 * C));
         const size_t kvb = R * (size_t)m->H * m->Lkv * 64 * (m->kv_fmt == 2 ? 6 : m->kv_fmt == 1 ? 2 : 4);
@@ -229,13 +247,13 @@ int sdvar_model_create(const sdvar_model_desc* desc, sdvar_model_t** out) {
 
 int sdvar_model_destroy(sdvar_model_t* m) {
     if (!m) return SDVAR_OK;
-    float* bufs[] = {m->lvl_pos, m->cond, m->cond_silu, m->x0, m->ada, m->ada_head, m->xn, m->qkv, m->qbuf, m->att, m->hid, m->ws_own, m->gss_lin};
+    float* bufs[] = {m->lvl_pos, m->cond, m->cond_silu, m->x0, m->ada, m->ada_head, m->xn, m->qkv, m->qbuf, m->att, m->hid, m->ws_own, m->gss_lin, m->head_wsc};
     for (float* p : bufs) if (p) (void)hipFree(p);
     if (m->stage_of_tok) (void)hipFree(m->stage_of_tok);
     uint16_t* pb[] = {m->xn_p, m->att_p, m->hid_p, m->head_wp};
     for (uint16_t* p : pb) if (p) (void)hipFree(p);
     for (auto& b : m->blk) { uint16_t* wp[] = {b.qkv_wp, b.proj_wp, b.fc1_wp, b.fc2_wp}; for (uint16_t* p : wp) if (p) (void)hipFree(p); }
-    for (auto& b : m->blk) { if (b.qkv_bias) (void)hipFree(b.qkv_bias); if (b.kc) (void)hipFree(b.kc); if (b.vc) (void)hipFree(b.vc); }
+    for (auto& b : m->blk) { if (b.qkv_bias) (void)hipFree(b.qkv_bias); if (b.kc) (void)hipFree(b.kc); if (b.vc) (void)hipFree(b.vc); if (b.wsc) (void)hipFree(b.wsc); }
     delete m;
     return SDVAR_OK;
 }
@@ -267,6 +285,15 @@ int sdvar_model_bind_block(sdvar_model_t* m, int32_t i, const float* ada_w, cons
         const int Ci = m->C;
         SDVAR_TRY(split_planes(qkv_w, b.qkv_wp, 3 * Ci, Ci, 3 * C * C, s)); SDVAR_TRY(split_planes(proj_w, b.proj_wp, Ci, Ci, C * C, s));
         SDVAR_TRY(split_planes(fc1_w, b.fc1_wp, 4 * Ci, Ci, 4 * C * C, s)); SDVAR_TRY(split_planes(fc2_w, b.fc2_wp, Ci, 4 * Ci, 4 * C * C, s));
+    } else if (m->d.gemm_mode == 2) {      // per-tensor power-of-two scale (computed on the device, no sync), then the two fp16 planes of w * 2^S
+        const int Ci = m->C;
+        const float* ws[4] = {qkv_w, proj_w, fc1_w, fc2_w};
+        uint16_t* wp[4] = {b.qkv_wp, b.proj_wp, b.fc1_wp, b.fc2_wp};
+        const int rows[4] = {3 * Ci, Ci, 4 * Ci, Ci}, cols[4] = {Ci, Ci, Ci, 4 * Ci};
+        for (int k = 0; k < 4; ++k) {
+            SDVAR_TRY(weight_scale_f16(ws[k], (size_t)rows[k] * cols[k], b.wsc + 4 * k, s));
+            SDVAR_TRY(split_planes_f16(ws[k], wp[k], rows[k], cols[k], (size_t)rows[k] * cols[k], b.wsc + 4 * k, s));
+        }
     }
     b.bound = true;
     return SDVAR_OK;
@@ -283,6 +310,10 @@ int sdvar_model_bind_head(sdvar_model_t* m, const float* nm_w, const float* nm_b
     SDVAR_CHECK_ARG(m && nm_w && nm_b && head_w && head_b, "bind_head: null argument");
     m->nm_w = nm_w; m->nm_b = nm_b; m->head_w = head_w; m->head_b = head_b; m->head_bound = true;
     if (m->d.gemm_mode == 1) SDVAR_TRY(split_planes(head_w, m->head_wp, m->d.vocab, m->C, (size_t)m->d.vocab * m->C, (hipStream_t)stream));
+    if (m->d.gemm_mode == 2) {
+        SDVAR_TRY(weight_scale_f16(head_w, (size_t)m->d.vocab * m->C, m->head_wsc, (hipStream_t)stream));
+        SDVAR_TRY(split_planes_f16(head_w, m->head_wp, m->d.vocab, m->C, (size_t)m->d.vocab * m->C, m->head_wsc, (hipStream_t)stream));
+    }
     return SDVAR_OK;
 }
 
@@ -379,7 +410,8 @@ int sdvar_stage_forward(sdvar_model_t* m, float* x, int32_t s0, int32_t n, float
     for (int j = 0; j < n; ++j) { qbeg[j] = lsum; lsum += m->lens[s0 + j]; vis[j] = m->cum[s0 + j] - m->kv_origin; lk += (double)m->lens[s0 + j] * vis[j]; }
     const int M = R * lsum, Ktot = m->kv_len + lsum;
     const double dM = M, dC = C;
-    const bool P = m->d.gemm_mode == 1;                               // bf16x3 split-operand GEMMs: inputs travel as planes
+    const bool P = m->d.gemm_mode >= 1;                               // split-operand GEMMs: inputs travel as planes
+    const int PF = m->d.gemm_mode == 2 ? PLANES_F16X2 : PLANES_BF16X3;
     const size_t ps = (size_t)M * C;                                  // plane stride of this call's (M, C) activations
     // In bf16x3 mode a split-K GEMM feeding a row kernel leaves its K-slice slabs in the shared workspace and the consumer
     // (qk_norm_append for QKV; the next ln_modulate for the two gated-residual GEMMs) sums them: no reduce launches.
@@ -392,34 +424,34 @@ int sdvar_stage_forward(sdvar_model_t* m, float* x, int32_t s0, int32_t n, float
         const BlockW& b = m->blk[i];
         const float* ada = m->ada + (size_t)i * m->Rmax * 6 * C;      // (R, 6C): gamma1 gamma2 scale1 scale2 shift1 shift2
         { ProfScope pp(2, 8 * dM * dC, (P ? 10 : 8) * dM * dC, s);
-          SDVAR_TRY(ln_modulate(x, ada + 2 * C, ada + 4 * C, m->xn, P ? m->xn_p : nullptr, ps, M, C, lsum, 6 * C, &pend, s)); pend.ws = nullptr; }
+          SDVAR_TRY(ln_modulate(x, ada + 2 * C, ada + 4 * C, m->xn, P ? m->xn_p : nullptr, ps, M, C, lsum, 6 * C, &pend, PF, s)); pend.ws = nullptr; }
         PendingSplitK pq{nullptr, nullptr, nullptr, 0, 1, 0};
         { ProfScope pp(0, 2 * dM * 3 * dC * dC, 4 * (dM * dC + 3 * dC * dC + 3 * dM * dC), s);
-          if (P) { SDVAR_TRY(gemm_bf16x3_nt(m->xn_p, ps, b.qkv_wp, (size_t)3 * C * C, b.qkv_bias, m->qkv, 3 * C, nullptr, 0, M, 3 * C, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, dp, s));
+          if (P) { SDVAR_TRY(plane_gemm(m, m->xn_p, ps, b.qkv_wp, (size_t)3 * C * C, b.wsc, b.qkv_bias, m->qkv, 3 * C, nullptr, 0, M, 3 * C, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, dp, s));
                    if (defer) pq = PendingSplitK{ws, b.qkv_bias, nullptr, defer, 1, 0}; }
           else SDVAR_TRY(gemm_f32_nt(m->xn, C, b.qkv_w, b.qkv_bias, m->qkv, 3 * C, M, 3 * C, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, s)); }
         { ProfScope pp(3, 6 * dM * dC, 4 * 6 * dM * dC, s);
           SDVAR_TRY(qk_norm_append(m->qkv, b.scale_mul, m->qbuf, b.kc, b.vc, m->kv_fmt, R, lsum, H, m->Lkv, m->kv_len, &pq, s)); }
-        { ProfScope pp(1, 4.0 * R * H * 64.0 * lk, R * H * 64.0 * ((m->d.kv_dtype ? 4.0 : 8.0) * Ktot + 8.0 * lsum), s);
-          SDVAR_TRY(attention_f32(m->qbuf, b.kc, b.vc, m->kv_fmt, m->att, P ? m->att_p : nullptr, ps, R, H, lsum, m->Lkv, Ktot, n, qbeg, vis, s)); }
+        { ProfScope pp(lsum <= 36 ? 8 : 1, 4.0 * R * H * 64.0 * lk, R * H * 64.0 * ((m->d.kv_dtype ? 4.0 : 8.0) * Ktot + 8.0 * lsum), s);
+          SDVAR_TRY(attention_f32(m->qbuf, b.kc, b.vc, m->kv_fmt, m->att, P ? m->att_p : nullptr, ps, PF, R, H, lsum, m->Lkv, Ktot, n, qbeg, vis, s)); }
         { ProfScope pp(0, 2 * dM * dC * dC, 4 * (3 * dM * dC + dC * dC), s);
-          if (P) { SDVAR_TRY(gemm_bf16x3_nt(m->att_p, ps, b.proj_wp, (size_t)C * C, b.proj_b, x, C, nullptr, 0, M, C, C, EPI_GATED_RES, x, C, ada, lsum, 6 * C, dp, s));
+          if (P) { SDVAR_TRY(plane_gemm(m, m->att_p, ps, b.proj_wp, (size_t)C * C, b.wsc + 4, b.proj_b, x, C, nullptr, 0, M, C, C, EPI_GATED_RES, x, C, ada, lsum, 6 * C, dp, s));
                    if (defer) pend = PendingSplitK{ws, b.proj_b, ada, defer, lsum, 6 * C}; }
           else SDVAR_TRY(gemm_f32_nt(m->att, C, b.proj_w, b.proj_b, x, C, M, C, C, EPI_GATED_RES, x, C, ada, lsum, 6 * C, s)); }
         { ProfScope pp(2, 8 * dM * dC, (P ? 10 : 8) * dM * dC, s);
-          SDVAR_TRY(ln_modulate(x, ada + 3 * C, ada + 5 * C, m->xn, P ? m->xn_p : nullptr, ps, M, C, lsum, 6 * C, &pend, s)); pend.ws = nullptr; }
+          SDVAR_TRY(ln_modulate(x, ada + 3 * C, ada + 5 * C, m->xn, P ? m->xn_p : nullptr, ps, M, C, lsum, 6 * C, &pend, PF, s)); pend.ws = nullptr; }
         { ProfScope pp(0, 2 * dM * 4 * dC * dC, 4 * (dM * dC + 4 * dC * dC + 4 * dM * dC), s);
-          if (P) SDVAR_TRY(gemm_bf16x3_nt(m->xn_p, ps, b.fc1_wp, (size_t)4 * C * C, b.fc1_b, nullptr, 0, m->hid_p, 4 * ps, M, 4 * C, C, EPI_BIAS_GELU, nullptr, 0, nullptr, 0, 0, nullptr, s));
+          if (P) SDVAR_TRY(plane_gemm(m, m->xn_p, ps, b.fc1_wp, (size_t)4 * C * C, b.wsc + 8, b.fc1_b, nullptr, 0, m->hid_p, 4 * ps, M, 4 * C, C, EPI_BIAS_GELU, nullptr, 0, nullptr, 0, 0, nullptr, s));
           else SDVAR_TRY(gemm_f32_nt(m->xn, C, b.fc1_w, b.fc1_b, m->hid, 4 * C, M, 4 * C, C, EPI_BIAS_GELU, nullptr, 0, nullptr, 0, 0, s)); }
         { ProfScope pp(0, 2 * dM * 4 * dC * dC, 4 * (4 * dM * dC + 4 * dC * dC + 2 * dM * dC), s);
-          if (P) { SDVAR_TRY(gemm_bf16x3_nt(m->hid_p, 4 * ps, b.fc2_wp, (size_t)4 * C * C, b.fc2_b, x, C, nullptr, 0, M, C, 4 * C, EPI_GATED_RES, x, C, ada + C, lsum, 6 * C, dp, s));
+          if (P) { SDVAR_TRY(plane_gemm(m, m->hid_p, 4 * ps, b.fc2_wp, (size_t)4 * C * C, b.wsc + 12, b.fc2_b, x, C, nullptr, 0, M, C, 4 * C, EPI_GATED_RES, x, C, ada + C, lsum, 6 * C, dp, s));
                    if (defer) pend = PendingSplitK{ws, b.fc2_b, ada + C, defer, lsum, 6 * C}; }
           else SDVAR_TRY(gemm_f32_nt(m->hid, 4 * C, b.fc2_w, b.fc2_b, x, C, M, C, 4 * C, EPI_GATED_RES, x, C, ada + C, lsum, 6 * C, s)); }
     }
     { ProfScope pp(2, 8 * dM * dC, (P ? 10 : 8) * dM * dC, s);      // also finishes the last block's fc2 residual when it was left split
-      SDVAR_TRY(ln_modulate(x, m->ada_head, m->ada_head + C, m->xn, P ? m->xn_p : nullptr, ps, M, C, lsum, 2 * C, &pend, s)); pend.ws = nullptr; }
+      SDVAR_TRY(ln_modulate(x, m->ada_head, m->ada_head + C, m->xn, P ? m->xn_p : nullptr, ps, M, C, lsum, 2 * C, &pend, PF, s)); pend.ws = nullptr; }
     { ProfScope pp(0, 2 * dM * dC * V, 4 * (dM * dC + dC * V + dM * V), s);
-      if (P) SDVAR_TRY(gemm_bf16x3_nt(m->xn_p, ps, m->head_wp, (size_t)V * C, m->head_b, logits, V, nullptr, 0, M, V, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, nullptr, s));
+      if (P) SDVAR_TRY(plane_gemm(m, m->xn_p, ps, m->head_wp, (size_t)V * C, m->head_wsc, m->head_b, logits, V, nullptr, 0, M, V, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, nullptr, s));
       else SDVAR_TRY(gemm_f32_nt(m->xn, C, m->head_w, m->head_b, logits, V, M, V, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, s)); }
     m->kv_len = Ktot;
     return SDVAR_OK;
@@ -432,12 +464,13 @@ int sdvar_head_forward(sdvar_model_t* m, const float* x, int32_t l, float* logit
     WsScope wsg(m->ws_own);
     const int C = m->C, R = 2 * m->B, V = m->d.vocab, M = R * l;
     const double dM = M, dC = C;
-    const bool P = m->d.gemm_mode == 1;
+    const bool P = m->d.gemm_mode >= 1;
+    const int PF = m->d.gemm_mode == 2 ? PLANES_F16X2 : PLANES_BF16X3;
     const size_t ps = (size_t)M * C;
     { ProfScope pp(2, 8 * dM * dC, (P ? 10 : 8) * dM * dC, s);
-      SDVAR_TRY(ln_modulate(const_cast<float*>(x), m->ada_head, m->ada_head + C, m->xn, P ? m->xn_p : nullptr, ps, M, C, l, 2 * C, nullptr, s)); }
+      SDVAR_TRY(ln_modulate(const_cast<float*>(x), m->ada_head, m->ada_head + C, m->xn, P ? m->xn_p : nullptr, ps, M, C, l, 2 * C, nullptr, PF, s)); }
     { ProfScope pp(0, 2 * dM * dC * V, 4 * (dM * dC + dC * V + dM * V), s);
-      if (P) SDVAR_TRY(gemm_bf16x3_nt(m->xn_p, ps, m->head_wp, (size_t)V * C, m->head_b, logits, V, nullptr, 0, M, V, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, nullptr, s));
+      if (P) SDVAR_TRY(plane_gemm(m, m->xn_p, ps, m->head_wp, (size_t)V * C, m->head_wsc, m->head_b, logits, V, nullptr, 0, M, V, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, nullptr, s));
       else SDVAR_TRY(gemm_f32_nt(m->xn, C, m->head_w, m->head_b, logits, V, M, V, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, s)); }
     return SDVAR_OK;
 }
@@ -589,10 +622,21 @@ int sdvar_op_gemm(const float* X, int32_t ldx, const float* W, const float* bias
     ProfScope ps(0, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), (hipStream_t)stream);
     return gemm_f32_nt(X, ldx, W, bias, out, ldo, M, N, K, epi, res, ldres, gate, rows_per_gate, gate_stride, (hipStream_t)stream);
 }
-int sdvar_op_ln_modulate(const float* x, const float* scale, const float* shift, float* out, uint16_t* out_planes, uint64_t plane_stride, int32_t rows,
-                         int32_t C, int32_t rows_per_img, int32_t mod_stride, void* stream) {
+int sdvar_op_ln_modulate(const float* x, const float* scale, const float* shift, float* out, uint16_t* out_planes, uint64_t plane_stride, int32_t plane_format,
+                         int32_t rows, int32_t C, int32_t rows_per_img, int32_t mod_stride, void* stream) {
     SDVAR_CHECK_ARG(out || out_planes, "op_ln_modulate: no output");
-    return ln_modulate(const_cast<float*>(x), scale, shift, out, out_planes, (size_t)plane_stride, rows, C, rows_per_img, mod_stride, nullptr, (hipStream_t)stream);
+    return ln_modulate(const_cast<float*>(x), scale, shift, out, out_planes, (size_t)plane_stride, rows, C, rows_per_img, mod_stride, nullptr, plane_format, (hipStream_t)stream);
+}
+int sdvar_op_split_planes_f16(const float* x, uint16_t* planes, int32_t rows, int32_t cols, uint64_t plane_stride, float* scale, void* stream) {
+    if (scale) SDVAR_TRY(weight_scale_f16(x, (size_t)rows * cols, scale, (hipStream_t)stream));
+    return split_planes_f16(x, planes, rows, cols, (size_t)plane_stride, scale, (hipStream_t)stream);
+}
+int sdvar_op_gemm_f16x2(const uint16_t* Xp, uint64_t x_plane_stride, const uint16_t* Wp, uint64_t w_plane_stride, const float* w_scale, const float* bias, float* out,
+                        int32_t ldo, uint16_t* out_planes, uint64_t out_plane_stride, int32_t M, int32_t N, int32_t K, int32_t epi, const float* res, int32_t ldres,
+                        const float* gate, int32_t rows_per_gate, int32_t gate_stride, void* stream) {
+    ProfScope ps(0, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), (hipStream_t)stream);
+    return gemm_f16x2_nt(Xp, (size_t)x_plane_stride, Wp, (size_t)w_plane_stride, w_scale ? w_scale + 1 : nullptr, bias, out, ldo, out_planes, (size_t)out_plane_stride, M, N, K,
+                         epi, res, ldres, gate, rows_per_gate, gate_stride, nullptr, (hipStream_t)stream);
 }
 int sdvar_op_split_planes(const float* x, uint16_t* planes, int32_t rows, int32_t cols, uint64_t plane_stride, void* stream) {
     return split_planes(x, planes, rows, cols, (size_t)plane_stride, (hipStream_t)stream);
@@ -608,13 +652,13 @@ int sdvar_op_qk_norm_append(const float* qkv, const float* scale_mul, float* q_o
                             int32_t H, int32_t Lmax, int32_t pos0, void* stream) {
     return qk_norm_append(qkv, scale_mul, q_out, k_cache, v_cache, kv_f16, R, l, H, Lmax, pos0, nullptr, (hipStream_t)stream);
 }
-int sdvar_op_attention(const float* q, const void* kc, const void* vc, int32_t kv_f16, float* out, uint16_t* out_planes, uint64_t plane_stride, int32_t R,
-                       int32_t H, int32_t l, int32_t Lmax, int32_t Ktot, int32_t n, const int32_t* qbeg, const int32_t* vis, void* stream) {
+int sdvar_op_attention(const float* q, const void* kc, const void* vc, int32_t kv_f16, float* out, uint16_t* out_planes, uint64_t plane_stride, int32_t plane_format,
+                       int32_t R, int32_t H, int32_t l, int32_t Lmax, int32_t Ktot, int32_t n, const int32_t* qbeg, const int32_t* vis, void* stream) {
     SDVAR_CHECK_ARG(qbeg && vis && n >= 1 && n <= SDVAR_MAX_STAGES, "op_attention: bad stage table");
     double lk = 0;
     for (int j = 0; j < n; ++j) lk += (double)((j + 1 < n ? qbeg[j + 1] : l) - qbeg[j]) * vis[j];
-    ProfScope ps(1, 4.0 * R * H * 64.0 * lk, R * H * 64.0 * ((kv_f16 ? 4.0 : 8.0) * Ktot + 8.0 * l), (hipStream_t)stream);
-    return attention_f32(q, kc, vc, kv_f16, out, out_planes, (size_t)plane_stride, R, H, l, Lmax, Ktot, n, qbeg, vis, (hipStream_t)stream);
+    ProfScope ps(l <= 36 ? 8 : 1, 4.0 * R * H * 64.0 * lk, R * H * 64.0 * ((kv_f16 ? 4.0 : 8.0) * Ktot + 8.0 * l), (hipStream_t)stream);
+    return attention_f32(q, kc, vc, kv_f16, out, out_planes, (size_t)plane_stride, plane_format, R, H, l, Lmax, Ktot, n, qbeg, vis, (hipStream_t)stream);
 }
 int sdvar_op_noise_fill(float* q, int32_t B, int32_t l, int32_t V, uint64_t seed, uint32_t draw, uint32_t image_offset, void* stream) {
     return noise_fill(q, B, l, V, seed, draw, image_offset, (hipStream_t)stream);
@@ -625,6 +669,7 @@ int sdvar_debug_set_gemm_cfg(int32_t bm, int32_t split) {
     SDVAR_CHECK_ARG(split >= 0 && split <= 64, "debug_set_gemm_cfg: split %d", split);
     debug_set_gemm_cfg(bm, split);
     debug_set_gemm_cfg_p(bm, split);
+    debug_set_gemm_cfg_h(bm, split);
     return SDVAR_OK;
 }
 

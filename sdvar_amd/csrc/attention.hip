@@ -27,7 +27,7 @@ constexpr int KSTR = 68;            // padded K row (floats)
 
 struct AttnArgs {
     const float* q; const void* kc; const void* vc; float* out;     // kc/vc: fp32 or fp16 (template KVH)
-    uint16_t* outp; size_t ops;                                     // optional bf16x3 planes output instead of `out`
+    uint16_t* outp; size_t ops; int pfmt;                           // optional operand planes output instead of `out` (common.h PLANES_*)
     int R, H, l, Lmax, Ktot;
     int n_chunk;
     int qbeg[ATT_MAX_CHUNK + 1];
@@ -233,18 +233,10 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(AttnArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v0[e] = o0[4 * g + e] * inv; v1[e] = o1[4 * g + e] * inv; }
             if (a.outp) {
-                uint16_t q0[3][4], q1[3][4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { split3(v0[e], q0[0][e], q0[1][e], q0[2][e]); split3(v1[e], q1[0][e], q1[1][e], q1[2][e]); }
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    uint2 w0, w1;
-                    w0.x = (uint32_t)q0[k][0] | ((uint32_t)q0[k][1] << 16); w0.y = (uint32_t)q0[k][2] | ((uint32_t)q0[k][3] << 16);
-                    w1.x = (uint32_t)q1[k][0] | ((uint32_t)q1[k][1] << 16); w1.y = (uint32_t)q1[k][2] | ((uint32_t)q1[k][3] << 16);
-                    const int orow = r * a.l + qi_raw, ocol = h * 64 + 4 * lh + 8 * g;      // K-blocked planes of the (R*l, H*64) matrix
-                    *reinterpret_cast<uint2*>(a.outp + k * a.ops + kb_index(orow, ocol, a.R * a.l)) = w0;
-                    *reinterpret_cast<uint2*>(a.outp + k * a.ops + kb_index(orow, ocol + 32, a.R * a.l)) = w1;
-                }
+                const float u0[4] = {v0[0], v0[1], v0[2], v0[3]}, u1[4] = {v1[0], v1[1], v1[2], v1[3]};
+                const int orow = r * a.l + qi_raw, ocol = h * 64 + 4 * lh + 8 * g;      // K-blocked planes of the (R*l, H*64) matrix
+                store_planes4(a.outp, a.ops, kb_index(orow, ocol, a.R * a.l), u0, a.pfmt);
+                store_planes4(a.outp, a.ops, kb_index(orow, ocol + 32, a.R * a.l), u1, a.pfmt);
             } else {
                 *reinterpret_cast<f32x4*>(a.out + obase + 8 * g) = v0;
                 *reinterpret_cast<f32x4*>(a.out + obase + 32 + 8 * g) = v1;
@@ -253,18 +245,19 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(AttnArgs a) {
     }
 }
 
-int attention_bf16x3(const float* q, const void* kc, const void* vc, float* out, uint16_t* outp, size_t ops, int R, int H, int l, int Lp,
+int attention_bf16x3(const float* q, const void* kc, const void* vc, float* out, uint16_t* outp, size_t ops, int pfmt, int R, int H, int l, int Lp,
                      int Ktot, int n_chunk, const int* qbeg, const int* vis, hipStream_t stream);
 
 // kv_f16: cache format, 0 = fp32, 1 = fp16 (this file), 2 = bf16x3 planes (attention_bf16x3.hip)
-int attention_f32(const float* q, const void* kc, const void* vc, int kv_f16, float* out, uint16_t* outp, size_t ops, int R, int H, int l, int Lmax,
+int attention_f32(const float* q, const void* kc, const void* vc, int kv_f16, float* out, uint16_t* outp, size_t ops, int pfmt, int R, int H, int l, int Lmax,
                   int Ktot, int n_chunk, const int* qbeg, const int* vis, hipStream_t stream) {
-    if (kv_f16 == 2) return attention_bf16x3(q, kc, vc, out, outp, ops, R, H, l, Lmax, Ktot, n_chunk, qbeg, vis, stream);
+    SDVAR_CHECK_ARG(!outp || pfmt == PLANES_BF16X3 || pfmt == PLANES_F16X2, "attention: plane format %d", pfmt);
+    if (kv_f16 == 2) return attention_bf16x3(q, kc, vc, out, outp, ops, pfmt, R, H, l, Lmax, Ktot, n_chunk, qbeg, vis, stream);
     SDVAR_CHECK_ARG(q && kc && vc && (out || outp), "attention: null operand");
     SDVAR_CHECK_ARG(n_chunk >= 1 && n_chunk <= ATT_MAX_CHUNK, "attention: chunk of %d stages unsupported (max %d)", n_chunk, ATT_MAX_CHUNK);
     SDVAR_CHECK_ARG(R > 0 && H > 0 && l > 0 && Ktot >= l && Ktot <= Lmax, "attention: bad lengths l=%d Ktot=%d Lmax=%d", l, Ktot, Lmax);
     AttnArgs a;
-    a.q = q; a.kc = kc; a.vc = vc; a.out = out; a.outp = outp; a.ops = ops; a.R = R; a.H = H; a.l = l; a.Lmax = Lmax; a.Ktot = Ktot; a.n_chunk = n_chunk;
+    a.q = q; a.kc = kc; a.vc = vc; a.out = out; a.outp = outp; a.ops = ops; a.pfmt = pfmt; a.R = R; a.H = H; a.l = l; a.Lmax = Lmax; a.Ktot = Ktot; a.n_chunk = n_chunk;
     for (int j = 0; j < n_chunk; ++j) {
         a.qbeg[j] = qbeg[j]; a.vis[j] = vis[j];
         SDVAR_CHECK_ARG(vis[j] >= 1 && vis[j] <= Ktot && (j == 0 ? qbeg[0] == 0 : (qbeg[j] > qbeg[j - 1] && vis[j] >= vis[j - 1])), "attention: bad stage table at %d", j);

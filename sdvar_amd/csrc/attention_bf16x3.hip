@@ -42,7 +42,7 @@ constexpr int ASTAGE = 6 * APL;         // one K tile + one V^T tile, 3 planes e
 
 struct AttnPArgs {
     const float* q; const uint16_t* kc; const uint16_t* vc; float* out;
-    uint16_t* outp; size_t ops;
+    uint16_t* outp; size_t ops; int pfmt;       // output planes for the proj GEMM: PLANES_BF16X3 or PLANES_F16X2 (common.h)
     int R, H, l, Lp, Ktot;
     int n_chunk;
     int qbeg[ATTP_MAX_CHUNK + 1];
@@ -268,18 +268,10 @@ __global__ __launch_bounds__(256, 2) void attention_bf16x3_kernel(AttnPArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v0[e] = o0[4 * g + e] * inv; v1[e] = o1[4 * g + e] * inv; }
             if (a.outp) {
-                uint16_t q0_[3][4], q1_[3][4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { split3(v0[e], q0_[0][e], q0_[1][e], q0_[2][e]); split3(v1[e], q1_[0][e], q1_[1][e], q1_[2][e]); }
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    uint2 w0, w1;
-                    w0.x = (uint32_t)q0_[k][0] | ((uint32_t)q0_[k][1] << 16); w0.y = (uint32_t)q0_[k][2] | ((uint32_t)q0_[k][3] << 16);
-                    w1.x = (uint32_t)q1_[k][0] | ((uint32_t)q1_[k][1] << 16); w1.y = (uint32_t)q1_[k][2] | ((uint32_t)q1_[k][3] << 16);
-                    const int orow = r * a.l + qi_raw, ocol = h * 64 + 4 * lh + 8 * g;      // K-blocked planes of the (R*l, H*64) matrix
-                    *reinterpret_cast<uint2*>(a.outp + k * a.ops + kb_index(orow, ocol, a.R * a.l)) = w0;
-                    *reinterpret_cast<uint2*>(a.outp + k * a.ops + kb_index(orow, ocol + 32, a.R * a.l)) = w1;
-                }
+                const float u0[4] = {v0[0], v0[1], v0[2], v0[3]}, u1[4] = {v1[0], v1[1], v1[2], v1[3]};
+                const int orow = r * a.l + qi_raw, ocol = h * 64 + 4 * lh + 8 * g;      // K-blocked planes of the (R*l, H*64) matrix
+                store_planes4(a.outp, a.ops, kb_index(orow, ocol, a.R * a.l), u0, a.pfmt);
+                store_planes4(a.outp, a.ops, kb_index(orow, ocol + 32, a.R * a.l), u1, a.pfmt);
             } else {
                 *reinterpret_cast<f32x4*>(a.out + obase + 8 * g) = v0;
                 *reinterpret_cast<f32x4*>(a.out + obase + 32 + 8 * g) = v1;
@@ -288,14 +280,14 @@ __global__ __launch_bounds__(256, 2) void attention_bf16x3_kernel(AttnPArgs a) {
     }
 }
 
-int attention_bf16x3(const float* q, const void* kc, const void* vc, float* out, uint16_t* outp, size_t ops, int R, int H, int l, int Lp,
+int attention_bf16x3(const float* q, const void* kc, const void* vc, float* out, uint16_t* outp, size_t ops, int pfmt, int R, int H, int l, int Lp,
                      int Ktot, int n_chunk, const int* qbeg, const int* vis, hipStream_t stream) {
     SDVAR_CHECK_ARG(q && kc && vc && (out || outp), "attention: null operand");
     SDVAR_CHECK_ARG(n_chunk >= 1 && n_chunk <= ATTP_MAX_CHUNK, "attention: chunk of %d stages unsupported (max %d)", n_chunk, ATTP_MAX_CHUNK);
     SDVAR_CHECK_ARG(R > 0 && H > 0 && l > 0 && Ktot >= l && Ktot <= Lp, "attention: bad lengths l=%d Ktot=%d Lmax=%d", l, Ktot, Lp);
     SDVAR_CHECK_ARG(Lp % 64 == 0, "attention: the planes KV format needs Lmax %% 64 == 0 (got %d)", Lp);
     AttnPArgs a;
-    a.q = q; a.kc = (const uint16_t*)kc; a.vc = (const uint16_t*)vc; a.out = out; a.outp = outp; a.ops = ops;
+    a.q = q; a.kc = (const uint16_t*)kc; a.vc = (const uint16_t*)vc; a.out = out; a.outp = outp; a.ops = ops; a.pfmt = pfmt;
     a.R = R; a.H = H; a.l = l; a.Lp = Lp; a.Ktot = Ktot; a.n_chunk = n_chunk;
     for (int j = 0; j < n_chunk; ++j) {
         a.qbeg[j] = qbeg[j]; a.vis[j] = vis[j];

@@ -92,6 +92,41 @@ __device__ __forceinline__ void split3(float x, uint16_t& p0, uint16_t& p1, uint
     p0 = (uint16_t)(u0 >> 16); p1 = (uint16_t)(u1 >> 16); p2 = (uint16_t)(__float_as_uint(r2) >> 16);
 }
 
+// ---- fp32 -> two fp16 planes (f16x2 operands, gemm_f16x2.hip): h = fp16(x) round-to-nearest, l = fp16(x - h); x saturates at the
+// fp16 range instead of turning into inf - inf = NaN
+__device__ __forceinline__ void split2h(float x, uint16_t& h, uint16_t& l) {
+    x = fminf(fmaxf(x, -65504.0f), 65504.0f);
+    const _Float16 hh = (_Float16)x;
+    const _Float16 ll = (_Float16)(x - (float)hh);
+    h = __builtin_bit_cast(uint16_t, hh); l = __builtin_bit_cast(uint16_t, ll);
+}
+// Output-plane format of the producers of GEMM operands (ln_modulate, attention, GELU epilogues): none, three bf16 planes, two fp16 planes
+enum { PLANES_NONE = 0, PLANES_F16X2 = 2, PLANES_BF16X3 = 3 };
+// four consecutive values of one row -> the packed 8-byte words of each plane, written at the K-blocked position
+__device__ __forceinline__ void store_planes4(uint16_t* outp, size_t ops, size_t o, const float* v, int fmt) {
+    if (fmt == PLANES_F16X2) {
+        uint16_t q[2][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split2h(v[e], q[0][e], q[1][e]);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            uint2 w;
+            w.x = (uint32_t)q[k][0] | ((uint32_t)q[k][1] << 16); w.y = (uint32_t)q[k][2] | ((uint32_t)q[k][3] << 16);
+            *reinterpret_cast<uint2*>(outp + k * ops + o) = w;
+        }
+    } else {
+        uint16_t q[3][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split3(v[e], q[0][e], q[1][e], q[2][e]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            uint2 w;
+            w.x = (uint32_t)q[k][0] | ((uint32_t)q[k][1] << 16); w.y = (uint32_t)q[k][2] | ((uint32_t)q[k][3] << 16);
+            *reinterpret_cast<uint2*>(outp + k * ops + o) = w;
+        }
+    }
+}
+
 // eight consecutive values -> three packed bf16x8 words (same split); the top halves of two values are packed with one v_perm_b32
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void split8_packed(const float* v, u32x4& a, u32x4& b, u32x4& c) {

@@ -33,7 +33,7 @@ constexpr int LN_MAX_C = 3072;
 template <int LN_MAX_V4>
 __device__ __forceinline__ void ln_row_finish(const f32x4* v, int lane, int row, const float* __restrict__ scale, const float* __restrict__ shift,
                                               float* __restrict__ out, uint16_t* __restrict__ outp, size_t ops, int rows, int C, int rows_per_img,
-                                              int mod_stride, float eps) {
+                                              int mod_stride, float eps, int pfmt) {
     const int nv = C >> 2;
     // modulation vectors first: their load latency overlaps the two wave reductions (these launches are latency-bound at small M)
     const size_t mo = (size_t)(row / rows_per_img) * mod_stride;
@@ -67,16 +67,9 @@ __device__ __forceinline__ void ln_row_finish(const f32x4* v, int lane, int row,
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = ((v[i][e] - mean) * rstd) * (sc[e] + 1.0f) + sh[e];
-            if (outp) {                      // bf16x3 planes for the split-operand GEMM (gemm_bf16x3.hip)
-                uint16_t q[3][4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) split3(o[e], q[0][e], q[1][e], q[2][e]);
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    uint2 w;
-                    w.x = (uint32_t)q[k][0] | ((uint32_t)q[k][1] << 16); w.y = (uint32_t)q[k][2] | ((uint32_t)q[k][3] << 16);
-                    *reinterpret_cast<uint2*>(outp + k * ops + kb_index(row, 4 * idx, rows)) = w;
-                }
+            if (outp) {                      // operand planes of the split-operand GEMMs (gemm_bf16x3.hip / gemm_f16x2.hip)
+                const float ov[4] = {o[0], o[1], o[2], o[3]};
+                store_planes4(outp, ops, kb_index(row, 4 * idx, rows), ov, pfmt);
             } else {
                 po[idx] = o;
             }
@@ -109,7 +102,7 @@ __device__ __forceinline__ f32x4 pending_residual(const PendingSplitK& pend, f32
 template <int LN_MAX_V4>
 __global__ __launch_bounds__(256) void ln_modulate_kernel(float* __restrict__ x, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, float* __restrict__ out, uint16_t* __restrict__ outp,
-                                                          size_t ops, int rows, int C, int rows_per_img, int mod_stride, float eps, PendingSplitK pend) {
+                                                          size_t ops, int rows, int C, int rows_per_img, int mod_stride, float eps, PendingSplitK pend, int pfmt) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int nv = C >> 2;
@@ -126,7 +119,7 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(float* __restrict__ x,
             }
         }
     }
-    ln_row_finish<LN_MAX_V4>(v, lane, row, scale, shift, out, outp, ops, rows, C, rows_per_img, mod_stride, eps);
+    ln_row_finish<LN_MAX_V4>(v, lane, row, scale, shift, out, outp, ops, rows, C, rows_per_img, mod_stride, eps, pfmt);
 }
 
 // Same result bit for bit, one WORKGROUP per row, for a pending split-K residual at small row counts: with one wave per row
@@ -135,7 +128,7 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(float* __restrict__ x,
 template <int LN_MAX_V4>
 __global__ __launch_bounds__(256) void ln_modulate_row_kernel(float* __restrict__ x, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, float* __restrict__ out, uint16_t* __restrict__ outp,
-                                                              size_t ops, int rows, int C, int rows_per_img, int mod_stride, float eps, PendingSplitK pend) {
+                                                              size_t ops, int rows, int C, int rows_per_img, int mod_stride, float eps, PendingSplitK pend, int pfmt) {
     __shared__ f32x4 vsm[64 * LN_MAX_V4];
     const int tid = threadIdx.x, row = blockIdx.x;
     const int nv = C >> 2;
@@ -151,11 +144,11 @@ __global__ __launch_bounds__(256) void ln_modulate_row_kernel(float* __restrict_
 #pragma unroll
     for (int i = 0; i < LN_MAX_V4; ++i)
         if (tid + 64 * i < nv) v[i] = vsm[tid + 64 * i];
-    ln_row_finish<LN_MAX_V4>(v, tid, row, scale, shift, out, outp, ops, rows, C, rows_per_img, mod_stride, eps);
+    ln_row_finish<LN_MAX_V4>(v, tid, row, scale, shift, out, outp, ops, rows, C, rows_per_img, mod_stride, eps, pfmt);
 }
 
 int ln_modulate(float* x, const float* scale, const float* shift, float* out, uint16_t* outp, size_t ops, int rows, int C, int rows_per_img,
-                int mod_stride, const PendingSplitK* pend, hipStream_t stream) {
+                int mod_stride, const PendingSplitK* pend, int pfmt, hipStream_t stream) {
     PendingSplitK pd{nullptr, nullptr, nullptr, 0, 1, 0};
     if (pend && pend->ws) {
         SDVAR_CHECK_ARG(pend->bias && pend->gate && pend->split >= 1 && pend->rows_per_gate > 0 && pend->gate_stride % 4 == 0, "ln_modulate: bad pending split-K descriptor");
@@ -163,11 +156,12 @@ int ln_modulate(float* x, const float* scale, const float* shift, float* out, ui
     }
     SDVAR_CHECK_ARG(C % 4 == 0 && C <= LN_MAX_C && rows > 0 && rows_per_img > 0, "ln_modulate: bad shape rows=%d C=%d (C <= %d)", rows, C, LN_MAX_C);
     SDVAR_CHECK_ARG(mod_stride % 4 == 0, "ln_modulate: mod_stride must be a multiple of 4");
+    SDVAR_CHECK_ARG(!outp || pfmt == PLANES_BF16X3 || pfmt == PLANES_F16X2, "ln_modulate: plane format %d", pfmt);
     const bool by_row = pd.ws && rows < 1024;
 #define SDVAR_LN_LAUNCH(NV4)                                                                                                                   \
     do {                                                                                                                                       \
-        if (by_row) hipLaunchKernelGGL(ln_modulate_row_kernel<NV4>, dim3(rows), dim3(256), 0, stream, x, scale, shift, out, outp, ops, rows, C, rows_per_img, mod_stride, 1e-6f, pd); \
-        else hipLaunchKernelGGL(ln_modulate_kernel<NV4>, dim3((rows + 3) / 4), dim3(256), 0, stream, x, scale, shift, out, outp, ops, rows, C, rows_per_img, mod_stride, 1e-6f, pd);  \
+        if (by_row) hipLaunchKernelGGL(ln_modulate_row_kernel<NV4>, dim3(rows), dim3(256), 0, stream, x, scale, shift, out, outp, ops, rows, C, rows_per_img, mod_stride, 1e-6f, pd, pfmt); \
+        else hipLaunchKernelGGL(ln_modulate_kernel<NV4>, dim3((rows + 3) / 4), dim3(256), 0, stream, x, scale, shift, out, outp, ops, rows, C, rows_per_img, mod_stride, 1e-6f, pd, pfmt);  \
     } while (0)
     if (C <= 1024) SDVAR_LN_LAUNCH(4);
     else if (C <= 2048) SDVAR_LN_LAUNCH(8);

@@ -1,0 +1,783 @@
+// fp32-accurate "NT" GEMM on the gfx950 f16 matrix cores with TWO-plane split operands (f16x2):
+//     out[M,N] = epilogue( X[M,K] . W[N,K]^T + bias[N] ),   X ~ Xh + Xl,  W * 2^S ~ Wh + Wl
+// Xh = fp16(X) (round to nearest), Xl = fp16(X - Xh): 11 + 11 significand bits, |X - Xh - Xl| <= 2^-22 |X| while Xl is a normal
+// fp16 number (|X| >= 2^-3); below that Xl runs into fp16's subnormals, which v_mfma_f32_32x32x16_f16 keeps (measured:
+// tools/micro/f16x2_probe.hip), and the error becomes an ABSOLUTE 2^-25.  Three of the four plane products are evaluated
+// (Xh.Wh + Xh.Wl + Xl.Wh; every fp16 x fp16 product is exact in fp32; fp32 accumulate); the dropped Xl.Wl term is <= 2^-22
+// relative.  Measured against fp64 on random operands at K = 1024 (the probe): max error / rms(out) 2.3e-6, against 3.1e-6 for the
+// six-product bf16x3 scheme (gemm_bf16x3.hip) and 2.7e-6 for an fp32 FMA chain - the fp32 accumulation order dominates all three -
+// at HALF the matrix-pipe work of bf16x3 (3 x 32 cycles per 16 k) and two thirds of its operand bytes.
+// Range: weights are scaled per tensor by an exact power of two at bind time (2^S brings max|W| to (2^12, 2^13], so the low
+// plane of a typical weight is a normal fp16 number; the epilogue multiplies by 2^-S); activations are taken as they are and
+// SATURATE at +-65504 (the fp16 range the reference's own half-precision attention path assumes, basic_var.py:97,113).  Rows whose
+// values are all below ~1e-3 lose relative precision (absolute error stays 2^-25): the bf16x3 mode has no such limit.
+//
+// Operands are PLANAR and K-blocked: planes[2][K/32][rows][32] fp16 (common.h kb_index); producers (ln_modulate, attention, the fc1
+// GELU epilogue) write them directly.  Kernels, tiling, split-K, deferral and the hybrid tail split are those of gemm_bf16x3.hip with
+// 2 planes / 3 products per k16-step; because a K-step now holds half the matrix work, the 256-row kernel keeps TWO K-steps of
+// LDS-DMA in flight (3-stage ring) instead of one.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace sdvar {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+enum { HEPI_BIAS = 0, HEPI_BIAS_GELU_PLANES = 1, HEPI_GATED_RES = 2, HEPI_PARTIAL = 3 };
+
+constexpr int HBK = 32;             // k per LDS stage
+constexpr int HROW = 40;            // padded row of the register-staged kernel, in fp16 elements (80 bytes)
+constexpr int HBN = 128;
+
+__device__ __forceinline__ float gelu_tanh_h(float x) {
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    return 0.5f * x * (1.0f + tanhf(k0 * (x + k1 * x * x * x)));
+}
+
+struct GemmHArgs {
+    const uint16_t* X; const uint16_t* W;        // K-blocked planes [2][K/32][M][32], [2][K/32][N][32]
+    size_t xps, wps;                             // plane strides in elements
+    const float* wsi;                            // device scalar 2^-S undoing the weight scale (null: 1)
+    const float* bias; float* out; uint16_t* outp; size_t ops;
+    const float* res; const float* gate;
+    int M, N, K, ldo, ldres, rows_per_gate, gate_stride, split, k_per_split;
+    int tile_off, tile_cnt;  // 256-row kernel only: this launch covers tile ids [tile_off, tile_off + tile_cnt) (tile_cnt = 0: all); with
+                             // HEPI_PARTIAL the slabs are compact [split][tile_cnt][256][128]
+};
+
+// acc += Al.Bh + Ah.Bl + Ah.Bh (smallest terms first)
+#define SDVAR_MFMA3(acc, ah, al, bh, bl)                                               \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);                \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);                \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0)
+
+// one output element of every epilogue: v = acc * 2^-S + bias, then the epilogue's own arithmetic
+template <int EPI>
+__device__ __forceinline__ void h_store(const GemmHArgs& a, float* outp, float accv, float wsi, float bv, int m, int n) {
+    float v = accv * wsi + bv;
+    if (EPI == HEPI_BIAS_GELU_PLANES) {
+        uint16_t h, l;
+        split2h(gelu_tanh_h(v), h, l);
+        const size_t o = kb_index(m, n, a.M);           // the output is the next GEMM's K-blocked operand
+        a.outp[o] = h; a.outp[a.ops + o] = l;
+    } else {
+        if (EPI == HEPI_GATED_RES) v = a.res[(size_t)m * a.ldres + n] + v * a.gate[(size_t)(m / a.rows_per_gate) * a.gate_stride + n];
+        outp[(size_t)m * a.ldo + n] = v;
+    }
+}
+
+template <int BM, int WAVES_M, int WAVES_N, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_f16x2_kernel(GemmHArgs a) {
+    constexpr int WM = BM / WAVES_M, WN = HBN / WAVES_N, TM = WM / 32, TN = WN / 32;
+    static_assert(WAVES_M * WAVES_N == 4 && TM >= 1 && TN >= 1, "bad wave layout");
+    constexpr int XCH = (BM * 4 + 255) / 256, WCH = HBN * 4 / 256;   // 16-byte chunks per plane per thread
+    extern __shared__ __attribute__((aligned(16))) uint16_t hsm[];
+    uint16_t* sA = hsm;                       // [2][BM][HROW]
+    uint16_t* sB = hsm + 2 * BM * HROW;       // [2][HBN][HROW]
+
+    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + HBN - 1) / HBN, ntile = tiles_m * tiles_n;
+    const int ks = blockIdx.x / ntile;
+    const int lid = xcd_remap(blockIdx.x - ks * ntile, ntile);
+    const int G = 8, per_group = tiles_m * G;
+    const int g = lid / per_group, rem = lid - g * per_group;
+    const int gw = min(G, tiles_n - g * G);
+    const int tm = rem / gw, tn = g * G + rem % gw;
+    const int m0 = tm * BM, n0 = tn * HBN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N, li = lane & 31, lh = lane >> 5;
+
+    f32x4 rx[2][XCH], rw[2][WCH];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < XCH; ++i) {
+            const int c = tid + 256 * i, row = c >> 2, col = (c & 3) * 8;
+            const int m = m0 + row;
+            const bool ok = (BM * 4 >= 256 || c < BM * 4) && m < a.M;
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                rx[p][i] = ok ? *reinterpret_cast<const f32x4*>(a.X + p * a.xps + ((size_t)(k0 >> 5) * a.M + m) * 32 + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) {
+            const int c = tid + 256 * i, row = c >> 2, col = (c & 3) * 8;
+            const int n = n0 + row;
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                rw[p][i] = (n < a.N) ? *reinterpret_cast<const f32x4*>(a.W + p * a.wps + ((size_t)(k0 >> 5) * a.N + n) * 32 + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < XCH; ++i) {
+            const int c = tid + 256 * i, row = c >> 2, col = (c & 3) * 8;
+            if (BM * 4 >= 256 || c < BM * 4) {
+#pragma unroll
+                for (int p = 0; p < 2; ++p) *reinterpret_cast<f32x4*>(sA + (p * BM + row) * HROW + col) = rx[p][i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) {
+            const int c = tid + 256 * i, row = c >> 2, col = (c & 3) * 8;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) *reinterpret_cast<f32x4*>(sB + (p * HBN + row) * HROW + col) = rw[p][i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int kt0 = ks * a.k_per_split;
+    const int nk = min(a.K / HBK - kt0, a.k_per_split);
+    load_tile(kt0 * HBK);
+    store_tile();
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) load_tile((kt0 + kt + 1) * HBK);
+        const uint16_t* pa = sA + (wm * WM + li) * HROW + 8 * lh;
+        const uint16_t* pb = sB + (wn * WN + li) * HROW + 8 * lh;
+#pragma unroll
+        for (int s = 0; s < HBK / 16; ++s) {
+            f16x8 fa[2][TM], fb[2][TN];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[p][i] = *reinterpret_cast<const f16x8*>(pa + (p * BM + i * 32) * HROW + 16 * s);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[p][j] = *reinterpret_cast<const f16x8*>(pb + (p * HBN + j * 32) * HROW + 16 * s);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) { SDVAR_MFMA3(acc[i][j], fa[0][i], fa[1][i], fb[0][j], fb[1][j]); }
+        }
+        __syncthreads();                        // every wave is done reading this stage
+        if (kt + 1 < nk) { store_tile(); __syncthreads(); }
+    }
+
+    const float wsi = a.wsi ? *a.wsi : 1.0f;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WN + j * 32 + li;
+        if (n >= a.N) continue;
+        const float bv = (EPI != HEPI_PARTIAL && a.bias) ? a.bias[n] : 0.f;
+        float* outp = (EPI == HEPI_PARTIAL) ? a.out + (size_t)ks * a.M * a.ldo : a.out;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= a.M) continue;
+                h_store<EPI>(a, outp, acc[i][j][r], wsi, bv, m, n);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 128 x 128 tile, 8 waves (2 x 4, 64x32 outputs each), K-steps of 32 streamed global -> LDS by the LDS-DMA into a 3-stage ring,
+// two K-steps in flight, ONE raw s_barrier per K-step and counted vmcnt waits.
+//   stage (32 KB) = 4 sub-arrays [128 rows][64 B]: X planes h, l then W planes h, l; unpadded rows, the 16-byte chunk c of row r is
+//   stored at chunk c ^ ((r >> 2) & 3) (applied on the DMA source address and on the ds_read address).
+//   Every wave issues 4 DMA instructions per K-step (rows 16w .. 16w+15 of each sub-array).
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+constexpr int H2_STAGE = 4 * 128 * 32;          // fp16 elements per stage (32 KB)
+#define SDVAR_LDS_RDH(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr) : "memory")
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_f16x2_v2_kernel(GemmHArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t hsm[];
+    constexpr int BM = 128;
+    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + HBN - 1) / HBN, ntile = tiles_m * tiles_n;
+    const int ks = blockIdx.x / ntile;
+    const int lid = xcd_remap(blockIdx.x - ks * ntile, ntile);
+    const int G = 8, per_group = tiles_m * G;
+    const int g = lid / per_group, rem = lid - g * per_group;
+    const int gw = min(G, tiles_n - g * G);
+    const int tm = rem / gw, tn = g * G + rem % gw;
+    const int m0 = tm * BM, n0 = tn * HBN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3, li = lane & 31, lh = lane >> 5;
+
+    const int drow = 16 * wave + (lane >> 2);
+    const int dchunk = (lane & 3) ^ ((drow >> 2) & 3);
+    const int xrow = min(m0 + drow, a.M - 1), wrow = min(n0 + drow, a.N - 1);   // clamped: rows past the edge are never stored
+    const int kt0 = ks * a.k_per_split;
+    const int nk = min(a.K / HBK - kt0, a.k_per_split);
+    const int swave = __builtin_amdgcn_readfirstlane(wave);
+    const uint32_t lx = (uint32_t)(xrow * 32 + 8 * dchunk) * 2u, lw = (uint32_t)(wrow * 32 + 8 * dchunk) * 2u;
+    const char* const bx = reinterpret_cast<const char*>(a.X + (size_t)kt0 * a.M * 32);
+    const char* const bw = reinterpret_cast<const char*>(a.W + (size_t)kt0 * a.N * 32);
+    // DMA instruction q (0..3) of K-step t (relative) -> stage t % 3: q = 2p is X plane p, q = 2p + 1 is W plane p
+    auto issue_one = [&](int t, int q) {
+        uint16_t* st = hsm + (t % 3) * H2_STAGE + swave * 512;       // + sub-array * 4096 elements
+        const int p = q >> 1;
+        if (q & 1) SDVAR_DMA16(lw, bw + ((size_t)t * a.N * 32 + p * a.wps) * 2, SDVAR_LDS_ADDR(st + (2 + p) * 4096));
+        else SDVAR_DMA16(lx, bx + ((size_t)t * a.M * 32 + p * a.xps) * 2, SDVAR_LDS_ADDR(st + p * 4096));
+    };
+    auto issue = [&](int t) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) issue_one(t, q);
+    };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    // fragment read offsets (elements) inside a sub-array: row * 32 + 8 * ((2s + lh) ^ ((li >> 2) & 3))
+    const int sw = (li >> 2) & 3;
+    const int offa0 = (wm * 64 + li) * 32, offb = (wn * 32 + li) * 32;
+    const int ch0 = 8 * ((0 + lh) ^ sw), ch1 = 8 * ((2 + lh) ^ sw);
+
+    issue(0);
+    if (nk > 1) issue(1);
+    for (int t = 0; t < nk; ++t) {
+        if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const bool pf = t + 2 < nk;
+        const uint32_t sb = (uint32_t)(uintptr_t)(lds_ptr_t)(hsm + (t % 3) * H2_STAGE);
+        const uint32_t aa0 = sb + 2 * (offa0 + ch0), aa1 = sb + 2 * (offa0 + ch1), ab0 = sb + 2 * (offb + ch0), ab1 = sb + 2 * (offb + ch1);
+        // fa[s][plane][row tile], fb[s][plane]: X plane p at +8192 p bytes, second 32-row tile at +2048; W plane p at +16384 + 8192 p
+        f16x8 fa[2][2][2], fb[2][2];
+        SDVAR_LDS_RDH(fa[0][1][0], aa0, 8192);  SDVAR_LDS_RDH(fb[0][0], ab0, 16384); SDVAR_LDS_RDH(fa[0][0][0], aa0, 0);
+        SDVAR_LDS_RDH(fb[0][1], ab0, 24576);    SDVAR_LDS_RDH(fa[0][1][1], aa0, 10240); SDVAR_LDS_RDH(fa[0][0][1], aa0, 2048);
+        SDVAR_LDS_RDH(fa[1][1][0], aa1, 8192);  SDVAR_LDS_RDH(fb[1][0], ab1, 16384); SDVAR_LDS_RDH(fa[1][0][0], aa1, 0);
+        SDVAR_LDS_RDH(fb[1][1], ab1, 24576);    SDVAR_LDS_RDH(fa[1][1][1], aa1, 10240); SDVAR_LDS_RDH(fa[1][0][1], aa1, 2048);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (s == 0) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                SDVAR_MFMA3(acc[i], fa[s][0][i], fa[s][1][i], fb[s][0], fb[s][1]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (pf) issue_one(t + 2, 2 * s + i);          // the 4 DMA instructions of K-step t+2, one behind each MFMA group
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    const float wsi = a.wsi ? *a.wsi : 1.0f;
+    const int n = n0 + wn * 32 + li;
+    if (n < a.N) {
+        const float bv = (EPI != HEPI_PARTIAL && a.bias) ? a.bias[n] : 0.f;
+        float* outp = (EPI == HEPI_PARTIAL) ? a.out + (size_t)ks * a.M * a.ldo : a.out;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= a.M) continue;
+                h_store<EPI>(a, outp, acc[i][r], wsi, bv, m, n);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 256 x 128 workgroup tile, 8 waves (4 x 2) of 64 x 64 outputs, LDS-DMA into a 3-stage ring (48 KB per stage: X planes [2][256][32]
+// then W planes [2][128][32]), two K-steps in flight: a K-step holds 24 MFMAs per wave (768 cycles), less than the DMA latency
+// under load, so one K-step of lookahead (what the bf16x3 kernel uses) would expose it.
+constexpr int H3_STAGE = 2 * (256 + 128) * 32;
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_f16x2_v3_kernel(GemmHArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t hsm[];
+    constexpr int BM = 256;
+    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + HBN - 1) / HBN, ntile = tiles_m * tiles_n;
+    const int tcnt = a.tile_cnt > 0 ? a.tile_cnt : ntile;
+    const int ks = blockIdx.x / tcnt;
+    const int lid = a.tile_off + xcd_remap(blockIdx.x - ks * tcnt, tcnt);
+    const int G = 8, per_group = tiles_m * G;
+    const int g = lid / per_group, rem = lid - g * per_group;
+    const int gw = min(G, tiles_n - g * G);
+    const int tm = rem / gw, tn = g * G + rem % gw;
+    const int m0 = tm * BM, n0 = tn * HBN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+
+    // DMA: wave w fills X rows [32w, 32w+32) (two 16-row groups) and W rows [16w, 16w+16) of both planes: 6 instructions per K-step
+    const int r16 = lane >> 2;
+    const int xr0 = 32 * wave + r16, xr1 = xr0 + 16, wr = 16 * wave + r16;
+    const int cx0 = (lane & 3) ^ ((xr0 >> 2) & 3), cx1 = (lane & 3) ^ ((xr1 >> 2) & 3), cw = (lane & 3) ^ ((wr >> 2) & 3);
+    const int kt0 = ks * a.k_per_split;
+    const int nk = min(a.K / HBK - kt0, a.k_per_split);
+    const int swave = __builtin_amdgcn_readfirstlane(wave);
+    const uint32_t lx0 = (uint32_t)(min(m0 + xr0, a.M - 1) * 32 + 8 * cx0) * 2u, lx1 = (uint32_t)(min(m0 + xr1, a.M - 1) * 32 + 8 * cx1) * 2u;
+    const uint32_t lw0 = (uint32_t)(min(n0 + wr, a.N - 1) * 32 + 8 * cw) * 2u;
+    const char* const bx = reinterpret_cast<const char*>(a.X + (size_t)kt0 * a.M * 32);
+    const char* const bw = reinterpret_cast<const char*>(a.W + (size_t)kt0 * a.N * 32);
+    // DMA instruction q (0..5) of K-step t -> stage t % 3: plane p = q / 3; q % 3 = 0 / 1: X row groups, 2: W row group
+    auto issue_one = [&](int t, int q) {
+        uint16_t* st = hsm + (t % 3) * H3_STAGE;
+        const int p = q / 3, kind = q % 3;
+        const char* ux = bx + ((size_t)t * a.M * 32 + p * a.xps) * 2;          // wave-uniform
+        const char* uw = bw + ((size_t)t * a.N * 32 + p * a.wps) * 2;
+        if (kind == 0) SDVAR_DMA16(lx0, ux, SDVAR_LDS_ADDR(st + p * 8192 + swave * 1024));
+        else if (kind == 1) SDVAR_DMA16(lx1, ux, SDVAR_LDS_ADDR(st + p * 8192 + swave * 1024 + 512));
+        else SDVAR_DMA16(lw0, uw, SDVAR_LDS_ADDR(st + 2 * 8192 + p * 4096 + swave * 512));
+    };
+    auto issue = [&](int t) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) issue_one(t, q);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int sw = (li >> 2) & 3;
+    const int offa = (wm * 64 + li) * 32, offb = 2 * 8192 + (wn * 64 + li) * 32;     // element offsets inside a stage
+    const int ch0 = 8 * ((0 + lh) ^ sw), ch1 = 8 * ((2 + lh) ^ sw);
+
+    issue(0);
+    if (nk > 1) issue(1);
+    for (int t = 0; t < nk; ++t) {
+        if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const bool pf = t + 2 < nk;     // the 6 DMA instructions of K-step t+2 are spread between the MFMA groups below
+        const uint32_t sb = (uint32_t)(uintptr_t)(lds_ptr_t)(hsm + (t % 3) * H3_STAGE);
+        const uint32_t aa0 = sb + 2 * (offa + ch0), aa1 = sb + 2 * (offa + ch1), ab0 = sb + 2 * (offb + ch0), ab1 = sb + 2 * (offb + ch1);
+        // fa[s][plane][row tile], fb[s][plane][col tile]: X plane p at +16384 p bytes, W plane p at +8192 p bytes (behind the X planes), second 32-row tile at +2048
+        f16x8 fa[2][2][2], fb[2][2][2];
+        SDVAR_LDS_RDH(fa[0][1][0], aa0, 16384); SDVAR_LDS_RDH(fb[0][0][0], ab0, 0);     SDVAR_LDS_RDH(fa[0][0][0], aa0, 0);     SDVAR_LDS_RDH(fb[0][1][0], ab0, 8192);
+        SDVAR_LDS_RDH(fb[0][0][1], ab0, 2048);  SDVAR_LDS_RDH(fb[0][1][1], ab0, 10240); SDVAR_LDS_RDH(fa[0][1][1], aa0, 18432); SDVAR_LDS_RDH(fa[0][0][1], aa0, 2048);
+        SDVAR_LDS_RDH(fa[1][1][0], aa1, 16384); SDVAR_LDS_RDH(fb[1][0][0], ab1, 0);     SDVAR_LDS_RDH(fa[1][0][0], aa1, 0);     SDVAR_LDS_RDH(fb[1][1][0], ab1, 8192);
+        SDVAR_LDS_RDH(fb[1][0][1], ab1, 2048);  SDVAR_LDS_RDH(fb[1][1][1], ab1, 10240); SDVAR_LDS_RDH(fa[1][1][1], aa1, 18432); SDVAR_LDS_RDH(fa[1][0][1], aa1, 2048);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (s == 0) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    SDVAR_MFMA3(acc[i][j], fa[s][0][i], fa[s][1][i], fb[s][0][j], fb[s][1][j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (pf) {
+                        const int grp = 4 * s + 2 * i + j;           // 0..7: six DMA instructions over the first six groups
+                        if (grp < 6) issue_one(t + 2, grp);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        }
+    }
+
+    const float wsi = a.wsi ? *a.wsi : 1.0f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + li;
+        if (n >= a.N) continue;
+        const float bv = (EPI != HEPI_PARTIAL && a.bias) ? a.bias[n] : 0.f;
+        float* outp = (EPI == HEPI_PARTIAL) ? a.out + (size_t)ks * a.M * a.ldo : a.out;
+        if (EPI == HEPI_PARTIAL && a.tile_cnt > 0) {         // tail tiles of a hybrid launch: compact slab of this (slice, tile)
+            float* slab = a.out + ((size_t)ks * a.tile_cnt + (lid - a.tile_off)) * (256 * 128);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    slab[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 128 + wn * 64 + j * 32 + li] = acc[i][j][r] * wsi;
+            continue;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= a.M) continue;
+                h_store<EPI>(a, outp, acc[i][j][r], wsi, bv, m, n);
+            }
+        }
+    }
+}
+
+// out = epi( sum_s slab[s] + bias ) for the split-K path; the GELU variant writes planes
+template <int EPI>
+__global__ __launch_bounds__(256) void splitk_reduce_h_kernel(const float* __restrict__ ws, int split, const float* __restrict__ bias, float* out,
+                                                              uint16_t* outp, size_t ops, const float* res, const float* __restrict__ gate, int M, int N,
+                                                              int ldo, int ldres, int rows_per_gate, int gate_stride) {
+    const int nv = N >> 2;
+    const size_t total = (size_t)M * nv, slab = (size_t)M * N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / nv), n = (int)(i % nv) * 4;
+        f32x4 acc = *reinterpret_cast<const f32x4*>(ws + (size_t)m * N + n);
+        for (int s = 1; s < split; ++s) {
+            const f32x4 p = *reinterpret_cast<const f32x4*>(ws + s * slab + (size_t)m * N + n);
+            acc[0] += p[0]; acc[1] += p[1]; acc[2] += p[2]; acc[3] += p[3];
+        }
+        uint16_t pl[2][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = acc[e] + (bias ? bias[n + e] : 0.f);
+            if (EPI == HEPI_BIAS_GELU_PLANES) { split2h(gelu_tanh_h(v), pl[0][e], pl[1][e]); continue; }
+            if (EPI == HEPI_GATED_RES) v = res[(size_t)m * ldres + n + e] + v * gate[(size_t)(m / rows_per_gate) * gate_stride + n + e];
+            out[(size_t)m * ldo + n + e] = v;
+        }
+        if (EPI == HEPI_BIAS_GELU_PLANES) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                uint2 w;
+                w.x = (uint32_t)pl[p][0] | ((uint32_t)pl[p][1] << 16); w.y = (uint32_t)pl[p][2] | ((uint32_t)pl[p][3] << 16);
+                *reinterpret_cast<uint2*>(outp + p * ops + kb_index(m, n, M)) = w;
+            }
+        }
+    }
+}
+
+// Tail tiles of a hybrid launch of the 256-row kernel (launch_h3_hybrid): out = epi( sum_s slab[s][tile] + bias ) for the tiles
+// [tile_off, tile_off + tile_cnt); 4 workgroups per tile, the tile id -> (row tile, column tile) map is the kernel's.
+template <int EPI>
+__global__ __launch_bounds__(256) void splitk_reduce_tiles_h_kernel(const float* __restrict__ ws, int split, GemmHArgs a) {
+    const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + HBN - 1) / HBN;
+    const int t = blockIdx.x >> 5, part = blockIdx.x & 31, lid = a.tile_off + t;       // 32 workgroups per tile, 8 rows each
+    const int G = 8, per_group = tiles_m * G;
+    const int g = lid / per_group, rem = lid - g * per_group;
+    const int gw = min(G, tiles_n - g * G);
+    const int tm = rem / gw, tn = g * G + rem % gw;
+    const int m0 = tm * 256, n0 = tn * HBN;
+    const size_t slab = (size_t)a.tile_cnt * (256 * 128);
+    {
+        const int i = threadIdx.x;                               // 8 rows x 32 float4: one per thread
+        const int row = part * 8 + (i >> 5), c4 = (i & 31) * 4;
+        const int m = m0 + row, n = n0 + c4;
+        if (m >= a.M || n >= a.N) return;
+        const float* p = ws + (size_t)t * (256 * 128) + row * 128 + c4;
+        f32x4 acc = *reinterpret_cast<const f32x4*>(p);
+        for (int s2 = 1; s2 < split; ++s2) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(p + s2 * slab);
+            acc[0] += q[0]; acc[1] += q[1]; acc[2] += q[2]; acc[3] += q[3];
+        }
+        uint16_t pl[2][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = acc[e] + (a.bias ? a.bias[n + e] : 0.f);
+            if (EPI == HEPI_BIAS_GELU_PLANES) { split2h(gelu_tanh_h(v), pl[0][e], pl[1][e]); continue; }
+            if (EPI == HEPI_GATED_RES) v = a.res[(size_t)m * a.ldres + n + e] + v * a.gate[(size_t)(m / a.rows_per_gate) * a.gate_stride + n + e];
+            a.out[(size_t)m * a.ldo + n + e] = v;
+        }
+        if (EPI == HEPI_BIAS_GELU_PLANES) {
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+                uint2 w;
+                w.x = (uint32_t)pl[pp][0] | ((uint32_t)pl[pp][1] << 16); w.y = (uint32_t)pl[pp][2] | ((uint32_t)pl[pp][3] << 16);
+                *reinterpret_cast<uint2*>(a.outp + pp * a.ops + kb_index(m, n, a.M)) = w;
+            }
+        }
+    }
+}
+
+// ---- weight scale: 2^S with max|w| * 2^S in (2^12, 2^13]; sc[0] = 2^S, sc[1] = 2^-S (device scalars, no host sync at bind)
+__global__ void absmax_kernel(const float* __restrict__ x, size_t n, unsigned int* out) {
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));        // non-negative floats order like their bit patterns
+}
+__global__ void weight_scale_kernel(const unsigned int* mx, float* sc) {
+    const float m = __uint_as_float(*mx);
+    int e = 0;
+    if (m > 0.f && m < INFINITY) (void)frexpf(m, &e);                     // m = f * 2^e, f in [0.5, 1)
+    int S = (m > 0.f && m < INFINITY) ? 13 - e : 0;
+    S = S < -24 ? -24 : (S > 40 ? 40 : S);
+    sc[0] = ldexpf(1.0f, S); sc[1] = ldexpf(1.0f, -S);
+}
+
+int weight_scale_f16(const float* w, size_t n, float* sc, hipStream_t stream) {
+    SDVAR_CHECK_ARG(w && sc && n > 0, "weight_scale_f16: null operand");
+    unsigned int* mx = reinterpret_cast<unsigned int*>(sc) + 2;           // sc holds 4 floats: scale, 1/scale, scratch, unused
+    SDVAR_HIP(hipMemsetAsync(mx, 0, sizeof(unsigned int), stream));
+    const size_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, stream, w, n, mx);
+    SDVAR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(weight_scale_kernel, dim3(1), dim3(1), 0, stream, mx, sc);
+    SDVAR_LAUNCH_CHECK();
+    return SDVAR_OK;
+}
+
+// fp32 (rows, cols) row-major -> K-blocked planes [2][cols/32][rows][32] fp16 of x * (*scale) (weights at bind time, tests)
+__global__ __launch_bounds__(256) void split_planes_h_kernel(const float* __restrict__ x, uint16_t* __restrict__ p, int rows, int cols, size_t ps, const float* scale) {
+    const size_t n4 = (size_t)rows * cols / 4;
+    const float sc = scale ? *scale : 1.0f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i / (cols / 4)), k = (int)(i % (cols / 4)) * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)row * cols + k);
+        uint16_t q[2][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split2h(v[e] * sc, q[0][e], q[1][e]);
+        const size_t o = kb_index(row, k, rows);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            uint2 w;
+            w.x = (uint32_t)q[j][0] | ((uint32_t)q[j][1] << 16); w.y = (uint32_t)q[j][2] | ((uint32_t)q[j][3] << 16);
+            *reinterpret_cast<uint2*>(p + j * ps + o) = w;
+        }
+    }
+}
+
+int split_planes_f16(const float* x, uint16_t* planes, int rows, int cols, size_t plane_stride, const float* scale, hipStream_t stream) {
+    SDVAR_CHECK_ARG(x && planes && rows > 0 && cols > 0 && cols % 32 == 0 && plane_stride % 8 == 0, "split_planes_f16: need cols %% 32 == 0 (rows=%d cols=%d)", rows, cols);
+    const size_t blocks = ((size_t)rows * cols / 4 + 255) / 256;
+    hipLaunchKernelGGL(split_planes_h_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream, x, planes, rows, cols, plane_stride, scale);
+    SDVAR_LAUNCH_CHECK();
+    return SDVAR_OK;
+}
+
+float* splitk_workspace(size_t* floats);     // gemm.hip: the shared slab workspace
+
+// cost-model constants (see choose_cfg_h; tools/fit_gemm_model.py on profiles/r01_e_gemm_sweep_bf16x3.jsonl: geometric-mean
+// regret 1.8 %, worst case 21 %, over the d12 / d16 shapes incl. gamma = 2 chunks)
+#define CM_R256 1
+#define CM_R128 1
+#define CM_R64 3
+#define CM_R32 3
+#define CM_P256 1.1
+#define CM_P64 1.3
+#define CM_P32 1.3
+#define CM_L1 1.2
+#define CM_L2 1.0
+#define CM_L3 1.0
+#define CM_KOVER 260.0
+#define CM_FIX 1500.0
+#define CM_FIXBM 20.0
+#define CM_RED0 2000.0
+#define CM_REDBW 5000.0
+
+static int g_force_bm_h = 0, g_force_split_h = 0;
+void debug_set_gemm_cfg_h(int bm, int split) { g_force_bm_h = bm; g_force_split_h = split; }
+
+// same cost model as gemm_bf16x3.hip with half the matrix work per K-step: 3 MFMAs x 32 cycles per 16 k per 32x32 tile
+static void choose_cfg_h(int M, int N, int K, size_t ws_floats, int* bm_out, int* split_out, int* tail_out, bool allow_hybrid) {
+    const int nkt = K / HBK, tiles_n = (N + HBN - 1) / HBN;
+    double best = 1e30; int bbm = 128, bs = 1, btail = 0;
+    // per row-tile constants fitted to tools/gemm_bench.py --mode bf16x3 --sweep --dump (tools/fit_gemm_model.py):
+    //   resident workgroups per CU, K-step cost factor over the MFMA time, slowdown when 1 / 2 / 3 workgroups share a CU
+    const int bms[4] = {256, 128, 64, 32};
+    const int resident[4] = {CM_R256, CM_R128, CM_R64, CM_R32};
+    const double kfac[4] = {CM_P256, 1.0, CM_P64, CM_P32};
+    const double lat[5] = {0.0, CM_L1, CM_L2, CM_L3, 1.0};
+    for (int bi = 0; bi < 4; ++bi) {
+        const int bm = bms[bi], res = resident[bi];
+        const int tiles = ((M + bm - 1) / bm) * tiles_n;
+        const double ktile = 192.0 * (bm / 32) * kfac[bi];              // 3 MFMAs x 32 cycles x 2 k16-steps per 32x32 sub-tile
+        for (int split = 1; split <= 32 && split <= nkt / 2; ++split) {
+            if (split > 1 && ((size_t)split * M * N > ws_floats || N % 4)) break;
+            const int kps = (nkt + split - 1) / split;
+            if ((nkt + kps - 1) / kps != split) continue;
+            const long blocks = (long)tiles * split;
+            const long per_cu = (blocks + 255) / 256;
+            const double T = kps * (ktile + CM_KOVER) + CM_FIX + CM_FIXBM * bm;    // + per-K-step sync/refill, prologue + epilogue
+            const long full = per_cu / res, rem = per_cu % res;
+            const double l_full = (bm == 256) ? 1.0 : lat[res < 4 ? res : 4], l_rem = (bm == 256) ? 1.0 : lat[rem < 4 ? rem : 4];
+            double cyc = full * res * T * l_full + (rem ? rem * T * l_rem : 0.0);
+            if (split > 1) cyc += CM_RED0 + (double)(split + 1) * M * N * 4.0 / CM_REDBW;
+            if (cyc < best) { best = cyc; bbm = bm; bs = split; btail = 0; }
+        }
+        // hybrid for the 256-row tile: the full rounds run unsplit, only the last, partial round is split along K so that it, too,
+        // spreads over the CUs (264 tiles = 256 + 8: the 8 cost a whole second round otherwise)
+        if (allow_hybrid && bm == 256 && tiles > 256 && tiles % 256 && N % 4 == 0) {
+            const long fullr = tiles / 256, remt = tiles % 256;
+            const double Tfull = nkt * (ktile + CM_KOVER) + CM_FIX + CM_FIXBM * bm;
+            const int cand[7] = {2, 3, 4, 6, 8, 12, 16};
+            for (int ci = 0; ci < 7; ++ci) {
+                const int ts = cand[ci];
+                if (ts > nkt / 2 || (size_t)ts * remt * (256 * 128) > ws_floats) continue;
+                const int kps = (nkt + ts - 1) / ts;
+                if ((nkt + kps - 1) / kps != ts) continue;
+                const long rounds = (remt * ts + 255) / 256;
+                // the two extra launches are not free: ~10 us of prologue / slab epilogue / launch latency for the tail kernel, ~6 us for the reduce
+                const double cyc = fullr * Tfull + rounds * (kps * (ktile + CM_KOVER) + 20000.0) + 12000.0 + (double)(ts + 1) * remt * (256.0 * 128.0) * 4.0 / CM_REDBW;
+                if (cyc < best) { best = cyc; bbm = 256; bs = 1; btail = ts; }
+            }
+        }
+    }
+    *bm_out = bbm; *split_out = bs; *tail_out = btail;
+}
+
+static thread_local int* g_defer_h = nullptr;     // set per call by gemm_bf16x3_nt; thread-local: host threads may drive different model objects concurrently
+
+template <int EPI>
+static int launch_h2_kernel(const GemmHArgs& a, int grid, hipStream_t stream) {
+    const size_t lds = 3 * (size_t)H2_STAGE * sizeof(uint16_t);      // 96 KB
+    static LdsOptIn opt_in;
+    SDVAR_LDS_OPT_IN(opt_in, lds, (const void*)gemm_f16x2_v2_kernel<EPI>);
+    hipLaunchKernelGGL((gemm_f16x2_v2_kernel<EPI>), dim3(grid), dim3(512), lds, stream, a);
+    SDVAR_LAUNCH_CHECK();
+    return SDVAR_OK;
+}
+
+template <int EPI>
+static int launch_h3_kernel(const GemmHArgs& a, int grid, hipStream_t stream) {
+    const size_t lds = 3 * (size_t)H3_STAGE * sizeof(uint16_t);      // 144 KB
+    static LdsOptIn opt_in;
+    SDVAR_LDS_OPT_IN(opt_in, lds, (const void*)gemm_f16x2_v3_kernel<EPI>);
+    hipLaunchKernelGGL((gemm_f16x2_v3_kernel<EPI>), dim3(grid), dim3(512), lds, stream, a);
+    SDVAR_LAUNCH_CHECK();
+    return SDVAR_OK;
+}
+
+static int launch_reduce_h(const GemmHArgs& a, const float* ws, int split, int epi, hipStream_t stream) {
+    const size_t total = (size_t)a.M * (a.N / 4);
+    const int rgrid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    dim3 block(256);
+    switch (epi) {
+        case HEPI_BIAS: hipLaunchKernelGGL(splitk_reduce_h_kernel<HEPI_BIAS>, dim3(rgrid), block, 0, stream, ws, split, a.bias, a.out, a.outp, a.ops, a.res, a.gate, a.M, a.N, a.ldo, a.ldres, a.rows_per_gate, a.gate_stride); break;
+        case HEPI_BIAS_GELU_PLANES: hipLaunchKernelGGL(splitk_reduce_h_kernel<HEPI_BIAS_GELU_PLANES>, dim3(rgrid), block, 0, stream, ws, split, a.bias, a.out, a.outp, a.ops, a.res, a.gate, a.M, a.N, a.ldo, a.ldres, a.rows_per_gate, a.gate_stride); break;
+        default: hipLaunchKernelGGL(splitk_reduce_h_kernel<HEPI_GATED_RES>, dim3(rgrid), block, 0, stream, ws, split, a.bias, a.out, a.outp, a.ops, a.res, a.gate, a.M, a.N, a.ldo, a.ldres, a.rows_per_gate, a.gate_stride); break;
+    }
+    SDVAR_LAUNCH_CHECK();
+    return SDVAR_OK;
+}
+
+static int launch_h3(GemmHArgs a, int epi, int split, hipStream_t stream) {
+    const int tiles = ((a.M + 255) / 256) * ((a.N + HBN - 1) / HBN);
+    const int nkt = a.K / HBK;
+    if (split > 1) {
+        size_t wsf = 0;
+        float* ws = splitk_workspace(&wsf);
+        if (!ws) return SDVAR_ERR_HIP;
+        GemmHArgs p = a;
+        p.out = ws; p.ldo = a.N; p.split = split; p.k_per_split = (nkt + split - 1) / split;
+        int rc = launch_h3_kernel<HEPI_PARTIAL>(p, tiles * split, stream);
+        if (rc) return rc;
+        if (g_defer_h) { *g_defer_h = split; return SDVAR_OK; }
+        return launch_reduce_h(a, ws, split, epi, stream);
+    }
+    a.split = 1; a.k_per_split = nkt;
+    switch (epi) {
+        case HEPI_BIAS: return launch_h3_kernel<HEPI_BIAS>(a, tiles, stream);
+        case HEPI_BIAS_GELU_PLANES: return launch_h3_kernel<HEPI_BIAS_GELU_PLANES>(a, tiles, stream);
+        default: return launch_h3_kernel<HEPI_GATED_RES>(a, tiles, stream);
+    }
+}
+
+// full rounds unsplit + the partial last round split `tail` ways along K (compact slabs) + a reduce over the tail tiles only
+static int launch_h3_hybrid(GemmHArgs a, int epi, int tail, hipStream_t stream) {
+    const int tiles = ((a.M + 255) / 256) * ((a.N + HBN - 1) / HBN), full = tiles / 256 * 256, remt = tiles - full;
+    const int nkt = a.K / HBK;
+    size_t wsf = 0;
+    float* ws = splitk_workspace(&wsf);
+    if (!ws) return SDVAR_ERR_HIP;
+    GemmHArgs f = a;
+    f.split = 1; f.k_per_split = nkt; f.tile_off = 0; f.tile_cnt = full;
+    int rc;
+    switch (epi) {
+        case HEPI_BIAS: rc = launch_h3_kernel<HEPI_BIAS>(f, full, stream); break;
+        case HEPI_BIAS_GELU_PLANES: rc = launch_h3_kernel<HEPI_BIAS_GELU_PLANES>(f, full, stream); break;
+        default: rc = launch_h3_kernel<HEPI_GATED_RES>(f, full, stream); break;
+    }
+    if (rc) return rc;
+    GemmHArgs p = a;
+    p.out = ws; p.split = tail; p.k_per_split = (nkt + tail - 1) / tail; p.tile_off = full; p.tile_cnt = remt;
+    rc = launch_h3_kernel<HEPI_PARTIAL>(p, remt * tail, stream);
+    if (rc) return rc;
+    GemmHArgs r = a;
+    r.tile_off = full; r.tile_cnt = remt;
+    switch (epi) {
+        case HEPI_BIAS: hipLaunchKernelGGL(splitk_reduce_tiles_h_kernel<HEPI_BIAS>, dim3(32 * remt), dim3(256), 0, stream, ws, tail, r); break;
+        case HEPI_BIAS_GELU_PLANES: hipLaunchKernelGGL(splitk_reduce_tiles_h_kernel<HEPI_BIAS_GELU_PLANES>, dim3(32 * remt), dim3(256), 0, stream, ws, tail, r); break;
+        default: hipLaunchKernelGGL(splitk_reduce_tiles_h_kernel<HEPI_GATED_RES>, dim3(32 * remt), dim3(256), 0, stream, ws, tail, r); break;
+    }
+    SDVAR_LAUNCH_CHECK();
+    return SDVAR_OK;
+}
+
+template <int BM, int WAVES_M, int WAVES_N>
+static int launch_h(GemmHArgs a, int epi, int split, hipStream_t stream) {
+    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + HBN - 1) / HBN);
+    const size_t lds = 2 * (size_t)(BM + HBN) * HROW * sizeof(uint16_t);
+    dim3 block(256);
+    const bool v2 = (BM == 128);
+    const int nkt = a.K / HBK;
+    if (split > 1) {
+        size_t wsf = 0;
+        float* ws = splitk_workspace(&wsf);
+        if (!ws) return SDVAR_ERR_HIP;
+        GemmHArgs p = a;
+        p.out = ws; p.ldo = a.N; p.split = split; p.k_per_split = (nkt + split - 1) / split;
+        if (v2) { int rc = launch_h2_kernel<HEPI_PARTIAL>(p, tiles * split, stream); if (rc) return rc; }
+        else { hipLaunchKernelGGL((gemm_f16x2_kernel<BM, WAVES_M, WAVES_N, HEPI_PARTIAL>), dim3(tiles * split), block, lds, stream, p); SDVAR_LAUNCH_CHECK(); }
+        if (g_defer_h) { *g_defer_h = split; return SDVAR_OK; }
+        const size_t total = (size_t)a.M * (a.N / 4);
+        const int rgrid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+        switch (epi) {
+            case HEPI_BIAS: hipLaunchKernelGGL(splitk_reduce_h_kernel<HEPI_BIAS>, dim3(rgrid), block, 0, stream, ws, split, a.bias, a.out, a.outp, a.ops, a.res, a.gate, a.M, a.N, a.ldo, a.ldres, a.rows_per_gate, a.gate_stride); break;
+            case HEPI_BIAS_GELU_PLANES: hipLaunchKernelGGL(splitk_reduce_h_kernel<HEPI_BIAS_GELU_PLANES>, dim3(rgrid), block, 0, stream, ws, split, a.bias, a.out, a.outp, a.ops, a.res, a.gate, a.M, a.N, a.ldo, a.ldres, a.rows_per_gate, a.gate_stride); break;
+            default: hipLaunchKernelGGL(splitk_reduce_h_kernel<HEPI_GATED_RES>, dim3(rgrid), block, 0, stream, ws, split, a.bias, a.out, a.outp, a.ops, a.res, a.gate, a.M, a.N, a.ldo, a.ldres, a.rows_per_gate, a.gate_stride); break;
+        }
+        SDVAR_LAUNCH_CHECK();
+        return SDVAR_OK;
+    }
+    a.split = 1; a.k_per_split = nkt;
+    if (v2) {
+        switch (epi) {
+            case HEPI_BIAS: return launch_h2_kernel<HEPI_BIAS>(a, tiles, stream);
+            case HEPI_BIAS_GELU_PLANES: return launch_h2_kernel<HEPI_BIAS_GELU_PLANES>(a, tiles, stream);
+            default: return launch_h2_kernel<HEPI_GATED_RES>(a, tiles, stream);
+        }
+    }
+    switch (epi) {
+        case HEPI_BIAS: hipLaunchKernelGGL((gemm_f16x2_kernel<BM, WAVES_M, WAVES_N, HEPI_BIAS>), dim3(tiles), block, lds, stream, a); break;
+        case HEPI_BIAS_GELU_PLANES: hipLaunchKernelGGL((gemm_f16x2_kernel<BM, WAVES_M, WAVES_N, HEPI_BIAS_GELU_PLANES>), dim3(tiles), block, lds, stream, a); break;
+        default: hipLaunchKernelGGL((gemm_f16x2_kernel<BM, WAVES_M, WAVES_N, HEPI_GATED_RES>), dim3(tiles), block, lds, stream, a); break;
+    }
+    SDVAR_LAUNCH_CHECK();
+    return SDVAR_OK;
+}
+
+// X planes [2][K/32][M][32] (plane stride xps), W planes [2][K/32][N][32] of W * 2^S (plane stride wps), wsi -> 2^-S on the device (null: 1).
+// epi: 0 bias -> out fp32; 1 bias + GELU -> outp planes of (M, N) (plane stride ops); 2 gated residual -> out fp32.
+// defer: as gemm_bf16x3_nt (the slabs already carry the 2^-S factor).
+int gemm_f16x2_nt(const uint16_t* X, size_t xps, const uint16_t* W, size_t wps, const float* wsi, const float* bias, float* out, int ldo, uint16_t* outp, size_t ops,
+                  int M, int N, int K, int epi, const float* res, int ldres, const float* gate, int rows_per_gate, int gate_stride, int* defer,
+                  hipStream_t stream) {
+    g_defer_h = defer;
+    if (defer) *defer = 0;
+    SDVAR_CHECK_ARG(X && W, "gemm_f16x2: null operand");
+    SDVAR_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % HBK == 0, "gemm_f16x2: need K %% 32 == 0 (M=%d N=%d K=%d)", M, N, K);
+    SDVAR_CHECK_ARG(epi >= HEPI_BIAS && epi <= HEPI_GATED_RES, "gemm_f16x2: unknown epilogue %d", epi);
+    SDVAR_CHECK_ARG(epi == HEPI_BIAS_GELU_PLANES ? (outp != nullptr && N % 4 == 0) : (out != nullptr && ldo >= N), "gemm_f16x2: missing output");
+    SDVAR_CHECK_ARG(((uintptr_t)X % 16) == 0 && ((uintptr_t)W % 16) == 0 && xps % 8 == 0 && wps % 8 == 0, "gemm_f16x2: planes must be 16-byte aligned");
+    if (epi == HEPI_GATED_RES) SDVAR_CHECK_ARG(res && gate && rows_per_gate > 0 && ldres >= N, "gemm_f16x2: gated-residual epilogue needs res/gate");
+    GemmHArgs a{X, W, xps, wps, wsi, bias, out, outp, ops, res, gate, M, N, K, ldo, ldres, rows_per_gate > 0 ? rows_per_gate : 1, gate_stride, 1, K / HBK, 0, 0};
+    size_t wsf = 0;
+    (void)splitk_workspace(&wsf);
+    int bm, split, tail = 0;
+    static const bool no_hybrid = getenv("SDVAR_GEMM_NO_HYBRID") != nullptr;       // A/B runs only
+    choose_cfg_h(M, N, K, wsf, &bm, &split, &tail, !no_hybrid);
+    if (g_force_bm_h) { bm = g_force_bm_h; tail = 0; }
+    static const bool trace = getenv("SDVAR_GEMM_TRACE") != nullptr;
+    if (trace) fprintf(stderr, "[gemm_f16x2] M=%d N=%d K=%d epi=%d -> bm=%d split=%d tail=%d\n", M, N, K, epi, bm, split, tail);
+    if (g_force_split_h) {
+        split = g_force_split_h;
+        const int nkt = K / HBK;
+        if (split > nkt) split = nkt;
+        while (split > 1 && (size_t)split * M * N > wsf) --split;
+        const int kps = (nkt + split - 1) / split;
+        split = (nkt + kps - 1) / kps;
+    }
+    if (bm == 256 && tail > 0) return launch_h3_hybrid(a, epi, tail, stream);
+    if (bm == 256) return launch_h3(a, epi, split, stream);
+    if (bm == 32) return launch_h<32, 1, 4>(a, epi, split, stream);
+    if (bm == 64) return launch_h<64, 2, 2>(a, epi, split, stream);
+    return launch_h<128, 2, 2>(a, epi, split, stream);
+}
+
+}  // namespace sdvar

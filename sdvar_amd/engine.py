@@ -28,8 +28,11 @@ MAX_STAGES = 16
 ABI_VERSION = 2
 # GEMM arithmetic of the transformer blocks: 'f32' = fp32-in/fp32-accumulate MFMA; 'bf16x3' = exact 3-way bf16 split of both
 # operands, 6 bf16 MFMA products, fp32 accumulate (fp32-accurate, 2.67x the matrix-pipe throughput).  See DESIGN.md section 4.
-DEFAULT_GEMM_MODE = "bf16x3"
-PROF_CLASSES = ("gemm", "attention", "ln_modulate", "qk_norm_append", "sampler", "verify", "quant", "embed_misc")
+#   'f16x2' = two fp16 planes per operand (x ~ xh + xl to 2^-22), 3 fp16 MFMA products, fp32 accumulate: half the matrix work of bf16x3 at the same
+#             measured accuracy while activations stay inside the fp16 range (csrc/gemm_f16x2.hip).
+GEMM_MODES = ("f32", "bf16x3", "f16x2")
+DEFAULT_GEMM_MODE = "f16x2"
+PROF_CLASSES = ("gemm", "attention", "ln_modulate", "qk_norm_append", "sampler", "verify", "quant", "embed_misc", "attention_small")
 
 
 class SdvarError(RuntimeError):
@@ -82,11 +85,13 @@ _SIGNATURES = {
     "sdvar_verify_accept": (_I, [_P, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_D), _P, _I, _D, _P, _P, _P]),
     "sdvar_verify_accept_ex": (_I, [_P, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_D), _P, _I, _D, _I, _I, _D, _P, _P, _P, _P, _P, _P]),
     "sdvar_op_gemm": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P]),
-    "sdvar_op_ln_modulate": (_I, [_P, _P, _P, _P, _P, _U64, _I, _I, _I, _I, _P]),
+    "sdvar_op_ln_modulate": (_I, [_P, _P, _P, _P, _P, _U64, _I, _I, _I, _I, _I, _P]),
+    "sdvar_op_split_planes_f16": (_I, [_P, _P, _I, _I, _U64, _P, _P]),
+    "sdvar_op_gemm_f16x2": (_I, [_P, _U64, _P, _U64, _P, _P, _P, _I, _P, _U64, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P]),
     "sdvar_op_split_planes": (_I, [_P, _P, _I, _I, _U64, _P]),
     "sdvar_op_gemm_bf16x3": (_I, [_P, _U64, _P, _U64, _P, _P, _I, _P, _U64, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P]),
     "sdvar_op_qk_norm_append": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "sdvar_op_attention": (_I, [_P, _P, _P, _I, _P, _P, _U64, _I, _I, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), _P]),
+    "sdvar_op_attention": (_I, [_P, _P, _P, _I, _P, _P, _U64, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), _P]),
     "sdvar_op_conv_weight_planes": (_I, [_P, _P, _I, _I, _I, _U64, _P]),
     "sdvar_op_vae_prep": (_I, [_P, _P, _P, _P, _P, _U64, _I, _I, _I, _I, _I, _I, _I, _P]),
     "sdvar_op_conv_bf16x3": (_I, [_P, _U64, _U64, _I, _P, _U64, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _U64, _I, _P]),
@@ -155,9 +160,9 @@ class ModelCtx:
         d.max_batch, d.max_chunk_stages, d.kv_dtype = max_batch, max_chunk, (1 if kv_fp16 else 0)
         self.kv_fp16 = bool(kv_fp16)
         self.gemm_mode = gemm_mode or os.environ.get("SDVAR_GEMM_MODE", DEFAULT_GEMM_MODE)
-        if self.gemm_mode not in ("f32", "bf16x3"):
-            raise SdvarError(f"gemm_mode {self.gemm_mode!r}: expected 'f32' or 'bf16x3'")
-        d.gemm_mode = 1 if self.gemm_mode == "bf16x3" else 0
+        if self.gemm_mode not in GEMM_MODES:
+            raise SdvarError(f"gemm_mode {self.gemm_mode!r}: expected one of {GEMM_MODES}")
+        d.gemm_mode = GEMM_MODES.index(self.gemm_mode)
         for i, p in enumerate(self.lad.patch_nums):
             d.patch_nums[i] = p
         self.h = C.c_void_p()
@@ -430,9 +435,10 @@ def prof_enable(on: bool):
 
 
 def prof_collect() -> Dict[str, Dict[str, float]]:
-    ms, n, fl, by = (_D * 8)(), (C.c_int64 * 8)(), (_D * 8)(), (_D * 8)()
+    k = len(PROF_CLASSES)
+    ms, n, fl, by = (_D * k)(), (C.c_int64 * k)(), (_D * k)(), (_D * k)()
     _check(load_library().sdvar_prof_collect(ms, n, fl, by))
-    return {PROF_CLASSES[i]: dict(ms=ms[i], launches=int(n[i]), flops=fl[i], bytes=by[i]) for i in range(8)}
+    return {PROF_CLASSES[i]: dict(ms=ms[i], launches=int(n[i]), flops=fl[i], bytes=by[i]) for i in range(k)}
 
 
 # ------------------------------------------------------------------------------------------------------- sampling loops

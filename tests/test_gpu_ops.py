@@ -67,7 +67,7 @@ def test_ln_modulate(dev, rows, Cw, rpi):
     R = (rows + rpi - 1) // rpi
     mod = rnd(2, (R, 6 * Cw)).to(dev)
     out = torch.empty_like(x)
-    E._check(lib.sdvar_op_ln_modulate(_p(x), C_void(mod, 2 * Cw), C_void(mod, 4 * Cw), _p(out), None, 0, rows, Cw, rpi, 6 * Cw, _st()))
+    E._check(lib.sdvar_op_ln_modulate(_p(x), C_void(mod, 2 * Cw), C_void(mod, 4 * Cw), _p(out), None, 0, 3, rows, Cw, rpi, 6 * Cw, _st()))
     sc = mod[:, 2 * Cw:3 * Cw].repeat_interleave(rpi, 0)[:rows]; sh = mod[:, 4 * Cw:5 * Cw].repeat_interleave(rpi, 0)[:rows]
     ref = F.layer_norm(x.cpu(), (Cw,), eps=1e-6).mul(sc.cpu().add(1)).add_(sh.cpu())
     assert (out.cpu() - ref).abs().max().item() <= 2e-5
@@ -116,7 +116,7 @@ def test_attention_matches_sdpa_with_block_causal_rows(dev, R, H, lens, prefix):
     vis = [prefix + int(sum(lens[:j + 1])) for j in range(len(lens))]
     out = torch.empty(R, l, H * 64, device=dev)
     n = len(lens)
-    E._check(lib.sdvar_op_attention(_p(q), _p(kc), _p(vc), 0, _p(out), None, 0, R, H, l, Lmax, Ktot, n, (C.c_int32 * n)(*qbeg), (C.c_int32 * n)(*vis), _st()))
+    E._check(lib.sdvar_op_attention(_p(q), _p(kc), _p(vc), 0, _p(out), None, 0, 3, R, H, l, Lmax, Ktot, n, (C.c_int32 * n)(*qbeg), (C.c_int32 * n)(*vis), _st()))
     ref = _attn_ref(q.cpu(), kc.cpu()[:, :, :Ktot], vc.cpu()[:, :, :Ktot], qbeg, vis).transpose(1, 2).reshape(R, l, H * 64)
     err = (out.cpu().double() - ref).abs().max().item()
     assert err <= 2e-5, err
@@ -133,7 +133,7 @@ def test_attention_forced_online_rescale(dev):
     v = rnd(3, (R, H, Ktot, 64))
     out = torch.empty(R, l, 64, device=dev)
     qd, kd, vd = q.to(dev), k.to(dev).contiguous(), v.to(dev)                  # keep the device copies alive across the call
-    E._check(lib.sdvar_op_attention(_p(qd), _p(kd), _p(vd), 0, _p(out), None, 0, R, H, l, Ktot, Ktot, 1, (C.c_int32 * 1)(0), (C.c_int32 * 1)(Ktot), _st()))
+    E._check(lib.sdvar_op_attention(_p(qd), _p(kd), _p(vd), 0, _p(out), None, 0, 3, R, H, l, Ktot, Ktot, 1, (C.c_int32 * 1)(0), (C.c_int32 * 1)(Ktot), _st()))
     ref = _attn_ref(q, k, v, [0], [Ktot]).transpose(1, 2).reshape(R, l, 64)
     assert (out.cpu().double() - ref).abs().max().item() <= 2e-5
 
@@ -283,7 +283,7 @@ def test_fp16_kv_cache_append_and_attention(dev):
     assert (diff > 0).float().mean().item() < 1e-3 and diff.max().item() <= 1e-3       # same rounding up to 1-ulp fp32 differences before it
     assert torch.equal(vc.cpu()[:, :, pos0:], v.half())
     out = torch.empty(R, l, H * 64, device=dev)
-    E._check(lib.sdvar_op_attention(_p(qo), _p(kc), _p(vc), 1, _p(out), None, 0, R, H, l, Lmax, Lmax, 1, (C.c_int32 * 1)(0), (C.c_int32 * 1)(Lmax), _st()))
+    E._check(lib.sdvar_op_attention(_p(qo), _p(kc), _p(vc), 1, _p(out), None, 0, 3, R, H, l, Lmax, Lmax, 1, (C.c_int32 * 1)(0), (C.c_int32 * 1)(Lmax), _st()))
     ref = _attn_ref(qo.cpu(), kc.cpu().float(), vc.cpu().float(), [0], [Lmax]).transpose(1, 2).reshape(R, l, H * 64)
     assert (out.cpu().double() - ref).abs().max().item() <= 2e-5
 
@@ -318,14 +318,14 @@ def test_planes_kv_cache_append_and_attention(dev, R, H, lens, prefix):
     vis = [prefix + int(sum(lens[:j + 1])) for j in range(len(lens))]
     out = torch.empty(R, l, H * 64, device=dev)
     n = len(lens)
-    E._check(lib.sdvar_op_attention(_p(qo), _p(kc), _p(vc), 2, _p(out), None, 0, R, H, l, Lp, Ktot, n, (C.c_int32 * n)(*qbeg), (C.c_int32 * n)(*vis), _st()))
+    E._check(lib.sdvar_op_attention(_p(qo), _p(kc), _p(vc), 2, _p(out), None, 0, 3, R, H, l, Lp, Ktot, n, (C.c_int32 * n)(*qbeg), (C.c_int32 * n)(*vis), _st()))
     ref = _attn_ref(qo.cpu(), k, v, qbeg, vis).transpose(1, 2).reshape(R, l, H * 64)
     err = (out.cpu().double() - ref).abs().max().item()
     assert err <= 2e-5, err
     # plane output == fp32 output (the projection GEMM's operand)
     M = R * l
     outp = torch.zeros(3, H * 64 // 32, M, 32, device=dev, dtype=torch.int16)
-    E._check(lib.sdvar_op_attention(_p(qo), _p(kc), _p(vc), 2, None, _p(outp), M * H * 64, R, H, l, Lp, Ktot, n, (C.c_int32 * n)(*qbeg), (C.c_int32 * n)(*vis), _st()))
+    E._check(lib.sdvar_op_attention(_p(qo), _p(kc), _p(vc), 2, None, _p(outp), M * H * 64, 3, R, H, l, Lp, Ktot, n, (C.c_int32 * n)(*qbeg), (C.c_int32 * n)(*vis), _st()))
     assert torch.equal(_unplanes(outp.cpu()).float().view(R, l, H * 64), out.cpu())
 
 
@@ -350,7 +350,7 @@ def test_planes_attention_forced_online_rescale(dev):
     vc[:, :, :, :, perm] = planes3(v).permute(1, 2, 0, 4, 3)
     out = torch.empty(R, l, 64, device=dev)
     qd, kd, vd = q.to(dev), kc.to(dev).contiguous(), vc.to(dev).contiguous()
-    E._check(lib.sdvar_op_attention(_p(qd), _p(kd), _p(vd), 2, _p(out), None, 0, R, H, l, Lp, Ktot, 1, (C.c_int32 * 1)(0), (C.c_int32 * 1)(Ktot), _st()))
+    E._check(lib.sdvar_op_attention(_p(qd), _p(kd), _p(vd), 2, _p(out), None, 0, 3, R, H, l, Lp, Ktot, 1, (C.c_int32 * 1)(0), (C.c_int32 * 1)(Ktot), _st()))
     ref = _attn_ref(q, k, v, [0], [Ktot]).transpose(1, 2).reshape(R, l, 64)
     assert (out.cpu().double() - ref).abs().max().item() <= 2e-5
 
@@ -410,15 +410,15 @@ def test_ln_and_attention_plane_outputs_equal_fp32_outputs(dev):
     rows, Cw = 41, 384
     x = rnd(1, (rows, Cw), 2.0).to(dev); mod = rnd(2, (1, 6 * Cw)).to(dev)
     o32 = torch.empty_like(x); op = torch.empty(3, Cw // 32, rows, 32, dtype=torch.int16, device=dev)
-    E._check(lib.sdvar_op_ln_modulate(_p(x), C_void(mod, 2 * Cw), C_void(mod, 4 * Cw), _p(o32), None, 0, rows, Cw, rows, 6 * Cw, _st()))
-    E._check(lib.sdvar_op_ln_modulate(_p(x), C_void(mod, 2 * Cw), C_void(mod, 4 * Cw), None, _p(op), rows * Cw, rows, Cw, rows, 6 * Cw, _st()))
+    E._check(lib.sdvar_op_ln_modulate(_p(x), C_void(mod, 2 * Cw), C_void(mod, 4 * Cw), _p(o32), None, 0, 3, rows, Cw, rows, 6 * Cw, _st()))
+    E._check(lib.sdvar_op_ln_modulate(_p(x), C_void(mod, 2 * Cw), C_void(mod, 4 * Cw), None, _p(op), rows * Cw, 3, rows, Cw, rows, 6 * Cw, _st()))
     assert torch.equal(_unplanes(op).float(), o32)
     R, H, l, K = 2, 3, 100, 255
     q = (F.normalize(rnd(1, (R, H, l, 64)), dim=-1) * 4).to(dev); kc = F.normalize(rnd(2, (R, H, K, 64)), dim=-1).to(dev); vc = rnd(3, (R, H, K, 64)).to(dev)
     a32 = torch.empty(R, l, H * 64, device=dev); ap = torch.empty(3, H * 2, R * l, 32, dtype=torch.int16, device=dev)
     one = (C.c_int32 * 1)
-    E._check(lib.sdvar_op_attention(_p(q), _p(kc), _p(vc), 0, _p(a32), None, 0, R, H, l, K, K, 1, one(0), one(K), _st()))
-    E._check(lib.sdvar_op_attention(_p(q), _p(kc), _p(vc), 0, None, _p(ap), R * l * H * 64, R, H, l, K, K, 1, one(0), one(K), _st()))
+    E._check(lib.sdvar_op_attention(_p(q), _p(kc), _p(vc), 0, _p(a32), None, 0, 3, R, H, l, K, K, 1, one(0), one(K), _st()))
+    E._check(lib.sdvar_op_attention(_p(q), _p(kc), _p(vc), 0, None, _p(ap), R * l * H * 64, 3, R, H, l, K, K, 1, one(0), one(K), _st()))
     assert torch.equal(_unplanes(ap).float().view(R, l, H * 64), a32)
 
 
@@ -470,3 +470,136 @@ def test_gemm_bf16x3_hybrid_tail_split(dev, M, N, K, epi):
     auto, ref = run((0, 0)), run((128, 1))
     err = (auto - ref).abs().max().item()
     assert err <= 3e-6 * max(1.0, ref.abs().max().item()), err
+
+
+# ------------------------------------------------------------------------------------------------ f16x2 split-operand path
+def _planes_h(t, dev, scaled=False):
+    """fp32 (rows, K) -> (K-blocked fp16 planes (2, K/32, rows, 32) int16, scale tensor or None) through the library's splitter."""
+    lib = E.load_library()
+    x = t.to(dev).contiguous()
+    rows, K = x.shape
+    p = torch.empty(2, K // 32, rows, 32, dtype=torch.int16, device=dev)
+    sc = torch.zeros(4, device=dev) if scaled else None
+    E._check(lib.sdvar_op_split_planes_f16(_p(x), _p(p), rows, K, rows * K, _p(sc) if scaled else None, _st()))
+    return p, sc
+
+
+def _unplanes_h(p):
+    """K-blocked fp16 planes (2, K/32, rows, 32) -> fp64 (rows, K)."""
+    v = sum(p[k].view(torch.float16).double() for k in range(2))
+    return v.permute(1, 0, 2).reshape(v.shape[1], -1)
+
+
+def test_split_planes_f16_accuracy_and_scale(dev):
+    """x ~ h + l to 2^-22 relative while l is a normal fp16 number (|x| >= 2^-3), absolute 2^-25 below; values beyond the fp16 range saturate;
+    the weight scale is the power of two that brings max|w| into (2^12, 2^13]."""
+    x = rnd(1, (257, 64), 3.0)
+    x[0, :6] = torch.tensor([0.0, 1.0, -1.0, 1e-9, 7e4, -1e9])
+    p, _ = _planes_h(x, dev)
+    got = _unplanes_h(p).cpu()
+    xs = x.double().clamp(-65504, 65504)
+    err = (got - xs).abs()
+    assert bool((err <= torch.maximum(xs.abs() * 2.0 ** -21.9, torch.tensor(2.0 ** -24.9, dtype=torch.float64))).all())
+    w = rnd(2, (128, 96), 0.02)
+    p, sc = _planes_h(w, dev, scaled=True)
+    S = sc.cpu()
+    assert S[0] * S[1] == 1.0 and 2 ** 12 < float(w.abs().max()) * float(S[0]) <= 2 ** 13 and math.log2(float(S[0])).is_integer()
+    rel = ((_unplanes_h(p).cpu() * float(S[1]) - w.double()).abs() / w.double().abs().clamp_min(1e-30))
+    assert float(rel[w.abs() > 1e-4].max()) <= 2.0 ** -21.9
+
+
+@pytest.mark.parametrize("M,N,K", [(16, 768, 256), (1, 128, 32), (33, 384, 1024), (64, 3072, 1024), (100, 1024, 4096), (400, 1152, 384),
+                                   (576, 4096, 1024), (1600, 1024, 1024), (4096, 256, 1024), (130, 192, 64), (2704, 1024, 4096)])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_gemm_f16x2_epilogues(dev, M, N, K, epi):
+    """The three-product fp16 scheme with scaled weights: error vs fp64 within the band of the fp32 MFMA kernel (same bound as bf16x3)."""
+    lib = E.load_library()
+    X, W, b = rnd(1, (M, K)), rnd(2, (N, K), 1 / math.sqrt(K)), rnd(3, (N,)).to(dev)
+    (Xp, _), (Wp, sc) = _planes_h(X, dev), _planes_h(W, dev, scaled=True)
+    rows_per_gate = 7 if M > 7 else 1
+    R = (M + rows_per_gate - 1) // rows_per_gate
+    res, gate = rnd(4, (M, N)).to(dev), rnd(5, (R, 2 * N)).to(dev)
+    out = res.clone() if epi == 2 else torch.empty(M, N, device=dev)
+    outp = torch.empty(2, N // 32, M, 32, dtype=torch.int16, device=dev) if epi == 1 else None
+    E._check(lib.sdvar_op_gemm_f16x2(_p(Xp), M * K, _p(Wp), N * K, _p(sc), _p(b), _p(out), N, _p(outp), M * N, M, N, K, epi, _p(out) if epi == 2 else None, N,
+                                     _p(gate) if epi == 2 else None, rows_per_gate, 2 * N, _st()))
+    ref = X.double() @ W.double().t() + b.cpu().double()
+    if epi == 1:
+        ref = F.gelu(ref, approximate="tanh"); got = _unplanes_h(outp).cpu()
+    elif epi == 2:
+        g = gate.cpu()[:, :N].double().repeat_interleave(rows_per_gate, 0)[:M]
+        ref = res.cpu().double() + ref * g; got = out.cpu().double()
+    else:
+        got = out.cpu().double()
+    err = (got - ref).abs().max().item()
+    assert err <= 2e-5 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("bm", [32, 64, 128, 256])
+@pytest.mark.parametrize("M,N,K,split", [(130, 192, 64, 1), (1, 128, 32, 1), (257, 384, 1024, 3), (4096, 256, 1024, 1), (2704, 1024, 4096, 5), (100, 4096, 1024, 2),
+                                         (300, 256, 96, 1), (300, 256, 96, 3)])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_gemm_f16x2_kernels_forced_tile(dev, M, N, K, split, epi, bm):
+    """Every f16x2 kernel (register-staged 32/64-row tiles, LDS-DMA 128x128 and 256x128 with their 3-stage rings) on ragged edges, K loops
+    of 1 .. 128 steps (ring fill / drain paths) and split-K."""
+    lib = E.load_library()
+    X, W, b = rnd(1, (M, K)), rnd(2, (N, K), 1 / math.sqrt(K)), rnd(3, (N,)).to(dev)
+    (Xp, _), (Wp, sc) = _planes_h(X, dev), _planes_h(W, dev, scaled=True)
+    res, gate = rnd(4, (M, N)).to(dev), rnd(5, (M, 2 * N)).to(dev)
+    out = res.clone() if epi == 2 else torch.full((M, N), float("nan"), device=dev)
+    outp = torch.empty(2, N // 32, M, 32, dtype=torch.int16, device=dev) if epi == 1 else None
+    E._check(lib.sdvar_debug_set_gemm_cfg(bm, split))
+    try:
+        E._check(lib.sdvar_op_gemm_f16x2(_p(Xp), M * K, _p(Wp), N * K, _p(sc), _p(b), _p(out), N, _p(outp), M * N, M, N, K, epi, _p(out) if epi == 2 else None, N,
+                                         _p(gate) if epi == 2 else None, 1, 2 * N, _st()))
+    finally:
+        E._check(lib.sdvar_debug_set_gemm_cfg(0, 0))
+    ref = X.double() @ W.double().t() + b.cpu().double()
+    if epi == 1:
+        ref = F.gelu(ref, approximate="tanh"); got = _unplanes_h(outp).cpu()
+    elif epi == 2:
+        ref = res.cpu().double() + ref * gate.cpu()[:, :N].double(); got = out.cpu().double()
+    else:
+        got = out.cpu().double()
+    err = (got - ref).abs().max().item()
+    assert err <= 2e-5 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(2704, 3072, 1024, 0), (4096, 2304, 768, 0), (2704, 4096, 1024, 1), (4096, 3072, 768, 2), (2500, 3072, 256, 0)])
+def test_gemm_f16x2_hybrid_tail_split(dev, M, N, K, epi):
+    lib = E.load_library()
+    x = rnd(1, (M, K)).to(dev); w = (rnd(2, (N, K)) / K ** 0.5).to(dev); b = rnd(3, (N,), 0.1).to(dev)
+    res = rnd(4, (M, N)).to(dev); gate = rnd(5, (4, N)).to(dev)
+    (xp, _), (wp, sc) = _planes_h(x, dev), _planes_h(w, dev, scaled=True)
+
+    def run(force):
+        E._check(lib.sdvar_debug_set_gemm_cfg(*force))
+        out = res.clone() if epi == 2 else torch.zeros(M, N, device=dev)
+        outp = torch.zeros(2, N // 32, M, 32, device=dev, dtype=torch.int16)
+        E._check(lib.sdvar_op_gemm_f16x2(_p(xp), M * K, _p(wp), N * K, _p(sc), _p(b), _p(out), N, _p(outp), M * N, M, N, K, epi, _p(out) if epi == 2 else None, N,
+                                         _p(gate) if epi == 2 else None, (M + 3) // 4, N, _st()))
+        E._check(lib.sdvar_debug_set_gemm_cfg(0, 0))
+        return _unplanes_h(outp.cpu()) if epi == 1 else out.cpu().double()
+    auto, ref = run((0, 0)), run((128, 1))
+    err = (auto - ref).abs().max().item()
+    assert err <= 3e-6 * max(1.0, ref.abs().max().item()), err
+
+
+def test_ln_and_attention_f16x2_plane_outputs(dev):
+    """The producers' f16x2 planes hold the fp32 outputs to 2^-22 relative / 2^-25 absolute."""
+    lib = E.load_library()
+    rows, Cw = 41, 384
+    x = rnd(1, (rows, Cw), 2.0).to(dev); mod = rnd(2, (1, 6 * Cw)).to(dev)
+    o32 = torch.empty_like(x); op = torch.empty(2, Cw // 32, rows, 32, dtype=torch.int16, device=dev)
+    E._check(lib.sdvar_op_ln_modulate(_p(x), C_void(mod, 2 * Cw), C_void(mod, 4 * Cw), _p(o32), None, 0, 3, rows, Cw, rows, 6 * Cw, _st()))
+    E._check(lib.sdvar_op_ln_modulate(_p(x), C_void(mod, 2 * Cw), C_void(mod, 4 * Cw), None, _p(op), rows * Cw, 2, rows, Cw, rows, 6 * Cw, _st()))
+    tol = lambda ref: torch.maximum(ref.abs() * 2.0 ** -21.9, torch.tensor(2.0 ** -24.9, dtype=torch.float64, device=ref.device))
+    assert bool(((_unplanes_h(op) - o32.double()).abs() <= tol(o32.double())).all())
+    R, H, l, K = 2, 3, 100, 255
+    q = (F.normalize(rnd(1, (R, H, l, 64)), dim=-1) * 4).to(dev); kc = F.normalize(rnd(2, (R, H, K, 64)), dim=-1).to(dev); vc = rnd(3, (R, H, K, 64)).to(dev)
+    a32 = torch.empty(R, l, H * 64, device=dev); ap = torch.empty(2, H * 2, R * l, 32, dtype=torch.int16, device=dev)
+    one = (C.c_int32 * 1)
+    E._check(lib.sdvar_op_attention(_p(q), _p(kc), _p(vc), 0, _p(a32), None, 0, 3, R, H, l, K, K, 1, one(0), one(K), _st()))
+    E._check(lib.sdvar_op_attention(_p(q), _p(kc), _p(vc), 0, None, _p(ap), R * l * H * 64, 2, R, H, l, K, K, 1, one(0), one(K), _st()))
+    ref = a32.double().view(R * l, H * 64)
+    assert bool(((_unplanes_h(ap) - ref).abs() <= tol(ref)).all())

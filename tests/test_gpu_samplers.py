@@ -13,7 +13,7 @@ from sdvar_amd.noise import exponential_noise
 
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
-GEMM_MODES = ["f32", "bf16x3"]
+GEMM_MODES = ["f32", "bf16x3", "f16x2"]          # fp32 MFMA and the two split-operand GEMMs: the same parity bar for all
 
 
 def _noise_o(seed):

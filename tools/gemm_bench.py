@@ -18,7 +18,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--chunk", type=int, default=1)
-    ap.add_argument("--mode", default="f32", choices=["f32", "bf16x3"])
+    ap.add_argument("--mode", default="f32", choices=["f32", "bf16x3", "f16x2"])
     ap.add_argument("--dump", default="", help="append the full sweep table (JSON lines) to this file")
     ap.add_argument("--sweep", action="store_true", help="time every (row tile, K slices) candidate per shape")
     a = ap.parse_args()
@@ -42,7 +42,17 @@ def main():
                 E._check(lib.sdvar_op_split_planes(C.c_void_p(X.data_ptr()), C.c_void_p(Xp.data_ptr()), M, K, M * K, st))
                 E._check(lib.sdvar_op_split_planes(C.c_void_p(W.data_ptr()), C.c_void_p(Wp.data_ptr()), N, K, N * K, st))
                 outp = torch.empty(3, M, N, dtype=torch.int16, device=dev)
+            if a.mode == "f16x2":
+                Xp = torch.empty(2, M, K, dtype=torch.int16, device=dev); Wp = torch.empty(2, N, K, dtype=torch.int16, device=dev); wsc = torch.zeros(4, device=dev)
+                E._check(lib.sdvar_op_split_planes_f16(C.c_void_p(X.data_ptr()), C.c_void_p(Xp.data_ptr()), M, K, M * K, None, st))
+                E._check(lib.sdvar_op_split_planes_f16(C.c_void_p(W.data_ptr()), C.c_void_p(Wp.data_ptr()), N, K, N * K, C.c_void_p(wsc.data_ptr()), st))
+                outp = torch.empty(2, M, N, dtype=torch.int16, device=dev)
             def run():
+                if a.mode == "f16x2":
+                    E._check(lib.sdvar_op_gemm_f16x2(C.c_void_p(Xp.data_ptr()), M * K, C.c_void_p(Wp.data_ptr()), N * K, C.c_void_p(wsc.data_ptr()), C.c_void_p(b.data_ptr()),
+                                                     C.c_void_p(out.data_ptr()), N, C.c_void_p(outp.data_ptr()), M * N, M, N, K, epi,
+                                                     C.c_void_p(out.data_ptr()) if epi == 2 else None, N, C.c_void_p(gate.data_ptr()) if epi == 2 else None, l, 6 * Cw, st))
+                    return
                 if a.mode == "bf16x3":
                     E._check(lib.sdvar_op_gemm_bf16x3(C.c_void_p(Xp.data_ptr()), M * K, C.c_void_p(Wp.data_ptr()), N * K, C.c_void_p(b.data_ptr()),
                                                       C.c_void_p(out.data_ptr()), N, C.c_void_p(outp.data_ptr()), M * N, M, N, K, epi,
@@ -60,7 +70,7 @@ def main():
             us = timeit()
             if a.sweep:
                 res = []
-                for bm in ((32, 64, 128, 256) if a.mode == "bf16x3" else (32, 64, 128)):
+                for bm in ((32, 64, 128, 256) if a.mode != "f32" else (32, 64, 128)):
                     for split in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 24, 32):
                         if split > K // 64: continue
                         E._check(lib.sdvar_debug_set_gemm_cfg(bm, split))

@@ -18,7 +18,7 @@ for n, pos0 in ((prefix, 0), (l, prefix)):
 out = torch.empty(R, l, H * 64, device=dev)
 qb, vs = (C.c_int32 * 1)(0), (C.c_int32 * 1)(Ktot)
 for _ in range(3):
-    E._check(lib.sdvar_op_attention(P(qo), P(kc), P(vc), 2, P(out), None, 0, R, H, l, Lp, Ktot, 1, qb, vs, st))
+    E._check(lib.sdvar_op_attention(P(qo), P(kc), P(vc), 2, P(out), None, 0, 3, R, H, l, Lp, Ktot, 1, qb, vs, st))
 torch.cuda.synchronize()
 nw = min(4096, R * H * ((l + 127) // 128) * 4)
 buf = np.zeros((nw, 8), dtype=np.uint64)

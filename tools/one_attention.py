@@ -20,7 +20,7 @@ for n, pos0 in ((prefix, 0), (l, prefix)):
         E._check(lib.sdvar_op_qk_norm_append(P(qkv), P(sm), P(qo), P(kc), P(vc), fmt, R, n, H, Lp, pos0, st))
 out = torch.empty(R, l, H * 64, device=dev)
 qb, vs = (C.c_int32 * 1)(0), (C.c_int32 * 1)(Ktot)
-run = lambda: E._check(lib.sdvar_op_attention(P(qo), P(kc), P(vc), fmt, P(out), None, 0, R, H, l, Lp, Ktot, 1, qb, vs, st))
+run = lambda: E._check(lib.sdvar_op_attention(P(qo), P(kc), P(vc), fmt, P(out), None, 0, 3, R, H, l, Lp, Ktot, 1, qb, vs, st))
 for _ in range(3): run()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
