@@ -542,8 +542,8 @@ int split_planes_f16(const float* x, uint16_t* planes, int rows, int cols, size_
 
 float* splitk_workspace(size_t* floats);     // gemm.hip: the shared slab workspace
 
-// cost-model constants (see choose_cfg_h; tools/fit_gemm_model.py on profiles/r01_e_gemm_sweep_bf16x3.jsonl: geometric-mean
-// regret 1.8 %, worst case 21 %, over the d12 / d16 shapes incl. gamma = 2 chunks)
+// cost-model constants (see choose_cfg_h; `tools/fit_gemm_model.py profiles/r02_gemm_sweep_f16x2.jsonl 192`: geometric-mean
+// regret 4.1 %, worst case 30 %, over the d12 / d16 shapes incl. gamma = 2 chunks)
 #define CM_R256 1
 #define CM_R128 1
 #define CM_R64 3
@@ -551,14 +551,14 @@ float* splitk_workspace(size_t* floats);     // gemm.hip: the shared slab worksp
 #define CM_P256 1.1
 #define CM_P64 1.3
 #define CM_P32 1.3
-#define CM_L1 1.2
-#define CM_L2 1.0
-#define CM_L3 1.0
-#define CM_KOVER 260.0
-#define CM_FIX 1500.0
-#define CM_FIXBM 20.0
+#define CM_L1 1.0
+#define CM_L2 1.1
+#define CM_L3 1.05
+#define CM_KOVER 600.0
+#define CM_FIX 12000.0
+#define CM_FIXBM 80.0
 #define CM_RED0 2000.0
-#define CM_REDBW 5000.0
+#define CM_REDBW 8000.0
 
 static int g_force_bm_h = 0, g_force_split_h = 0;
 void debug_set_gemm_cfg_h(int bm, int split) { g_force_bm_h = bm; g_force_split_h = split; }

@@ -1,14 +1,16 @@
 #!/usr/bin/env python3
-"""Fit the constants of gemm_bf16x3.hip::choose_cfg_p to a sweep dump (tools/gemm_bench.py --mode bf16x3 --sweep --dump F).
+"""Fit the constants of gemm_bf16x3.hip::choose_cfg_p / gemm_f16x2.hip::choose_cfg_h to a sweep dump
+(tools/gemm_bench.py --mode bf16x3|f16x2 --sweep --dump F).   python tools/fit_gemm_model.py F [ktile: 384 (bf16x3, default) | 192 (f16x2)]
 Random search minimising the geometric-mean regret (time of the model's pick / time of the best swept configuration)."""
 import json, math, random, sys
 rows = [json.loads(l) for l in open(sys.argv[1])]
+KTILE = float(sys.argv[2]) if len(sys.argv) > 2 else 384.0
 
 def model(M, N, K, bm, split, c):
     nkt, tiles_n = K // 32, (N + 127) // 128
     res = {256: 1, 128: c['r128'], 64: c['r64'], 32: c['r32']}[bm]
     tiles = ((M + bm - 1) // bm) * tiles_n
-    ktile = 384.0 * (bm // 32) * {256: c['p256'], 128: 1.0, 64: c['p64'], 32: c['p32']}[bm]
+    ktile = KTILE * (bm // 32) * {256: c['p256'], 128: 1.0, 64: c['p64'], 32: c['p32']}[bm]
     kps = (nkt + split - 1) // split
     per_cu = (tiles * split + 255) // 256
     T = kps * (ktile + c['kover']) + c['fix'] + c['fixbm'] * bm
