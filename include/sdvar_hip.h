@@ -125,6 +125,7 @@ typedef struct {
     int32_t num_res_blocks;                 /* 2: every decoder level has num_res_blocks + 1 ResnetBlocks (basic_vae.py:196) */
     int32_t max_batch;
     int32_t latent_hw;                      /* side of f_hat: 16 for 256^2 images, 32 for 512^2 */
+    int32_t plane_format;                   /* operands of the convolutions: 0 or 2 = f16x2 (two fp16 planes, three MFMA products), 3 = bf16x3 */
 } sdvar_vae_desc;
 int sdvar_vae_create(const sdvar_vae_desc* desc /*host*/, sdvar_vae_t** out /*host*/);
 int sdvar_vae_destroy(sdvar_vae_t* v);
@@ -193,17 +194,18 @@ int sdvar_op_attention(const float* q, const void* k_cache, const void* v_cache,
 int sdvar_op_noise_fill(float* q, int32_t B, int32_t l, int32_t V, uint64_t seed, uint32_t draw, uint32_t image_offset, void* stream);
 
 /* conv weight (Cout, Cin, kh, kw) with kh*kw = taps (1 or 9) -> K-blocked planes [3][taps*Cin/32][Cout][32], k = tap*Cin + cin */
-int sdvar_op_conv_weight_planes(const float* w, uint16_t* planes, int32_t Cout, int32_t Cin, int32_t taps, uint64_t plane_stride, void* stream);
+int sdvar_op_conv_weight_planes(const float* w, uint16_t* planes, int32_t Cout, int32_t Cin, int32_t taps, uint64_t plane_stride, int32_t plane_format /* 3 | 2 */,
+                                float* scale /* f16x2: receives {2^S, 2^-S, ..} (4 device floats), may be NULL */, void* stream);
 /* fp32 channel-last rows [B H W][C] of a (B,C,H,W) tensor -> planes [3][C/32][guard + B(Ho+2)(Wo+2) + guard][32] of the
  * (B,C,H<<up,W<<up) tensor over padded pixel rows (prow(b,y,x) = (b(Ho+2)+y+1)(Wo+2)+x+1, zero frame and guards).
  * mode bit 0: GroupNorm(32 groups) with stats (B,32,{mean,rstd}), gamma, beta; bit 1: SiLU. */
-int sdvar_op_vae_prep(const float* in, const float* stats, const float* gamma, const float* beta, uint16_t* planes, uint64_t plane_stride, int32_t B, int32_t C,
-                      int32_t H, int32_t W, int32_t up, int32_t mode, int32_t guard, void* stream);
+int sdvar_op_vae_prep(const float* in, const float* stats, const float* gamma, const float* beta, uint16_t* planes, uint64_t plane_stride, int32_t plane_format, int32_t B,
+                      int32_t C, int32_t H, int32_t W, int32_t up, int32_t mode, int32_t guard, void* stream);
 /* out[B H W][N] = conv(x planes of a (B,Cin,H,W) tensor, w planes) + bias (+ res[B H W][N]); taps = 9: 3x3 pad 1, taps = 1: 1x1.  x_row0 =
  * guard rows (>= W+3).  workspace: split-K slabs (may be NULL: no split); force_split > 0 overrides the heuristic. */
-int sdvar_op_conv_bf16x3(const uint16_t* x_planes, uint64_t x_plane_stride, uint64_t x_rows, int32_t x_row0, const uint16_t* w_planes, uint64_t w_plane_stride,
-                         const float* bias, const float* res, float* out, int32_t B, int32_t H, int32_t W, int32_t N, int32_t Cin, int32_t taps, float* workspace,
-                         uint64_t workspace_floats, int32_t force_split, void* stream);
+int sdvar_op_conv_planes(const uint16_t* x_planes, uint64_t x_plane_stride, uint64_t x_rows, int32_t x_row0, const uint16_t* w_planes, uint64_t w_plane_stride,
+                         int32_t plane_format, const float* w_scale, const float* bias, const float* res, float* out, int32_t B, int32_t H, int32_t W, int32_t N,
+                         int32_t Cin, int32_t taps, float* workspace, uint64_t workspace_floats, int32_t force_split, void* stream);
 /* tuning aid (tools/gemm_bench.py --sweep): force the GEMM row tile (32/64/128) and K-slice count; 0 = automatic */
 int sdvar_debug_set_gemm_cfg(int32_t bm, int32_t split);
 /* diagnostic: per-workgroup s_memtime stamps (4 x u64 per workgroup: entry, main loop start, main loop end, exit) of the

@@ -22,24 +22,99 @@
 namespace sdvar {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
 enum { CEPI_BIAS = 0, CEPI_BIAS_RES = 1, CEPI_PARTIAL = 2 };
 constexpr int CBM = 256, CBN = 160;
 constexpr int CSTAGE = 3 * (CBM + CBN) * 32;        // bf16 elements per stage: X planes [3][256][32] then W planes [3][160][32]
+constexpr int CSTAGE_H = 2 * (CBM + CBN) * 32;      // f16x2 kernel: X planes [2][256][32] then W planes [2][160][32] (52 KB), 3-stage ring
 
 struct ConvArgs {
     const uint16_t* X; const uint16_t* W;          // planes; X rows include the guards
     size_t xps, wps;                               // plane strides (elements)
     size_t x_rows;                                 // rows per channel block of X (G + M + G)
     int x_row0;                                    // G
+    const float* wsi;                              // f16x2 only: device scalar 2^-S undoing the weight scale (gemm_f16x2.hip), null = 1
     const float* bias; const float* res; float* out;
     int M, N, cb, taps, ih, iw, ldo, split, k_per_split;   // cb = Cin / 32; K-steps = taps * cb; (ih, iw): image size, M = B ih iw
     double* gn_part; int cpg;                      // optional GroupNorm partial sums of the OUTPUT: [M/256][32 groups][sum, sumsq], cpg = N / 32
     int up_phase;                                  // >= 0: fused nearest-2x up-sampling (taps = 4): blockIdx.y = output phase (py, px) = (y >> 1, y & 1)
     size_t w_phase_stride;                         //       weight planes of phase p at W + p * w_phase_stride
 };
+
+// Shared epilogue of both convolution kernels: (acc * wsi) + bias (+ residual), the up-sampling phase scatter, split-K slabs, and the
+// fused GroupNorm statistics of the tile just written.
+template <int EPI>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[5], float wsi, int m0, int n0, int tm, int ks, int phase, int wave, int li, int lh,
+                                              int tid, uint16_t* csm) {
+    // epilogue.  The residual is fetched for the whole wave tile first (80 independent loads in flight: the operand
+    // fragments are dead by now), then added and stored: interleaved load -> add -> store chains cost 35 us per workgroup.
+    float rv[5][16];
+    if (EPI == CEPI_BIAS_RES) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int n = n0 + j * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                rv[j][r] = (n < a.N && m < a.M) ? a.res[(size_t)m * a.ldo + n] : 0.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int n = n0 + j * 32 + li;
+        if (n >= a.N) continue;
+        const float bv = (EPI != CEPI_PARTIAL && a.bias) ? a.bias[n] : 0.f;
+        float* outp = (EPI == CEPI_PARTIAL) ? a.out + (size_t)ks * a.M * a.ldo : a.out;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (m >= a.M) continue;
+            float v = acc[j][r] * wsi + bv;
+            if (EPI == CEPI_BIAS_RES) v += rv[j][r];
+            size_t orow = (size_t)m;
+            if (EPI != CEPI_PARTIAL && a.up_phase >= 0) {         // pixel (b, y, x) of the input grid -> (b, 2y + py, 2x + px) of the output grid
+                const int hw = a.ih * a.iw, b = m / hw, rem = m - b * hw, y = rem / a.iw, x = rem - y * a.iw;
+                orow = ((size_t)(b * 2 * a.ih + 2 * y + (phase >> 1)) * (2 * a.iw) + 2 * x + (phase & 1));
+            }
+            outp[orow * a.ldo + n] = v;
+            acc[j][r] = v;
+        }
+    }
+    // GroupNorm statistics of the tile just written (the next layer's norm): per column sum / sum of squares over the 256 rows
+    // (all of one image: the host enables this only when H W is a multiple of 256), reduced lane -> wave -> workgroup through
+    // LDS in a fixed order, then per group in fp64.  Saves a full read of the activation tensor per normalisation.
+    if (EPI != CEPI_PARTIAL && a.gn_part) {
+        float* red = reinterpret_cast<float*>(csm);          // [2][8][160]
+        __syncthreads();                                     // every wave is done with the operand stages
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            float s1 = 0.f, s2 = 0.f;
+            if (n0 + j * 32 + li < a.N) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s1 += acc[j][r]; s2 += acc[j][r] * acc[j][r]; }
+            }
+            const auto w1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(s1), __float_as_uint(s1), false, false);
+            const auto w2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(s2), __float_as_uint(s2), false, false);
+            if (lh == 0) {
+                red[wave * 160 + j * 32 + li] = __uint_as_float(w1[0]) + __uint_as_float(w1[1]);
+                red[1280 + wave * 160 + j * 32 + li] = __uint_as_float(w2[0]) + __uint_as_float(w2[1]);
+            }
+        }
+        __syncthreads();
+        const int gl = tid, col0 = gl * a.cpg;
+        if (col0 < CBN && n0 + col0 < a.N) {
+            double a1 = 0.0, a2 = 0.0;
+            for (int w = 0; w < 8; ++w)
+                for (int c = 0; c < a.cpg; ++c) { a1 += (double)red[w * 160 + col0 + c]; a2 += (double)red[1280 + w * 160 + col0 + c]; }
+            double* o = a.gn_part + ((size_t)(a.up_phase >= 0 ? 4 * tm + phase : tm) * 32 + (n0 + col0) / a.cpg) * 2;
+            o[0] = a1; o[1] = a2;
+        }
+    }
+}
 
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void conv_bf16x3_kernel(ConvArgs a) {
@@ -160,71 +235,126 @@ __global__ __launch_bounds__(512, 2) void conv_bf16x3_kernel(ConvArgs a) {
 #undef SDVAR_LDS_RD
     }
 
-    // epilogue.  The residual is fetched for the whole wave tile first (80 independent loads in flight: the operand
-    // fragments are dead by now), then added and stored: interleaved load -> add -> store chains cost 35 us per workgroup.
-    float rv[5][16];
-    if (EPI == CEPI_BIAS_RES) {
+    conv_epilogue<EPI>(a, acc, 1.0f, m0, n0, tm, ks, phase, wave, li, lh, tid, csm);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same implicit GEMM on f16x2 operands (gemm_f16x2.hip: two fp16 planes, three products, weights scaled by 2^S): half the matrix
+// work per K-step (30 MFMAs per wave), so the ring has three stages and keeps two K-steps of LDS-DMA in flight.
+//   stage = X planes [2][256][32] then W planes [2][160][32]; per K-step wave w issues X rows [32w, 32w+32) of both planes (4 instructions)
+//   and W rows [16w, 16w+16) (2), waves 0 and 1 also W rows [128 + 16w, ...) (2 more): the counted vmcnt wait is per wave.
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t csm[];
+    const int tiles_m = (a.M + CBM - 1) / CBM, tiles_n = (a.N + CBN - 1) / CBN, ntile = tiles_m * tiles_n;
+    const int ks = blockIdx.x / ntile;
+    const int lid = xcd_remap(blockIdx.x - ks * ntile, ntile);
+    const int tm = lid / tiles_n, tn = lid - tm * tiles_n;
+    const int m0 = tm * CBM, n0 = tn * CBN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int phase = a.up_phase >= 0 ? (int)blockIdx.y : 0;
+    const uint16_t* Wp = a.W + (size_t)phase * a.w_phase_stride;
+
+    const int r16 = lane >> 2;
+    const int xr0 = 32 * wave + r16, xr1 = xr0 + 16, wr0 = 16 * wave + r16, wr1 = 128 + wr0;
+    const int cx0 = (lane & 3) ^ ((xr0 >> 2) & 3), cx1 = (lane & 3) ^ ((xr1 >> 2) & 3), cw0 = (lane & 3) ^ ((wr0 >> 2) & 3), cw1 = (lane & 3) ^ ((wr1 >> 2) & 3);
+    const int nkt = a.taps * a.cb;
+    const int kt0 = ks * a.k_per_split;
+    const int nk = min(nkt - kt0, a.k_per_split);
+    const int w2 = a.iw + 2;
+    auto prow = [&](int m) {
+        const int hw = a.ih * a.iw, b = m / hw, rem = m - b * hw, y = rem / a.iw, x = rem - y * a.iw;
+        return (size_t)(b * (a.ih + 2) + y + 1) * w2 + x + 1;
+    };
+    const int swave = __builtin_amdgcn_readfirstlane(wave);
+    const uint32_t lx0 = (uint32_t)((a.x_row0 + prow(min(m0 + xr0, a.M - 1))) * 32 + 8 * cx0) * 2u;
+    const uint32_t lx1 = (uint32_t)((a.x_row0 + prow(min(m0 + xr1, a.M - 1))) * 32 + 8 * cx1) * 2u;
+    const uint32_t lw0 = (uint32_t)(min(n0 + wr0, a.N - 1) * 32 + 8 * cw0) * 2u, lw1 = (uint32_t)(min(n0 + wr1, a.N - 1) * 32 + 8 * cw1) * 2u;
+    const bool two_w = swave < 2;
+    const char* ux = nullptr; const char* uw = nullptr;
+    const int tw = (a.taps == 9) ? 3 : 2;
+    int sc = kt0 % a.cb, stap = kt0 / a.cb, sty = stap / tw, stx = stap - sty * tw, skb = kt0;
+    auto set_next = [&]() {
+        const int shift = (a.taps == 9) ? (sty - 1) * w2 + (stx - 1) : (a.taps == 4) ? (sty - 1 + (phase >> 1)) * w2 + (stx - 1 + (phase & 1)) : 0;
+        ux = reinterpret_cast<const char*>(a.X) + ((long long)sc * (long long)a.x_rows + shift) * 64;
+        uw = reinterpret_cast<const char*>(Wp) + (size_t)skb * a.N * 64;
+        ++skb;
+        if (++sc == a.cb) { sc = 0; if (++stx == tw) { stx = 0; ++sty; } }
+    };
+    // DMA instruction q of the step set up last -> stage st: q in [0, 6): plane q / 3, kind q % 3 (X group 0, X group 1, W group 0); q in [6, 8): W group 1 of plane q - 6
+    auto issue_one = [&](uint16_t* st, int q) {
+        if (q < 6) {
+            const int p = q / 3, kind = q % 3;
+            if (kind == 0) SDVAR_DMA16(lx0, ux + p * a.xps * 2, SDVAR_LDS_ADDR(st + p * 8192 + swave * 1024));
+            else if (kind == 1) SDVAR_DMA16(lx1, ux + p * a.xps * 2, SDVAR_LDS_ADDR(st + p * 8192 + swave * 1024 + 512));
+            else SDVAR_DMA16(lw0, uw + p * a.wps * 2, SDVAR_LDS_ADDR(st + 2 * 8192 + p * 5120 + swave * 512));
+        } else if (two_w) {
+            const int p = q - 6;
+            SDVAR_DMA16(lw1, uw + p * a.wps * 2, SDVAR_LDS_ADDR(st + 2 * 8192 + p * 5120 + 4096 + swave * 512));
+        }
+    };
+
+    f32x16 acc[5];
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const int n = n0 + j * 32 + li;
+    for (int j = 0; j < 5; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                rv[j][r] = (n < a.N && m < a.M) ? a.res[(size_t)m * a.ldo + n] : 0.f;
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    const int sw = (li >> 2) & 3;
+    const int offa = (wave * 32 + li) * 32, offb = 2 * 8192 + li * 32;       // element offsets inside a stage
+    const int ch0 = 8 * ((0 + lh) ^ sw), ch1 = 8 * ((2 + lh) ^ sw);
+
+    set_next();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) issue_one(csm, q);
+    if (nk > 1) {
+        set_next();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) issue_one(csm + CSTAGE_H, q);
+    }
+    for (int t = 0; t < nk; ++t) {
+        // K-step t has landed when only the newest K-step's instructions (8 for waves 0-1, 6 for the others) are still in flight
+        if (t + 1 < nk) { if (two_w) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const bool pf = t + 2 < nk;
+        if (pf) set_next();
+        uint16_t* nst = csm + ((t + 2) % 3) * CSTAGE_H;
+        const uint32_t sb = (uint32_t)(uintptr_t)(lds_ptr_t)(csm + (t % 3) * CSTAGE_H);
+        const uint32_t aa0 = sb + 2 * (offa + ch0), aa1 = sb + 2 * (offa + ch1), ab0 = sb + 2 * (offb + ch0), ab1 = sb + 2 * (offb + ch1);
+        f16x8 fa[2][2], fb[2][2][5];
+#define SDVAR_LDS_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr) : "memory")
+        // X plane p at +16384 p bytes; W plane p at +10240 p bytes (behind the X planes), column tile j at +2048 j
+#define SDVAR_RD_B(s, ab, p, pb) SDVAR_LDS_RD(fb[s][p][0], ab, pb); SDVAR_LDS_RD(fb[s][p][1], ab, pb + 2048); SDVAR_LDS_RD(fb[s][p][2], ab, pb + 4096); \
+                                 SDVAR_LDS_RD(fb[s][p][3], ab, pb + 6144); SDVAR_LDS_RD(fb[s][p][4], ab, pb + 8192)
+        SDVAR_LDS_RD(fa[0][0], aa0, 0); SDVAR_LDS_RD(fa[0][1], aa0, 16384);
+        SDVAR_RD_B(0, ab0, 0, 0); SDVAR_RD_B(0, ab0, 1, 10240);
+        SDVAR_LDS_RD(fa[1][0], aa1, 0); SDVAR_LDS_RD(fa[1][1], aa1, 16384);
+        SDVAR_RD_B(1, ab1, 0, 0); SDVAR_RD_B(1, ab1, 1, 10240);
+#undef SDVAR_RD_B
+#undef SDVAR_LDS_RD
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (s == 0) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s][1], fb[s][0][j], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s][0], fb[s][1][j], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s][0], fb[s][0][j], acc[j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (pf) {
+                    const int grp = 5 * s + j;      // 0..9: the 8 DMA slots of K-step t+2 behind the first eight MFMA groups
+                    if (grp < 8) issue_one(nst, grp);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        const int n = n0 + j * 32 + li;
-        if (n >= a.N) continue;
-        const float bv = (EPI != CEPI_PARTIAL && a.bias) ? a.bias[n] : 0.f;
-        float* outp = (EPI == CEPI_PARTIAL) ? a.out + (size_t)ks * a.M * a.ldo : a.out;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (m >= a.M) continue;
-            float v = acc[j][r] + bv;
-            if (EPI == CEPI_BIAS_RES) v += rv[j][r];
-            size_t orow = (size_t)m;
-            if (EPI != CEPI_PARTIAL && a.up_phase >= 0) {         // pixel (b, y, x) of the input grid -> (b, 2y + py, 2x + px) of the output grid
-                const int hw = a.ih * a.iw, b = m / hw, rem = m - b * hw, y = rem / a.iw, x = rem - y * a.iw;
-                orow = ((size_t)(b * 2 * a.ih + 2 * y + (phase >> 1)) * (2 * a.iw) + 2 * x + (phase & 1));
-            }
-            outp[orow * a.ldo + n] = v;
-            acc[j][r] = v;
-        }
-    }
-    // GroupNorm statistics of the tile just written (the next layer's norm): per column sum / sum of squares over the 256 rows
-    // (all of one image: the host enables this only when H W is a multiple of 256), reduced lane -> wave -> workgroup through
-    // LDS in a fixed order, then per group in fp64.  Saves a full read of the activation tensor per normalisation.
-    if (EPI != CEPI_PARTIAL && a.gn_part) {
-        float* red = reinterpret_cast<float*>(csm);          // [2][8][160]
-        __syncthreads();                                     // every wave is done with the operand stages
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            float s1 = 0.f, s2 = 0.f;
-            if (n0 + j * 32 + li < a.N) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { s1 += acc[j][r]; s2 += acc[j][r] * acc[j][r]; }
-            }
-            const auto w1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(s1), __float_as_uint(s1), false, false);
-            const auto w2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(s2), __float_as_uint(s2), false, false);
-            if (lh == 0) {
-                red[wave * 160 + j * 32 + li] = __uint_as_float(w1[0]) + __uint_as_float(w1[1]);
-                red[1280 + wave * 160 + j * 32 + li] = __uint_as_float(w2[0]) + __uint_as_float(w2[1]);
-            }
-        }
-        __syncthreads();
-        const int gl = tid, col0 = gl * a.cpg;
-        if (col0 < CBN && n0 + col0 < a.N) {
-            double a1 = 0.0, a2 = 0.0;
-            for (int w = 0; w < 8; ++w)
-                for (int c = 0; c < a.cpg; ++c) { a1 += (double)red[w * 160 + col0 + c]; a2 += (double)red[1280 + w * 160 + col0 + c]; }
-            double* o = a.gn_part + ((size_t)(a.up_phase >= 0 ? 4 * tm + phase : tm) * 32 + (n0 + col0) / a.cpg) * 2;
-            o[0] = a1; o[1] = a2;
-        }
-    }
+    conv_epilogue<EPI>(a, acc, a.wsi ? *a.wsi : 1.0f, m0, n0, tm, ks, phase, wave, li, lh, tid, csm);
 }
 
 // out = sum_s slab[s] + bias (+ res)
@@ -245,22 +375,33 @@ __global__ __launch_bounds__(256) void conv_reduce_kernel(const float* __restric
     }
 }
 
-// conv weight (Cout, Cin, taps) fp32 -> planes [3][taps Cin / 32][Cout][32], k = tap Cin + cin
-__global__ __launch_bounds__(256) void conv_weight_planes_kernel(const float* __restrict__ w, uint16_t* __restrict__ p, int Cout, int Cin, int taps, size_t ps) {
+// conv weight (Cout, Cin, taps) fp32 -> planes [3 | 2][taps Cin / 32][Cout][32], k = tap Cin + cin; pfmt 2: the two fp16 planes of w * (*scale)
+__global__ __launch_bounds__(256) void conv_weight_planes_kernel(const float* __restrict__ w, uint16_t* __restrict__ p, int Cout, int Cin, int taps, size_t ps, int pfmt,
+                                                                 const float* scale) {
     const int K = taps * Cin;
     const size_t total = (size_t)Cout * K;
+    const float sc = (pfmt == PLANES_F16X2 && scale) ? *scale : 1.0f;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int co = (int)(i / K), k = (int)(i % K), tap = k / Cin, ci = k - tap * Cin;
-        uint16_t p0, p1, p2;
-        split3(w[((size_t)co * Cin + ci) * taps + tap], p0, p1, p2);
+        const float v = w[((size_t)co * Cin + ci) * taps + tap];
         const size_t o = kb_index(co, k, Cout);
-        p[o] = p0; p[ps + o] = p1; p[2 * ps + o] = p2;
+        if (pfmt == PLANES_F16X2) {
+            uint16_t h, l;
+            split2h(v * sc, h, l);
+            p[o] = h; p[ps + o] = l;
+        } else {
+            uint16_t p0, p1, p2;
+            split3(v, p0, p1, p2);
+            p[o] = p0; p[ps + o] = p1; p[2 * ps + o] = p2;
+        }
     }
 }
 
-int conv_weight_planes(const float* w, uint16_t* planes, int Cout, int Cin, int taps, size_t plane_stride, hipStream_t stream) {
+// scale (pfmt 2): device {2^S, 2^-S, ..} from weight_scale_f16 (gemm_f16x2.hip) over the tensor(s) that share one launch; null = unscaled
+int conv_weight_planes(const float* w, uint16_t* planes, int Cout, int Cin, int taps, size_t plane_stride, int pfmt, const float* scale, hipStream_t stream) {
     SDVAR_CHECK_ARG(w && planes && Cout > 0 && Cin % 32 == 0 && (taps == 1 || taps == 4 || taps == 9), "conv_weight_planes: Cout=%d Cin=%d taps=%d", Cout, Cin, taps);
-    hipLaunchKernelGGL(conv_weight_planes_kernel, dim3(1024), dim3(256), 0, stream, w, planes, Cout, Cin, taps, plane_stride);
+    SDVAR_CHECK_ARG(pfmt == PLANES_BF16X3 || pfmt == PLANES_F16X2, "conv_weight_planes: plane format %d", pfmt);
+    hipLaunchKernelGGL(conv_weight_planes_kernel, dim3(1024), dim3(256), 0, stream, w, planes, Cout, Cin, taps, plane_stride, pfmt, scale);
     SDVAR_LAUNCH_CHECK();
     return SDVAR_OK;
 }
@@ -291,7 +432,7 @@ int upconv_weights(const float* w, float* weff, int Cout, int Cin, hipStream_t s
 }
 
 // split heuristic: fill the 256 CUs (one resident workgroup each) without leaving a mostly empty last round
-static int conv_choose_split(int M, int N, int nkt, size_t ws_floats) {
+static int conv_choose_split(int M, int N, int nkt, size_t ws_floats, double kstep_cycles) {
     const long tiles = (long)((M + CBM - 1) / CBM) * ((N + CBN - 1) / CBN);
     double best = 1e30; int bs = 1;
     for (int split = 1; split <= 16 && split <= nkt / 2; ++split) {
@@ -299,7 +440,7 @@ static int conv_choose_split(int M, int N, int nkt, size_t ws_floats) {
         const int kps = (nkt + split - 1) / split;
         if ((nkt + kps - 1) / kps != split) continue;
         const long rounds = (tiles * split + 255) / 256;
-        double cyc = (double)rounds * (kps * 2100.0 + 3000.0);               // 60 MFMAs per wave and K-step, 2 waves per SIMD + DMA/sync; prologue + epilogue
+        double cyc = (double)rounds * (kps * kstep_cycles + 3000.0);         // bf16x3: 60 MFMAs per wave and K-step, 2 waves per SIMD + DMA/sync (f16x2: 30); prologue + epilogue
         if (split > 1) cyc += 4000.0 + (double)(split + 2) * M * N * 4.0 / 4000.0;
         if (cyc < best) { best = cyc; bs = split; }
     }
@@ -311,8 +452,9 @@ static int conv_choose_split(int M, int N, int nkt, size_t ws_floats) {
 // of the nearest-2x up-sampled tensor, all four output phases in one launch, written into out[B 2H 2W][N].
 // gn_part (optional): receives the GroupNorm partial sums of the output, [B H W / 256][32][2] doubles, when the shape allows the fused
 // epilogue (no split-K, H W a multiple of 256, 32 groups that tile the 160-column workgroup tile); *gn_done tells whether it was written.
-int conv_bf16x3(const uint16_t* X, size_t xps, size_t x_rows, int x_row0, const uint16_t* W, size_t wps, const float* bias, const float* res, float* out,
-                int B, int H, int Wd, int N, int Cin, int taps, float* ws, size_t ws_floats, int force_split, double* gn_part, int* gn_done, int up_phase,
+// pfmt: PLANES_BF16X3 (six bf16 products) or PLANES_F16X2 (three fp16 products; wsi -> 2^-S of the weight scale, or null)
+int conv_planes(const uint16_t* X, size_t xps, size_t x_rows, int x_row0, const uint16_t* W, size_t wps, int pfmt, const float* wsi, const float* bias, const float* res,
+                float* out, int B, int H, int Wd, int N, int Cin, int taps, float* ws, size_t ws_floats, int force_split, double* gn_part, int* gn_done, int up_phase,
                 size_t w_phase_stride, hipStream_t stream) {
     if (gn_done) *gn_done = 0;
     const int M = B * H * Wd, w2 = Wd + 2;
@@ -322,10 +464,12 @@ int conv_bf16x3(const uint16_t* X, size_t xps, size_t x_rows, int x_row0, const 
     SDVAR_CHECK_ARG(B > 0 && H > 0 && Wd > 0 && x_row0 >= w2 + 1, "conv: guard rows %d < row pitch %d + 1", x_row0, w2);
     SDVAR_CHECK_ARG(x_rows >= (size_t)x_row0 + Mp + w2 + 1, "conv: plane rows %zu too few", x_rows);
     SDVAR_CHECK_ARG(((uintptr_t)X % 16) == 0 && ((uintptr_t)W % 16) == 0 && xps % 8 == 0 && wps % 8 == 0, "conv: planes must be 16-byte aligned");
-    ConvArgs a{X, W, xps, wps, x_rows, x_row0, bias, res, out, M, N, Cin / 32, taps, H, Wd, N, 1, taps * (Cin / 32), nullptr, 1, up_phase, w_phase_stride};
+    SDVAR_CHECK_ARG(pfmt == PLANES_BF16X3 || pfmt == PLANES_F16X2, "conv: plane format %d", pfmt);
+    const bool F16 = pfmt == PLANES_F16X2;
+    ConvArgs a{X, W, xps, wps, x_rows, x_row0, F16 ? wsi : nullptr, bias, res, out, M, N, Cin / 32, taps, H, Wd, N, 1, taps * (Cin / 32), nullptr, 1, up_phase, w_phase_stride};
     const int nkt = taps * (Cin / 32);
     const int tiles = ((M + CBM - 1) / CBM) * ((N + CBN - 1) / CBN);
-    int split = up_phase >= 0 ? 1 : force_split > 0 ? force_split : conv_choose_split(M, N, nkt, ws ? ws_floats : 0);
+    int split = up_phase >= 0 ? 1 : force_split > 0 ? force_split : conv_choose_split(M, N, nkt, ws ? ws_floats : 0, F16 ? 1200.0 : 2100.0);
     if (split > nkt) split = nkt;
     if (split > 1) {
         SDVAR_CHECK_ARG(ws && (size_t)split * M * N <= ws_floats && N % 4 == 0, "conv: split-K workspace too small");
@@ -333,13 +477,15 @@ int conv_bf16x3(const uint16_t* X, size_t xps, size_t x_rows, int x_row0, const 
         split = (nkt + kps - 1) / kps;
         a.k_per_split = kps; a.split = split;
     }
-    const size_t lds = 2 * (size_t)CSTAGE * sizeof(uint16_t);      // 156 KB
-    static LdsOptIn opt_in;
-    SDVAR_LDS_OPT_IN(opt_in, lds, (const void*)conv_bf16x3_kernel<CEPI_BIAS>, (const void*)conv_bf16x3_kernel<CEPI_BIAS_RES>, (const void*)conv_bf16x3_kernel<CEPI_PARTIAL>);
+    const size_t lds = F16 ? 3 * (size_t)CSTAGE_H * sizeof(uint16_t) : 2 * (size_t)CSTAGE * sizeof(uint16_t);      // 156 KB either way
+    static LdsOptIn opt_in, opt_in_h;
+    if (F16) SDVAR_LDS_OPT_IN(opt_in_h, lds, (const void*)conv_f16x2_kernel<CEPI_BIAS>, (const void*)conv_f16x2_kernel<CEPI_BIAS_RES>, (const void*)conv_f16x2_kernel<CEPI_PARTIAL>);
+    else SDVAR_LDS_OPT_IN(opt_in, lds, (const void*)conv_bf16x3_kernel<CEPI_BIAS>, (const void*)conv_bf16x3_kernel<CEPI_BIAS_RES>, (const void*)conv_bf16x3_kernel<CEPI_PARTIAL>);
     if (split > 1) {
         ConvArgs p = a;
         p.out = ws;
-        hipLaunchKernelGGL((conv_bf16x3_kernel<CEPI_PARTIAL>), dim3(tiles * split), dim3(512), lds, stream, p);
+        if (F16) hipLaunchKernelGGL((conv_f16x2_kernel<CEPI_PARTIAL>), dim3(tiles * split), dim3(512), lds, stream, p);
+        else hipLaunchKernelGGL((conv_bf16x3_kernel<CEPI_PARTIAL>), dim3(tiles * split), dim3(512), lds, stream, p);
         SDVAR_LAUNCH_CHECK();
         const size_t total = (size_t)M * (N / 4);
         const int rgrid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
@@ -348,7 +494,10 @@ int conv_bf16x3(const uint16_t* X, size_t xps, size_t x_rows, int x_row0, const 
         return SDVAR_OK;
     }
     if (gn_part && N % 32 == 0 && CBN % (N / 32) == 0 && (H * Wd) % CBM == 0) { a.gn_part = gn_part; a.cpg = N / 32; if (gn_done) *gn_done = 1; }
-    if (res) hipLaunchKernelGGL((conv_bf16x3_kernel<CEPI_BIAS_RES>), dim3(tiles), dim3(512), lds, stream, a);
+    if (F16) {
+        if (res) hipLaunchKernelGGL((conv_f16x2_kernel<CEPI_BIAS_RES>), dim3(tiles), dim3(512), lds, stream, a);
+        else hipLaunchKernelGGL((conv_f16x2_kernel<CEPI_BIAS>), dim3(tiles, up_phase >= 0 ? 4 : 1), dim3(512), lds, stream, a);
+    } else if (res) hipLaunchKernelGGL((conv_bf16x3_kernel<CEPI_BIAS_RES>), dim3(tiles), dim3(512), lds, stream, a);
     else hipLaunchKernelGGL((conv_bf16x3_kernel<CEPI_BIAS>), dim3(tiles, up_phase >= 0 ? 4 : 1), dim3(512), lds, stream, a);
     SDVAR_LAUNCH_CHECK();
     return SDVAR_OK;

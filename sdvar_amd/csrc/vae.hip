@@ -18,9 +18,11 @@
 
 namespace sdvar {
 
-int conv_weight_planes(const float* w, uint16_t* planes, int Cout, int Cin, int taps, size_t plane_stride, hipStream_t stream);
-int conv_bf16x3(const uint16_t* X, size_t xps, size_t x_rows, int x_row0, const uint16_t* W, size_t wps, const float* bias, const float* res, float* out,
-                int B, int H, int Wd, int N, int Cin, int taps, float* ws, size_t ws_floats, int force_split, double* gn_part, int* gn_done, int up_phase, size_t w_phase_stride, hipStream_t stream);
+int conv_weight_planes(const float* w, uint16_t* planes, int Cout, int Cin, int taps, size_t plane_stride, int pfmt, const float* scale, hipStream_t stream);
+int weight_scale_f16(const float* w, size_t n, float* sc, hipStream_t stream);
+int conv_planes(const uint16_t* X, size_t xps, size_t x_rows, int x_row0, const uint16_t* W, size_t wps, int pfmt, const float* wsi, const float* bias, const float* res,
+                float* out, int B, int H, int Wd, int N, int Cin, int taps, float* ws, size_t ws_floats, int force_split, double* gn_part, int* gn_done, int up_phase,
+                size_t w_phase_stride, hipStream_t stream);
 int upconv_weights(const float* w, float* weff, int Cout, int Cin, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------------- layout helpers
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
 // Ho = Hi << up.  mode bit 0: GroupNorm (stats, gamma, beta); bit 1: SiLU.  Thread = (output row incl. guards, 8 channels).
 __global__ __launch_bounds__(256) void prep_planes_kernel(const float* __restrict__ in, const float* __restrict__ stats, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, uint16_t* __restrict__ outp, size_t ops, int B, int C, int Hi, int Wi,
-                                                          int up, int mode, int G) {
+                                                          int up, int mode, int G, int pfmt) {
     const int Ho = Hi << up, Wo = Wi << up, w2o = Wo + 2, h2o = Ho + 2;
     const size_t Mo = (size_t)B * h2o * w2o, R = Mo + 2 * (size_t)G;
     const int c8n = C >> 3, cpg = C / 32;
@@ -116,8 +118,20 @@ __global__ __launch_bounds__(256) void prep_planes_kernel(const float* __restric
             }
         }
         u32x4 a = {0, 0, 0, 0}, bq = {0, 0, 0, 0}, cq = {0, 0, 0, 0};
-        if (live) split8_packed(v, a, bq, cq);
         const size_t o = ((size_t)(c8 >> 2) * R + r) * 32 + 8 * (c8 & 3);
+        if (pfmt == PLANES_F16X2) {          // two fp16 planes (gemm_f16x2.hip): h = fp16(v), l = fp16(v - h)
+            if (live) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    uint16_t h0, l0, h1, l1;
+                    split2h(v[2 * e], h0, l0); split2h(v[2 * e + 1], h1, l1);
+                    a[e] = (uint32_t)h0 | ((uint32_t)h1 << 16); bq[e] = (uint32_t)l0 | ((uint32_t)l1 << 16);
+                }
+            }
+            *reinterpret_cast<u32x4*>(outp + o) = a; *reinterpret_cast<u32x4*>(outp + ops + o) = bq;
+            continue;
+        }
+        if (live) split8_packed(v, a, bq, cq);
         *reinterpret_cast<u32x4*>(outp + o) = a; *reinterpret_cast<u32x4*>(outp + ops + o) = bq; *reinterpret_cast<u32x4*>(outp + 2 * ops + o) = cq;
     }
 }
@@ -312,7 +326,8 @@ int vmalloc(T** p, size_t n) {
 }
 #define VAE_TRY(call) do { int rc_ = (call); if (rc_ != SDVAR_OK) return rc_; } while (0)
 
-struct ConvW { uint16_t* wp = nullptr; size_t wps = 0; const float* bias = nullptr; int cin = 0, cout = 0, taps = 0; };   // taps = 4: four phase weight sets, 3 wps apart
+struct ConvW { uint16_t* wp = nullptr; size_t wps = 0; const float* bias = nullptr; int cin = 0, cout = 0, taps = 0;   // taps = 4: four phase weight sets, NPL wps apart
+               float* wsc = nullptr; };                                          // f16x2: device {2^S, 2^-S, scratch, -}, the weight scale of the launch
 struct NormW { const float* gamma = nullptr; const float* beta = nullptr; int C = 0; };
 struct ResW { NormW n1, n2; ConvW c1, c2, sc; bool has_sc = false; };
 struct AttnW { NormW n; ConvW qkv, proj; };
@@ -333,6 +348,7 @@ struct sdvar_vae {
     double* part = nullptr;
     uint16_t *p1 = nullptr, *p2 = nullptr;
     size_t f_floats = 0, p1_elems = 0, p2_elems = 0, ws_floats = 0;
+    int pfmt = PLANES_F16X2, npl = 2;     // operand plane format of the convolutions (desc.plane_format: 0 / 2 = f16x2, 3 = bf16x3)
     std::vector<void*> owned;
 };
 
@@ -351,8 +367,10 @@ int sdvar_vae_create(const sdvar_vae_desc* desc, sdvar_vae_t** out) {
         const int c = desc->ch * desc->ch_mult[i];
         SDVAR_CHECK_ARG(c <= 640 * 2 && 320 % (c / 4) == 0, "vae_create: width %d unsupported by the GroupNorm kernel ((C/4) must divide 320)", c);
     }
+    SDVAR_CHECK_ARG(desc->plane_format == 0 || desc->plane_format == PLANES_F16X2 || desc->plane_format == PLANES_BF16X3, "vae_create: plane_format %d (0 / 2 = f16x2, 3 = bf16x3)", desc->plane_format);
     sdvar_vae* v = new sdvar_vae();
     v->d = *desc; v->nlev = desc->n_mult; v->H0 = desc->latent_hw;
+    v->pfmt = desc->plane_format == PLANES_BF16X3 ? PLANES_BF16X3 : PLANES_F16X2; v->npl = v->pfmt == PLANES_BF16X3 ? 3 : 2;
     const int B = desc->max_batch;
     // largest fp32 activation / plane tensors over the levels (level lv runs at H0 << (nlev-1-lv) with width ch*mult[lv]; the
     // first block of a level and the up-sampling conv see the previous level's width)
@@ -367,7 +385,7 @@ int sdvar_vae_create(const sdvar_vae_desc* desc, sdvar_vae_t** out) {
         if (plane_rows(B, H, H) * cm > pmax) pmax = plane_rows(B, H, H) * cm;
         cprev = c;
     }
-    v->f_floats = fmax_; v->p1_elems = 3 * pmax; v->p2_elems = 3 * pmax;
+    v->f_floats = fmax_; v->p1_elems = v->npl * pmax; v->p2_elems = v->npl * pmax;
     v->ws_floats = (size_t)64 << 20;
     const int Hl = v->H0 << (desc->n_mult - 1);
     if (vmalloc(&v->fa, v->f_floats) || vmalloc(&v->fb, v->f_floats) || vmalloc(&v->fc, v->f_floats) || vmalloc(&v->p1, v->p1_elems) ||
@@ -396,16 +414,23 @@ namespace {
 struct Binder {
     sdvar_vae* v; const float* const* t; int n, pos; hipStream_t s; int rc;
     const float* next() { if (pos >= n) { rc = SDVAR_ERR_ARG; return nullptr; } return t[pos++]; }
+    int scale_of(ConvW& c, const float* w, size_t n) {          // f16x2: the power-of-two scale of this launch's weights, computed on the device
+        if (v->pfmt != PLANES_F16X2) return SDVAR_OK;
+        if (hipMalloc((void**)&c.wsc, 4 * sizeof(float)) != hipSuccess) return SDVAR_ERR_HIP;
+        v->owned.push_back(c.wsc);
+        return weight_scale_f16(w, n, c.wsc, s);
+    }
     void conv(ConvW& c, int cin, int cout, int taps) {
         const float* w = next(); const float* b = next();
         if (rc || !w || !b) { rc = SDVAR_ERR_ARG; return; }
         c.cin = cin; c.cout = cout; c.taps = taps; c.bias = b;
         c.wps = (size_t)taps * cin * cout;
         uint16_t* p = nullptr;
-        if (hipMalloc((void**)&p, 3 * c.wps * sizeof(uint16_t)) != hipSuccess) { rc = SDVAR_ERR_HIP; return; }
+        if (hipMalloc((void**)&p, v->npl * c.wps * sizeof(uint16_t)) != hipSuccess) { rc = SDVAR_ERR_HIP; return; }
         v->owned.push_back(p);
         c.wp = p;
-        const int r = conv_weight_planes(w, p, cout, cin, taps, c.wps, s);
+        int r = scale_of(c, w, c.wps);
+        if (!r) r = conv_weight_planes(w, p, cout, cin, taps, c.wps, v->pfmt, c.wsc, s);
         if (r) rc = r;
     }
     void upconv(ConvW& c, ConvW& c9, int ch) {          // Upsample2x conv: four 2x2 phase convolutions (conv.hip upconv_weights) + the plain 3x3 form
@@ -417,11 +442,12 @@ struct Binder {
         c.cin = ch; c.cout = ch; c.taps = 4; c.bias = b;
         c.wps = (size_t)4 * ch * ch;
         uint16_t* p = nullptr; float* weff = nullptr;
-        if (hipMalloc((void**)&p, 4 * 3 * c.wps * sizeof(uint16_t)) != hipSuccess || hipMalloc((void**)&weff, 4 * c.wps * sizeof(float)) != hipSuccess) { rc = SDVAR_ERR_HIP; return; }
+        if (hipMalloc((void**)&p, 4 * v->npl * c.wps * sizeof(uint16_t)) != hipSuccess || hipMalloc((void**)&weff, 4 * c.wps * sizeof(float)) != hipSuccess) { rc = SDVAR_ERR_HIP; return; }
         v->owned.push_back(p); v->owned.push_back(weff);
         c.wp = p;
         int r = upconv_weights(w, weff, ch, ch, s);
-        for (int ph = 0; ph < 4 && !r; ++ph) r = conv_weight_planes(weff + ph * c.wps, p + (size_t)ph * 3 * c.wps, ch, ch, 4, c.wps, s);
+        if (!r) r = scale_of(c, weff, 4 * c.wps);                  // the four phase kernels run in one launch: one scale
+        for (int ph = 0; ph < 4 && !r; ++ph) r = conv_weight_planes(weff + ph * c.wps, p + (size_t)ph * v->npl * c.wps, ch, ch, 4, c.wps, v->pfmt, c.wsc, s);
         if (r) rc = r;
     }
     void norm(NormW& nw, int C) { nw.gamma = next(); nw.beta = next(); nw.C = C; if (!nw.gamma || !nw.beta) rc = SDVAR_ERR_ARG; }
@@ -521,19 +547,20 @@ struct Runner {
     int prep(const float* src, int C, const NormW* nw, int silu, int up, uint16_t* dst, size_t dst_elems, size_t* ops, size_t* rows, int* G) {
         const int Ho = H << up;
         *G = guard_rows(Ho); *rows = plane_rows(B, Ho, Ho); *ops = *rows * (size_t)C;
-        SDVAR_CHECK_ARG(3 * *ops <= dst_elems, "vae: plane buffer too small");
+        SDVAR_CHECK_ARG(v->npl * *ops <= dst_elems, "vae: plane buffer too small");
         if (nw) VAE_TRY(stats_of(src, C));
         const size_t total = *rows * (C / 8);
         const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
         hipLaunchKernelGGL(prep_planes_kernel, dim3(grid), dim3(256), 0, s, src, v->stats, nw ? nw->gamma : nullptr, nw ? nw->beta : nullptr, dst, *ops, B, C, H, H,
-                           up, (nw ? 1 : 0) | (silu ? 2 : 0), *G);
+                           up, (nw ? 1 : 0) | (silu ? 2 : 0), *G, v->pfmt);
         SDVAR_LAUNCH_CHECK();
         return SDVAR_OK;
     }
     int conv(const ConvW& c, const uint16_t* xp, size_t ops, size_t rows, int G, const float* res, float* out) {
         SDVAR_CHECK_ARG(M() * c.cout <= v->f_floats, "vae: activation buffer too small");
         int done = 0;
-        VAE_TRY(conv_bf16x3(xp, ops, rows, G, c.wp, c.wps, c.bias, res, out, B, H, H, c.cout, c.cin, c.taps, v->ws, v->ws_floats, 0, v->part, &done, -1, 0, s));
+        VAE_TRY(conv_planes(xp, ops, rows, G, c.wp, c.wps, v->pfmt, c.wsc ? c.wsc + 1 : nullptr, c.bias, res, out, B, H, H, c.cout, c.cin, c.taps, v->ws, v->ws_floats, 0,
+                            v->part, &done, -1, 0, s));
         stats_src = done ? out : nullptr; stats_chunks = H * H / 256;
         return SDVAR_OK;
     }
@@ -603,8 +630,8 @@ int sdvar_vae_decode(sdvar_vae_t* v, const float* f_hat, int32_t B, float* img, 
                 VAE_TRY(r.prep(r.x, L.up.cin, nullptr, 0, 0, v->p1, v->p1_elems, &ops, &rows, &G));
                 SDVAR_CHECK_ARG(4 * r.M() * L.up.cout <= v->f_floats, "vae: activation buffer too small");
                 int done = 0;
-                VAE_TRY(conv_bf16x3(v->p1, ops, rows, G, L.up.wp, L.up.wps, L.up.bias, nullptr, r.h, B, r.H, r.H, L.up.cout, L.up.cin, 4, nullptr, 0, 0, v->part, &done, 0,
-                                    3 * L.up.wps, s));
+                VAE_TRY(conv_planes(v->p1, ops, rows, G, L.up.wp, L.up.wps, v->pfmt, L.up.wsc ? L.up.wsc + 1 : nullptr, L.up.bias, nullptr, r.h, B, r.H, r.H, L.up.cout,
+                                    L.up.cin, 4, nullptr, 0, 0, v->part, &done, 0, v->npl * L.up.wps, s));
                 r.stats_src = done ? r.h : nullptr; r.stats_chunks = 4 * (r.H * r.H / 256);
                 r.H <<= 1;
             } else {                                                                       // too few tiles: 3x3 on the up-sampled planes, split along K
@@ -627,24 +654,27 @@ int sdvar_vae_decode(sdvar_vae_t* v, const float* f_hat, int32_t B, float* img, 
     return SDVAR_OK;
 }
 
+#define SDVAR_TRY_(call) do { int rc_ = (call); if (rc_ != SDVAR_OK) return rc_; } while (0)
 /* single operators for the parity tests */
-int sdvar_op_conv_weight_planes(const float* w, uint16_t* planes, int32_t Cout, int32_t Cin, int32_t taps, uint64_t plane_stride, void* stream) {
-    return conv_weight_planes(w, planes, Cout, Cin, taps, (size_t)plane_stride, (hipStream_t)stream);
+int sdvar_op_conv_weight_planes(const float* w, uint16_t* planes, int32_t Cout, int32_t Cin, int32_t taps, uint64_t plane_stride, int32_t plane_format, float* scale,
+                                void* stream) {
+    if (plane_format == PLANES_F16X2 && scale) SDVAR_TRY_(weight_scale_f16(w, (size_t)Cout * Cin * taps, scale, (hipStream_t)stream));
+    return conv_weight_planes(w, planes, Cout, Cin, taps, (size_t)plane_stride, plane_format, scale, (hipStream_t)stream);
 }
-int sdvar_op_vae_prep(const float* in, const float* stats, const float* gamma, const float* beta, uint16_t* planes, uint64_t plane_stride, int32_t B, int32_t C,
-                      int32_t H, int32_t W, int32_t up, int32_t mode, int32_t guard, void* stream) {
+int sdvar_op_vae_prep(const float* in, const float* stats, const float* gamma, const float* beta, uint16_t* planes, uint64_t plane_stride, int32_t plane_format, int32_t B,
+                      int32_t C, int32_t H, int32_t W, int32_t up, int32_t mode, int32_t guard, void* stream) {
     SDVAR_CHECK_ARG(in && planes && C % 32 == 0 && (!(mode & 1) || (stats && gamma && beta)), "vae_prep: bad arguments");
     const size_t rows = (size_t)B * ((H << up) + 2) * ((W << up) + 2) + 2 * (size_t)guard, total = rows * (C / 8);
     hipLaunchKernelGGL(prep_planes_kernel, dim3((unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192)), dim3(256), 0, (hipStream_t)stream, in, stats, gamma,
-                       beta, planes, (size_t)plane_stride, B, C, H, W, up, mode, guard);
+                       beta, planes, (size_t)plane_stride, B, C, H, W, up, mode, guard, plane_format);
     SDVAR_LAUNCH_CHECK();
     return SDVAR_OK;
 }
-int sdvar_op_conv_bf16x3(const uint16_t* x_planes, uint64_t x_plane_stride, uint64_t x_rows, int32_t x_row0, const uint16_t* w_planes, uint64_t w_plane_stride,
-                         const float* bias, const float* res, float* out, int32_t B, int32_t H, int32_t W, int32_t N, int32_t Cin, int32_t taps, float* workspace,
-                         uint64_t workspace_floats, int32_t force_split, void* stream) {
-    return conv_bf16x3(x_planes, (size_t)x_plane_stride, (size_t)x_rows, x_row0, w_planes, (size_t)w_plane_stride, bias, res, out, B, H, W, N, Cin, taps, workspace,
-                       (size_t)workspace_floats, force_split, nullptr, nullptr, -1, 0, (hipStream_t)stream);
+int sdvar_op_conv_planes(const uint16_t* x_planes, uint64_t x_plane_stride, uint64_t x_rows, int32_t x_row0, const uint16_t* w_planes, uint64_t w_plane_stride,
+                         int32_t plane_format, const float* w_scale, const float* bias, const float* res, float* out, int32_t B, int32_t H, int32_t W, int32_t N, int32_t Cin,
+                         int32_t taps, float* workspace, uint64_t workspace_floats, int32_t force_split, void* stream) {
+    return conv_planes(x_planes, (size_t)x_plane_stride, (size_t)x_rows, x_row0, w_planes, (size_t)w_plane_stride, plane_format, w_scale ? w_scale + 1 : nullptr, bias, res, out,
+                       B, H, W, N, Cin, taps, workspace, (size_t)workspace_floats, force_split, nullptr, nullptr, -1, 0, (hipStream_t)stream);
 }
 
 }  // extern "C"

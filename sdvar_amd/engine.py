@@ -46,7 +46,7 @@ class _ModelDesc(C.Structure):
 
 class _VaeDesc(C.Structure):
     _fields_ = [("ch", C.c_int32), ("z_channels", C.c_int32), ("n_mult", C.c_int32), ("ch_mult", C.c_int32 * 8), ("num_res_blocks", C.c_int32),
-                ("max_batch", C.c_int32), ("latent_hw", C.c_int32)]
+                ("max_batch", C.c_int32), ("latent_hw", C.c_int32), ("plane_format", C.c_int32)]
 
 
 _P, _I, _D, _U64, _U32 = C.c_void_p, C.c_int32, C.c_double, C.c_uint64, C.c_uint32
@@ -92,9 +92,9 @@ _SIGNATURES = {
     "sdvar_op_gemm_bf16x3": (_I, [_P, _U64, _P, _U64, _P, _P, _I, _P, _U64, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P]),
     "sdvar_op_qk_norm_append": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "sdvar_op_attention": (_I, [_P, _P, _P, _I, _P, _P, _U64, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), _P]),
-    "sdvar_op_conv_weight_planes": (_I, [_P, _P, _I, _I, _I, _U64, _P]),
-    "sdvar_op_vae_prep": (_I, [_P, _P, _P, _P, _P, _U64, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "sdvar_op_conv_bf16x3": (_I, [_P, _U64, _U64, _I, _P, _U64, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _U64, _I, _P]),
+    "sdvar_op_conv_weight_planes": (_I, [_P, _P, _I, _I, _I, _U64, _I, _P, _P]),
+    "sdvar_op_vae_prep": (_I, [_P, _P, _P, _P, _P, _U64, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "sdvar_op_conv_planes": (_I, [_P, _U64, _U64, _I, _P, _U64, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _U64, _I, _P]),
     "sdvar_op_noise_fill": (_I, [_P, _I, _I, _I, _U64, _U32, _U32, _P]),
     "sdvar_debug_set_gemm_cfg": (_I, [_I, _I]),
     "sdvar_debug_set_gemm_stamps": (_I, [_P]),
@@ -295,13 +295,17 @@ class VaeCtx:
     """sdvar_vae_t from the VQVAE state_dict: `fhat_to_img` (vqvae.py:62-63) as hand-written HIP (csrc/conv.hip, csrc/vae.hip)."""
 
     def __init__(self, vae_sd: Dict[str, torch.Tensor], max_batch: int, device, latent_hw: int = 16, ch: Optional[int] = None,
-                 ch_mult: Sequence[int] = (1, 1, 2, 2, 4), num_res_blocks: int = 2):
+                 ch_mult: Sequence[int] = (1, 1, 2, 2, 4), num_res_blocks: int = 2, conv_mode: Optional[str] = None):
         self.lib = load_library()
         self.device = torch.device(device)
         z = vae_sd["post_quant_conv.weight"].shape[0]
         ch = ch if ch is not None else vae_sd["decoder.norm_out.weight"].shape[0] // ch_mult[0]
         d = _VaeDesc()
         d.ch, d.z_channels, d.n_mult, d.num_res_blocks, d.max_batch, d.latent_hw = ch, z, len(ch_mult), num_res_blocks, max_batch, latent_hw
+        self.conv_mode = conv_mode or os.environ.get("SDVAR_CONV_MODE", DEFAULT_GEMM_MODE if DEFAULT_GEMM_MODE != "f32" else "f16x2")   # operands of the convolutions
+        if self.conv_mode not in ("bf16x3", "f16x2"):
+            raise SdvarError(f"conv_mode {self.conv_mode!r}: expected 'bf16x3' or 'f16x2'")
+        d.plane_format = 3 if self.conv_mode == "bf16x3" else 2
         for i, m in enumerate(ch_mult):
             d.ch_mult[i] = m
         self.desc, self.max_batch, self.latent_hw, self.z = d, max_batch, latent_hw, z

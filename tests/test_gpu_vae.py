@@ -44,10 +44,21 @@ def _guard(W):
     return (W + 3 + 15) // 16 * 16
 
 
+def _unplanes_any(xp, pf):
+    """operand planes (3 bf16 | 2 fp16, ...) -> fp64 values"""
+    if pf == 3:
+        return sum((xp[k].to(torch.int32) << 16).view(torch.float32).double() for k in range(3))
+    return sum(xp[k].view(torch.float16).double() for k in range(2))
+
+
+PFMTS = [3, 2]          # bf16x3 and f16x2 operand planes
+
+
+@pytest.mark.parametrize("pf", PFMTS)
 @pytest.mark.parametrize("B,Cin,Cout,H,taps,res,split", [(2, 64, 96, 8, 9, False, 0), (1, 32, 32, 16, 9, False, 0), (2, 160, 160, 12, 9, True, 0),
                                                          (2, 320, 160, 6, 1, False, 0), (2, 128, 320, 5, 9, True, 3), (1, 640, 1920, 4, 1, False, 4),
-                                                         (3, 96, 40, 7, 9, False, 2)])
-def test_conv_matches_torch(dev, B, Cin, Cout, H, taps, res, split):
+                                                         (3, 96, 40, 7, 9, False, 2), (2, 32, 64, 9, 1, False, 0), (2, 64, 64, 9, 1, False, 0)])
+def test_conv_matches_torch(dev, B, Cin, Cout, H, taps, res, split, pf):
     lib = E.load_library()
     W = H + 1                                                                  # non-square on purpose
     x = rnd(1, (B, Cin, H, W)).to(dev)
@@ -55,15 +66,16 @@ def test_conv_matches_torch(dev, B, Cin, Cout, H, taps, res, split):
     w = (rnd(2, (Cout, Cin, k, k)) / (Cin * taps) ** 0.5).to(dev); b = rnd(3, (Cout,), 0.1).to(dev)
     r = rnd(4, (B, Cout, H, W)).to(dev) if res else None
     G = _guard(W); M = B * H * W; R = B * (H + 2) * (W + 2) + 2 * G
-    xp = torch.full((3, Cin // 32, R, 32), 0x7FC0, dtype=torch.int16, device=dev)          # NaN patterns: every row must be written
-    E._check(lib.sdvar_op_vae_prep(_p(_rows(x)), None, None, None, _p(xp), (Cin // 32) * R * 32, B, Cin, H, W, 0, 0, G, _st()))
-    wp = torch.zeros(3, taps * Cin // 32, Cout, 32, dtype=torch.int16, device=dev)
-    E._check(lib.sdvar_op_conv_weight_planes(_p(w), _p(wp), Cout, Cin, taps, taps * Cin * Cout, _st()))
+    xp = torch.full((pf, Cin // 32, R, 32), 0x7FC0 if pf == 3 else 0x7E00, dtype=torch.int16, device=dev)          # NaN patterns: every row must be written
+    E._check(lib.sdvar_op_vae_prep(_p(_rows(x)), None, None, None, _p(xp), (Cin // 32) * R * 32, pf, B, Cin, H, W, 0, 0, G, _st()))
+    wp = torch.zeros(pf, taps * Cin // 32, Cout, 32, dtype=torch.int16, device=dev)
+    wsc = torch.zeros(4, device=dev)
+    E._check(lib.sdvar_op_conv_weight_planes(_p(w), _p(wp), Cout, Cin, taps, taps * Cin * Cout, pf, _p(wsc), _st()))
     out = torch.empty(M, Cout, device=dev)
     ws = torch.empty(max(split, 1) * M * Cout, device=dev)
     rr = _rows(r) if res else None
-    E._check(lib.sdvar_op_conv_bf16x3(_p(xp), (Cin // 32) * R * 32, R, G, _p(wp), taps * Cin * Cout, _p(b), _p(rr), _p(out), B, H, W, Cout, Cin, taps,
-                                      _p(ws), ws.numel(), split, _st()))
+    E._check(lib.sdvar_op_conv_planes(_p(xp), (Cin // 32) * R * 32, R, G, _p(wp), taps * Cin * Cout, pf, _p(wsc) if pf == 2 else None, _p(b), _p(rr), _p(out), B, H, W,
+                                      Cout, Cin, taps, _p(ws), ws.numel(), split, _st()))
     want = F.conv2d(x.double(), w.double(), b.double(), padding=k // 2) + (r.double() if res else 0)
     got = _unrows(out, B, H, W).double()
     assert torch.isfinite(out).all()
@@ -71,8 +83,9 @@ def test_conv_matches_torch(dev, B, Cin, Cout, H, taps, res, split):
     assert err <= 2e-5, err
 
 
+@pytest.mark.parametrize("pf", PFMTS)
 @pytest.mark.parametrize("up,mode", [(0, 0), (0, 3), (1, 0), (0, 1)])
-def test_prep_groupnorm_silu_upsample(dev, up, mode):
+def test_prep_groupnorm_silu_upsample(dev, up, mode, pf):
     lib = E.load_library()
     B, Cc, H, W = 2, 64, 6, 5
     x = rnd(5, (B, Cc, H, W), 2.0).to(dev)
@@ -82,9 +95,9 @@ def test_prep_groupnorm_silu_upsample(dev, up, mode):
     stats = torch.stack([mean, 1 / torch.sqrt(var + 1e-6)], -1).float().contiguous()
     Ho, Wo = H << up, W << up
     G = _guard(Wo); M = B * (Ho + 2) * (Wo + 2); R = M + 2 * G
-    xp = torch.full((3, Cc // 32, R, 32), 0x7FC0, dtype=torch.int16, device=dev)
-    E._check(lib.sdvar_op_vae_prep(_p(_rows(x)), _p(stats), _p(gamma), _p(beta), _p(xp), (Cc // 32) * R * 32, B, Cc, H, W, up, mode, G, _st()))
-    v = sum((xp[k].to(torch.int32) << 16).view(torch.float32).double() for k in range(3))   # (C/32, R, 32)
+    xp = torch.full((pf, Cc // 32, R, 32), 0x7FC0 if pf == 3 else 0x7E00, dtype=torch.int16, device=dev)
+    E._check(lib.sdvar_op_vae_prep(_p(_rows(x)), _p(stats), _p(gamma), _p(beta), _p(xp), (Cc // 32) * R * 32, pf, B, Cc, H, W, up, mode, G, _st()))
+    v = _unplanes_any(xp, pf)   # (C/32, R, 32)
     v = v.permute(1, 0, 2).reshape(R, Cc)
     assert v[:G].abs().max().item() == 0 and v[G + M:].abs().max().item() == 0              # guards
     full = v[G:G + M].view(B, Ho + 2, Wo + 2, Cc)
@@ -97,22 +110,23 @@ def test_prep_groupnorm_silu_upsample(dev, up, mode):
     if up:
         want = F.interpolate(want, scale_factor=2, mode="nearest")
     got = full[:, 1:-1, 1:-1].permute(0, 3, 1, 2)
-    assert (got - want.double()).abs().max().item() <= (2e-6 if mode else 0.0)
+    assert (got - want.double()).abs().max().item() <= (2e-6 if (mode or pf == 2) else 0.0)       # bf16x3 planes are exact, f16x2 planes hold 2^-22
 
 
-def _decode_pair(dev, ch, B, latent=16, seed=11):
+def _decode_pair(dev, ch, B, latent=16, seed=11, conv_mode=None):
     pns = (1, 2, 3, 4, 5, 6, 8, 10, 13, 16)
     sd = vae_state_dict(pns, "stress", seed, V=64, Cvae=32, ch=ch, with_encoder=False)
     vae = VQVAE(vocab_size=64, z_channels=32, ch=ch, v_patch_nums=pns, with_encoder=False)
     vae.load_state_dict(sd)
     vae = vae.to(dev)
-    ctx = E.VaeCtx(sd, B, dev, latent_hw=latent)
+    ctx = E.VaeCtx(sd, B, dev, latent_hw=latent, conv_mode=conv_mode)
     f_hat = rnd(seed + 1, (B, 32, latent, latent), 1.5).to(dev)
     return vae, ctx, f_hat
 
 
-def test_decoder_small_width_matches_pytorch(dev):
-    vae, ctx, f_hat = _decode_pair(dev, 32, 3)
+@pytest.mark.parametrize("cm", ["bf16x3", "f16x2"])
+def test_decoder_small_width_matches_pytorch(dev, cm):
+    vae, ctx, f_hat = _decode_pair(dev, 32, 3, conv_mode=cm)
     got = ctx.decode(f_hat)
     want = vae.fhat_to_img_torch(f_hat.clone())
     assert got.shape == want.shape == (3, 3, 256, 256)
@@ -123,9 +137,10 @@ def test_decoder_small_width_matches_pytorch(dev):
     assert (sub - got[:1]).abs().max().item() <= 2e-5
 
 
-def test_decoder_reference_width_matches_pytorch(dev):
+@pytest.mark.parametrize("cm", ["bf16x3", "f16x2"])
+def test_decoder_reference_width_matches_pytorch(dev, cm):
     """vae_ch160v4096z32 geometry (the checkpoint the reference loads): ch = 160, widths 640/320/160, 256^2 output."""
-    vae, ctx, f_hat = _decode_pair(dev, 160, 2)
+    vae, ctx, f_hat = _decode_pair(dev, 160, 2, conv_mode=cm)
     got = ctx.decode(f_hat)
     want = vae.fhat_to_img_torch(f_hat.clone())
     err = (got - want).abs().max().item()
