@@ -187,8 +187,12 @@ int sdvar_model_create(const sdvar_model_desc* desc, sdvar_model_t** out) {
     }
     m->L = c;
     // the split-operand GEMM mode keeps an fp32 cache as exact bf16 planes so that attention runs on the bf16 matrix cores too
-    m->kv_fmt = (desc->kv_dtype == 0 && desc->gemm_mode >= 1 && !getenv("SDVAR_ATTN_F32")) ? 2 : desc->kv_dtype;   // env: A/B runs only
-    m->Lkv = (m->kv_fmt == 2) ? (c + 63) / 64 * 64 : c;
+    // cache format handed to the kernels: the split-operand GEMM modes keep an fp32 cache as operand planes of the matching matrix-core
+    // format (2: three bf16 planes, 3: two fp16 planes) so that attention runs on the matrix cores too; the fp16 cache of config P4 is ONE
+    // fp16 plane (4) in the same layout.  SDVAR_ATTN_F32 (A/B runs only) keeps the plain layouts and the fp32-MFMA kernel.
+    const bool planes_ok = desc->gemm_mode >= 1 && !getenv("SDVAR_ATTN_F32");
+    m->kv_fmt = !planes_ok ? desc->kv_dtype : desc->kv_dtype == 1 ? 4 : (desc->gemm_mode == 2 && !getenv("SDVAR_ATTN_BF16X3")) ? 3 : 2;
+    m->Lkv = (m->kv_fmt >= 2) ? (c + 63) / 64 * 64 : c;
     // the largest chunk is a window of max_chunk_stages consecutive stages; stage lengths are non-decreasing
     m->lmax = 0;
     for (int s = 0; s < m->S; ++s) {
@@ -233,7 +237,7 @@ int sdvar_model_create(const sdvar_model_desc* desc, sdvar_model_t** out) {
             if (desc->gemm_mode == 2) SDVAR_TRY(dmalloc(&b.wsc, (size_t)16));
         }
         SDVAR_TRY(dmalloc(&b.qkv_bias, 3 * C));
-        const size_t kvb = R * (size_t)m->H * m->Lkv * 64 * (m->kv_fmt == 2 ? 6 : m->kv_fmt == 1 ? 2 : 4);
+        const size_t kvb = R * (size_t)m->H * m->Lkv * 64 * (m->kv_fmt == 2 ? 6 : (m->kv_fmt == 1 || m->kv_fmt == 4) ? 2 : 4);
         SDVAR_HIP(hipMalloc(&b.kc, kvb));
         SDVAR_HIP(hipMalloc(&b.vc, kvb));
         SDVAR_HIP(hipMemset(b.kc, 0, kvb));        // the planes kernel streams whole 64-key tiles: rows past kv_len must be finite

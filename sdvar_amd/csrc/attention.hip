@@ -248,10 +248,14 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(AttnArgs a) {
 int attention_bf16x3(const float* q, const void* kc, const void* vc, float* out, uint16_t* outp, size_t ops, int pfmt, int R, int H, int l, int Lp,
                      int Ktot, int n_chunk, const int* qbeg, const int* vis, hipStream_t stream);
 
-// kv_f16: cache format, 0 = fp32, 1 = fp16 (this file), 2 = bf16x3 planes (attention_bf16x3.hip)
+int attention_f16x2(const float* q, const void* kc, const void* vc, int nkp, float* out, uint16_t* outp, size_t ops, int pfmt, int R, int H, int l, int Lp,
+                    int Ktot, int n_chunk, const int* qbeg, const int* vis, hipStream_t stream);
+
+// kv_f16: cache format, 0 = fp32, 1 = fp16 (this file), 2 = bf16x3 planes (attention_bf16x3.hip), 3 = f16x2 planes, 4 = one fp16 plane (attention_f16x2.hip)
 int attention_f32(const float* q, const void* kc, const void* vc, int kv_f16, float* out, uint16_t* outp, size_t ops, int pfmt, int R, int H, int l, int Lmax,
                   int Ktot, int n_chunk, const int* qbeg, const int* vis, hipStream_t stream) {
     SDVAR_CHECK_ARG(!outp || pfmt == PLANES_BF16X3 || pfmt == PLANES_F16X2, "attention: plane format %d", pfmt);
+    if (kv_f16 == 3 || kv_f16 == 4) return attention_f16x2(q, kc, vc, kv_f16 == 3 ? 2 : 1, out, outp, ops, pfmt, R, H, l, Lmax, Ktot, n_chunk, qbeg, vis, stream);
     if (kv_f16 == 2) return attention_bf16x3(q, kc, vc, out, outp, ops, pfmt, R, H, l, Lmax, Ktot, n_chunk, qbeg, vis, stream);
     SDVAR_CHECK_ARG(q && kc && vc && (out || outp), "attention: null operand");
     SDVAR_CHECK_ARG(n_chunk >= 1 && n_chunk <= ATT_MAX_CHUNK, "attention: chunk of %d stages unsupported (max %d)", n_chunk, ATT_MAX_CHUNK);

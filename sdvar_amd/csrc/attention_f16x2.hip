@@ -1,0 +1,265 @@
+// Verify-attention on the gfx950 f16 matrix cores with two-plane split operands (the arithmetic contract of gemm_f16x2.hip: an fp32
+// value is held as h + l, two fp16 numbers, to 2^-22; three of the four plane products are evaluated, fp32 accumulate), for the
+// fp16-plane KV-cache formats.  Same semantics and structure as attention_bf16x3.hip (basic_var.py:107-117 with the mask rows of
+// var.py:108-113, flash-style over 32-key tiles, scores never leave registers); what changes is the operand format:
+//
+//   NKP = 2 (cache format 3, fp32 models in gemm mode f16x2): K and V are split when they are appended (elementwise.hip
+//       qk_norm_append, format 3); S^T = Kh Qh + Kh Ql + Kl Qh and O^T = Vh Ph + Vh Pl + Vl Ph: 3 + 3 MFMAs per 16 k instead of the
+//       6 + 6 of bf16x3, and the cache is 4 bytes per element - the size of the fp32 cache it stands for (bf16x3 planes: 6).
+//   NKP = 1 (cache format 4, BASELINE config P4's fp16 KV cache): the cache holds fp16(k), fp16(v) - exactly what the reference's
+//       half-precision cache would hold - so the K / V operands ARE exact fp16 and only Q and P need their low plane: 2 + 2 MFMAs.
+//
+// KV cache (Lp = Lmax rounded up to a multiple of 64, zero-initialised by the owner):
+//     kc  [R][H][NKP][Lp][64]  fp16   K planes, one 128-byte row per key
+//     vc  [R][H][NKP][64][Lp]  fp16   V^T planes, one row per channel; inside every block of 16 keys the position of key
+//                                     b3 b2 b1 b0 is b2 b3 b1 b0 (the order in which a lane's score registers hold their keys)
+// Mapping (wave64): workgroup = 4 waves = 128 queries of one (row, head); tiles of 32 keys x (NKP K planes + NKP V^T planes) are
+// DMA'd (global_load_lds, 16 B per lane) into a 3-stage ring (16 KB per stage at NKP = 2), XOR-swizzled as in attention_bf16x3.hip.
+// Algorithmic bytes per launch: R*H*64*4*(2*Ktot + 2*l) for NKP = 2 - now also the bytes the cache really holds.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace sdvar {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+typedef uint16_t u16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+constexpr int ATTH_MAX_CHUNK = 16;
+constexpr int AKT = 32;                 // keys per LDS tile
+constexpr int APL = AKT * 64;           // fp16 elements per plane tile (K: 32 keys x 64 channels; V^T: 64 channels x 32 keys)
+constexpr int ANST = 3;                 // ring depth
+
+struct AttnHArgs {
+    const float* q; const uint16_t* kc; const uint16_t* vc; float* out;
+    uint16_t* outp; size_t ops; int pfmt;       // output planes for the proj GEMM: PLANES_BF16X3 or PLANES_F16X2 (common.h)
+    int R, H, l, Lp, Ktot;
+    int n_chunk;
+    int qbeg[ATTH_MAX_CHUNK + 1];
+    int vis[ATTH_MAX_CHUNK];
+};
+
+// eight consecutive values -> the two packed fp16x8 words (h = fp16(x), l = fp16(x - h)); values saturate at the fp16 range
+__device__ __forceinline__ void split8h(const float* v, f16x8& h, f16x8& l) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = fminf(fmaxf(v[e], -65504.0f), 65504.0f);
+        const _Float16 hh = (_Float16)x;
+        h[e] = hh; l[e] = (_Float16)(x - (float)hh);
+    }
+}
+
+// acc += A.B over the kept plane products, smallest terms first: a = planes of the cache operand (NKP of them), b = {h, l} of Q or P
+template <int NKP>
+__device__ __forceinline__ void mfma_planes(f32x16& acc, const f16x8* a, const f16x8* b) {
+    if (NKP == 2) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], acc, 0, 0, 0);
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// The softmax / split arithmetic is written for instruction count (vector-ALU work does not hide under MFMAs on gfx950: see
+// attention_bf16x3.hip): packed fp32 ops on register pairs, v_max3, masking only in the tiles that straddle a visibility boundary.
+template <int NKP>
+__global__ __launch_bounds__(256, 2) void attention_f16x2_kernel(AttnHArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t att_sm[];
+    constexpr int ASTAGE = 2 * NKP * APL;         // one K tile + one V^T tile, NKP planes each
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int qt = blockIdx.x, h = blockIdx.y, r = blockIdx.z;
+    const int q0 = qt * 128;
+
+    const int qi_raw = q0 + wave * 32 + li;
+    const int qi = min(qi_raw, a.l - 1);
+    int vis_q = a.vis[0];
+#pragma unroll 1
+    for (int j = 1; j < a.n_chunk; ++j) if (qi >= a.qbeg[j]) vis_q = a.vis[j];
+    const int q_last = min(q0 + 127, a.l - 1);
+    int kend = a.vis[0];
+#pragma unroll 1
+    for (int j = 1; j < a.n_chunk; ++j) if (q_last >= a.qbeg[j]) kend = a.vis[j];
+    const bool wave_active = (q0 + wave * 32) < a.l;
+
+    // Q planes: B operand of S^T = K Q^T; lane (query li, half lh) holds channels 16c + 8lh .. +7 of step c
+    f16x8 qp[4][2];
+    {
+        const float* pq = a.q + (((size_t)r * a.H + h) * a.l + qi) * 64 + 8 * lh;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float v[8];
+            const f32x4 u0 = *reinterpret_cast<const f32x4*>(pq + 16 * c), u1 = *reinterpret_cast<const f32x4*>(pq + 16 * c + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = u0[e]; v[4 + e] = u1[e]; }
+            split8h(v, qp[c][0], qp[c][1]);
+        }
+    }
+
+    // DMA, 6 instructions per wave per tile: K plane tile = 32 key rows of 128 B (wave w: rows 8w..8w+7, chunk swizzle
+    // (row >> 1) & 7); V^T plane tile = 64 channel rows of 64 B (wave w: rows 16w..16w+15, chunk swizzle (row >> 2) & 3).
+    // LDS ring of 3 stages (K planes then V^T planes, 24 KB each); tile t lives in stage t % 3 and is requested two
+    // iterations before it is read: one 32-key iteration (~1 us) is shorter than the HBM/MALL latency.
+    const size_t head = ((size_t)r * a.H + h) * NKP * (size_t)a.Lp * 64;
+    const size_t kps = (size_t)a.Lp * 64;                    // plane stride, both operands
+    const int krow = 8 * wave + (lane >> 3), kchunk = (lane & 7) ^ ((krow >> 1) & 7);
+    const int vrow = 16 * wave + (lane >> 2), vchunk = (lane & 3) ^ ((vrow >> 2) & 3);
+    // loop-invariant 32-bit lane offsets + wave-uniform bases (common.h SDVAR_DMA16): no vector address arithmetic per tile
+    const int swave = __builtin_amdgcn_readfirstlane(wave);
+    const uint32_t lk = (uint32_t)(krow * 64 + 8 * kchunk) * 2u, lv = (uint32_t)(vrow * a.Lp + 8 * vchunk) * 2u;
+    const char* const bk = reinterpret_cast<const char*>(a.kc + head);
+    const char* const bv = reinterpret_cast<const char*>(a.vc + head);
+    auto issue = [&](int t) {
+        uint16_t* st = att_sm + (t % ANST) * ASTAGE + swave * 512;
+#pragma unroll
+        for (int p = 0; p < NKP; ++p) {
+            SDVAR_DMA16(lk, bk + (p * kps + (size_t)t * AKT * 64) * 2, SDVAR_LDS_ADDR(st + p * APL));
+            SDVAR_DMA16(lv, bv + (p * kps + (size_t)t * AKT) * 2, SDVAR_LDS_ADDR(st + (NKP + p) * APL));
+        }
+    };
+
+    f32x16 o0, o1;                        // O^T accumulators: d = db*32 + (reg&3) + 8*(reg>>2) + 4*lh, column = this query
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
+    // running maximum in log2 units (M = m log2 e, rounded once per tile so that p and the rescale factor use the same value)
+    float M_run = -INFINITY, l_run = 0.f;
+
+    const int swk = (li >> 1) & 7, swv = (li >> 2) & 3;
+    const int ntiles = (kend + AKT - 1) / AKT;
+    const float L2E = 1.4426950408889634f;
+    issue(0);
+    if (ntiles > 1) issue(1);
+    for (int t = 0; t < ntiles; ++t) {
+        // tile t must have landed; the requests of tile t+1 (issued one iteration ago) may still be in flight
+        if (t + 1 < ntiles) { if (NKP == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                           // ... and every wave is done with tile t-1, whose stage is refilled now
+        if (t + 2 < ntiles) issue(t + 2);
+        if (!wave_active) continue;
+        const int k0 = t * AKT;
+        const uint16_t* sk = att_sm + (t % ANST) * ASTAGE + li * 64;              // this lane's K row (key li)
+        const uint16_t* sv = att_sm + (t % ANST) * ASTAGE + NKP * APL + li * 32;  // this lane's V^T rows (channels li and 32 + li)
+        f32x16 s;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            f16x8 kf[NKP];
+#pragma unroll
+            for (int p = 0; p < NKP; ++p) kf[p] = *reinterpret_cast<const f16x8*>(sk + p * APL + 8 * ((2 * c + lh) ^ swk));
+            mfma_planes<NKP>(s, kf, qp[c]);
+        }
+        // V^T fragments of the tile: issued now, consumed after the softmax arithmetic
+        f16x8 vf[2][2][NKP];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int p = 0; p < NKP; ++p) {
+                vf[j][0][p] = *reinterpret_cast<const f16x8*>(sv + p * APL + 8 * ((2 * j + lh) ^ swv));
+                vf[j][1][p] = *reinterpret_cast<const f16x8*>(sv + p * APL + 1024 + 8 * ((2 * j + lh) ^ swv));
+            }
+        // ---- mask (only in tiles that reach past some query's visible keys; this lane holds keys k0 + (i&3) + 8*(i>>2) + 4*lh)
+        if (__builtin_amdgcn_ballot_w64(k0 + AKT > vis_q) != 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) if (k0 + (i & 3) + 8 * (i >> 2) + 4 * lh >= vis_q) s[i] = -INFINITY;
+        }
+        // ---- online softmax in log2 units: p = 2^(s log2e - M)
+        float mloc = s[0];                                      // scores are never NaN: plain v_max3_f32, no canonicalisation
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mloc) : "v"(s[0]), "v"(s[1]), "v"(s[2]));
+#pragma unroll
+        for (int i = 3; i < 15; i += 2) asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mloc) : "v"(mloc), "v"(s[i]), "v"(s[i + 1]));
+        asm("v_max_f32 %0, %1, %2" : "=v"(mloc) : "v"(mloc), "v"(s[15]));
+        {
+            const auto sw2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mloc), __float_as_uint(mloc), false, false);
+            mloc = fmaxf(__uint_as_float(sw2[0]), __uint_as_float(sw2[1]));                  // the other half of the query's keys
+        }
+        const float M_new = fmaxf(M_run, mloc * L2E);          // finite from the first tile on (key 0 is always visible)
+        const float alpha = __builtin_amdgcn_exp2f(M_run - M_new);
+        M_run = M_new;
+        const f32x2 l2e2 = {L2E, L2E}, nM2 = {-M_new, -M_new};
+        f32x2 pr[8], ls2 = {0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const f32x2 x = __builtin_elementwise_fma(f32x2{s[2 * e], s[2 * e + 1]}, l2e2, nM2);      // v_pk_fma_f32
+            pr[e] = f32x2{__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+            ls2 += pr[e];
+        }
+        float lsum = ls2[0] + ls2[1];
+        {
+            const auto sw2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(lsum), __float_as_uint(lsum), false, false);
+            lsum = __uint_as_float(sw2[0]) + __uint_as_float(sw2[1]);
+        }
+        l_run = l_run * alpha + lsum;
+        // ---- two-plane split of the probabilities, two at a time; pair e of step j = registers 8j + 2e, 8j + 2e + 1, which
+        // are k-slots 8lh + 2e, +1 of the MFMA, i.e. keys 16j + {0..3, 8..11} + 4lh - the permuted key order of the V^T rows
+        f16x8 pp[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const f32x2 x = pr[4 * j + e];                                   // p in [0, 1]: no saturation needed
+                const f16x2v hh = __builtin_convertvector(x, f16x2v);
+                const f32x2 rr = x - __builtin_convertvector(hh, f32x2);
+                const f16x2v ll = __builtin_convertvector(rr, f16x2v);
+                pp[j][0][2 * e] = hh[0]; pp[j][0][2 * e + 1] = hh[1];
+                pp[j][1][2 * e] = ll[0]; pp[j][1][2 * e + 1] = ll[1];
+            }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+        // ---- O^T += V^T P^T
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            mfma_planes<NKP>(o0, vf[j][0], pp[j]);
+            mfma_planes<NKP>(o1, vf[j][1], pp[j]);
+        }
+    }
+
+    if (wave_active && qi_raw < a.l) {
+        const float inv = 1.0f / l_run;
+        const size_t obase = ((size_t)r * a.l + qi_raw) * (a.H * 64) + h * 64 + 4 * lh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v0, v1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v0[e] = o0[4 * g + e] * inv; v1[e] = o1[4 * g + e] * inv; }
+            if (a.outp) {
+                const float u0[4] = {v0[0], v0[1], v0[2], v0[3]}, u1[4] = {v1[0], v1[1], v1[2], v1[3]};
+                const int orow = r * a.l + qi_raw, ocol = h * 64 + 4 * lh + 8 * g;      // K-blocked planes of the (R*l, H*64) matrix
+                store_planes4(a.outp, a.ops, kb_index(orow, ocol, a.R * a.l), u0, a.pfmt);
+                store_planes4(a.outp, a.ops, kb_index(orow, ocol + 32, a.R * a.l), u1, a.pfmt);
+            } else {
+                *reinterpret_cast<f32x4*>(a.out + obase + 8 * g) = v0;
+                *reinterpret_cast<f32x4*>(a.out + obase + 32 + 8 * g) = v1;
+            }
+        }
+    }
+}
+
+// nkp: 2 = cache format 3 (two fp16 planes per value), 1 = cache format 4 (one fp16 plane: the fp16 KV cache)
+int attention_f16x2(const float* q, const void* kc, const void* vc, int nkp, float* out, uint16_t* outp, size_t ops, int pfmt, int R, int H, int l, int Lp,
+                    int Ktot, int n_chunk, const int* qbeg, const int* vis, hipStream_t stream) {
+    SDVAR_CHECK_ARG(q && kc && vc && (out || outp), "attention: null operand");
+    SDVAR_CHECK_ARG(nkp == 1 || nkp == 2, "attention: %d cache planes", nkp);
+    SDVAR_CHECK_ARG(n_chunk >= 1 && n_chunk <= ATTH_MAX_CHUNK, "attention: chunk of %d stages unsupported (max %d)", n_chunk, ATTH_MAX_CHUNK);
+    SDVAR_CHECK_ARG(R > 0 && H > 0 && l > 0 && Ktot >= l && Ktot <= Lp, "attention: bad lengths l=%d Ktot=%d Lmax=%d", l, Ktot, Lp);
+    SDVAR_CHECK_ARG(Lp % 64 == 0, "attention: the planes KV formats need Lmax %% 64 == 0 (got %d)", Lp);
+    AttnHArgs a;
+    a.q = q; a.kc = (const uint16_t*)kc; a.vc = (const uint16_t*)vc; a.out = out; a.outp = outp; a.ops = ops; a.pfmt = pfmt;
+    a.R = R; a.H = H; a.l = l; a.Lp = Lp; a.Ktot = Ktot; a.n_chunk = n_chunk;
+    for (int j = 0; j < n_chunk; ++j) {
+        a.qbeg[j] = qbeg[j]; a.vis[j] = vis[j];
+        SDVAR_CHECK_ARG(vis[j] >= 1 && vis[j] <= Ktot && (j == 0 ? qbeg[0] == 0 : (qbeg[j] > qbeg[j - 1] && vis[j] >= vis[j - 1])), "attention: bad stage table at %d", j);
+    }
+    a.qbeg[n_chunk] = l;
+    const size_t lds = ANST * (size_t)(2 * nkp * APL) * sizeof(uint16_t);       // 48 KB / 24 KB: under the 64 KB default limit
+    if (nkp == 2) hipLaunchKernelGGL(attention_f16x2_kernel<2>, dim3((l + 127) / 128, H, R), dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL(attention_f16x2_kernel<1>, dim3((l + 127) / 128, H, R), dim3(256), lds, stream, a);
+    SDVAR_LAUNCH_CHECK();
+    return SDVAR_OK;
+}
+
+}  // namespace sdvar

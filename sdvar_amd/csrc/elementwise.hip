@@ -204,21 +204,25 @@ __global__ __launch_bounds__(256) void qk_norm_append_kernel(const float* __rest
     v_cache[c] = (KV)v;
 }
 
-// Format 2 of the cache (attention_bf16x3.hip): K planes [R][H][3][Lp][64] and V^T planes [R][H][3][64][Lp] with bits 2 and 3
-// of the key position swapped inside every block of 16 keys.  Same arithmetic as above; the fp32 values are split exactly.
+// Formats 2 / 3 / 4 of the cache (attention_bf16x3.hip: three bf16 planes; attention_f16x2.hip: two fp16 planes, or ONE fp16 plane = the
+// fp16 KV cache of BASELINE config P4): K planes [R][H][NP][Lp][64] and V^T planes [R][H][NP][64][Lp] with bits 2 and 3 of the key
+// position swapped inside every block of 16 keys.  Same arithmetic as above; format 2 holds the fp32 values exactly, format 3 to
+// 2^-22, format 4 holds fp16(k), fp16(v) rounded to nearest even like torch's .half().
 // One workgroup per (32-position block of the cache, head, row): the waves normalise their tokens and write q and the K
 // planes (128-byte rows), V goes through LDS and leaves as 16-byte runs of 8 cache positions per channel row (transposed
 // 2-byte stores cost 2x the whole kernel: 1.15 ms against 0.44 ms per d16 stage-9 call).
 __global__ __launch_bounds__(256) void qk_norm_append_planes_kernel(const float* __restrict__ qkv, const float* __restrict__ scale_mul,
                                                                     float* __restrict__ q_out, uint16_t* __restrict__ k_cache,
-                                                                    uint16_t* __restrict__ v_cache, int R, int l, int H, int Lp, int pos0, PendingSplitK pend) {
+                                                                    uint16_t* __restrict__ v_cache, int R, int l, int H, int Lp, int pos0, PendingSplitK pend,
+                                                                    int fmt) {
     __shared__ float vs[32 * 65];
+    const int NP = fmt == 2 ? 3 : (fmt == 3 ? 2 : 1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = blockIdx.y, r = blockIdx.z;
     const int P0 = (pos0 / 32 + blockIdx.x) * 32;
     const int pb = max(P0, pos0), pe = min(P0 + 32, pos0 + l);
     const int C = H * 64;
-    const size_t head = ((size_t)r * H + h) * 3 * (size_t)Lp * 64, ps = (size_t)Lp * 64;
+    const size_t head = ((size_t)r * H + h) * NP * (size_t)Lp * 64, ps = (size_t)Lp * 64;
     const float sm = expf(fminf(scale_mul[h], 4.605170249938965f));
     // wave w owns positions pb + w, + 4, ... (at most 8); four of them are in flight at a time (their loads - up to 3 x split slab reads
     // each - are independent, the wave reductions are not the bottleneck)
@@ -248,10 +252,17 @@ __global__ __launch_bounds__(256) void qk_norm_append_planes_kernel(const float*
             const float qn = fmaxf(sqrtf(wave_sum(q[u] * q[u])), 1e-12f);
             const float kn = fmaxf(sqrtf(wave_sum(k[u] * k[u])), 1e-12f);
             q_out[(((size_t)r * H + h) * l + t) * 64 + lane] = (q[u] / qn) * sm;
-            uint16_t k0, k1, k2;
-            split3(k[u] / kn, k0, k1, k2);
             uint16_t* pk = k_cache + head + (size_t)pos * 64 + lane;
-            pk[0] = k0; pk[ps] = k1; pk[2 * ps] = k2;
+            if (fmt == 2) {
+                uint16_t k0, k1, k2;
+                split3(k[u] / kn, k0, k1, k2);
+                pk[0] = k0; pk[ps] = k1; pk[2 * ps] = k2;
+            } else {
+                uint16_t kh, kl;
+                split2h(k[u] / kn, kh, kl);
+                pk[0] = kh;
+                if (fmt == 3) pk[ps] = kl;
+            }
             vs[(pos - P0) * 65 + lane] = v[u];
         }
     }
@@ -270,7 +281,24 @@ __global__ __launch_bounds__(256) void qk_norm_append_planes_kernel(const float*
             v[e] = in ? vs[(key - P0) * 65 + d] : 0.f;
         }
         uint16_t* pv = v_cache + head + (size_t)d * Lp + P0 + 8 * c;
-        if (inside == 8) {
+        if (fmt != 2) {             // fp16 planes: h = fp16(v) (+ l = fp16(v - h) for format 3)
+            uint16_t hh[8], ll[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) split2h(v[e], hh[e], ll[e]);
+            if (inside == 8) {
+                u32x4 a, b;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { a[e] = (uint32_t)hh[2 * e] | ((uint32_t)hh[2 * e + 1] << 16); b[e] = (uint32_t)ll[2 * e] | ((uint32_t)ll[2 * e + 1] << 16); }
+                *reinterpret_cast<u32x4*>(pv) = a;
+                if (fmt == 3) *reinterpret_cast<u32x4*>(pv + ps) = b;
+            } else if (inside) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int key = kb + (e & 3) + 8 * (e >> 2);
+                    if (key >= pb && key < pe) { pv[e] = hh[e]; if (fmt == 3) pv[ps + e] = ll[e]; }
+                }
+            }
+        } else if (inside == 8) {
             u32x4 a, b, cc;
             split8_packed(v, a, b, cc);
             *reinterpret_cast<u32x4*>(pv) = a; *reinterpret_cast<u32x4*>(pv + ps) = b; *reinterpret_cast<u32x4*>(pv + 2 * ps) = cc;
@@ -294,10 +322,10 @@ int qk_norm_append(const float* qkv, const float* scale_mul, float* q_out, void*
     if (pend && pend->ws) { SDVAR_CHECK_ARG(pend->bias && pend->split >= 1, "qk_norm_append: bad pending split-K descriptor"); pd = *pend; }
     SDVAR_CHECK_ARG(R > 0 && l > 0 && H > 0 && pos0 >= 0 && pos0 + l <= Lmax, "qk_norm_append: cache overflow pos0=%d l=%d Lmax=%d", pos0, l, Lmax);
     const long long items = (long long)R * l * H;
-    SDVAR_CHECK_ARG(kv_f16 >= 0 && kv_f16 <= 2, "qk_norm_append: cache format %d (0 = fp32, 1 = fp16, 2 = bf16x3 planes)", kv_f16);
-    if (kv_f16 == 2) {
-        SDVAR_CHECK_ARG(Lmax % 64 == 0, "qk_norm_append: the planes KV format needs Lmax %% 64 == 0 (got %d)", Lmax);
-        hipLaunchKernelGGL(qk_norm_append_planes_kernel, dim3((unsigned)((pos0 + l + 31) / 32 - pos0 / 32), H, R), dim3(256), 0, stream, qkv, scale_mul, q_out, (uint16_t*)k_cache, (uint16_t*)v_cache, R, l, H, Lmax, pos0, pd);
+    SDVAR_CHECK_ARG(kv_f16 >= 0 && kv_f16 <= 4, "qk_norm_append: cache format %d (0 = fp32, 1 = fp16, 2 = bf16x3 planes, 3 = f16x2 planes, 4 = one fp16 plane)", kv_f16);
+    if (kv_f16 >= 2) {
+        SDVAR_CHECK_ARG(Lmax % 64 == 0, "qk_norm_append: the planes KV formats need Lmax %% 64 == 0 (got %d)", Lmax);
+        hipLaunchKernelGGL(qk_norm_append_planes_kernel, dim3((unsigned)((pos0 + l + 31) / 32 - pos0 / 32), H, R), dim3(256), 0, stream, qkv, scale_mul, q_out, (uint16_t*)k_cache, (uint16_t*)v_cache, R, l, H, Lmax, pos0, pd, kv_f16);
     } else if (kv_f16) hipLaunchKernelGGL(qk_norm_append_kernel<__half>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, qkv, scale_mul, q_out, (__half*)k_cache, (__half*)v_cache, R, l, H, Lmax, pos0, pd);
     else hipLaunchKernelGGL(qk_norm_append_kernel<float>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, qkv, scale_mul, q_out, (float*)k_cache, (float*)v_cache, R, l, H, Lmax, pos0, pd);
     SDVAR_LAUNCH_CHECK();

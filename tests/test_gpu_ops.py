@@ -603,3 +603,78 @@ def test_ln_and_attention_f16x2_plane_outputs(dev):
     E._check(lib.sdvar_op_attention(_p(q), _p(kc), _p(vc), 0, None, _p(ap), R * l * H * 64, 2, R, H, l, K, K, 1, one(0), one(K), _st()))
     ref = a32.double().view(R * l, H * 64)
     assert bool(((_unplanes_h(ap) - ref).abs() <= tol(ref)).all())
+
+
+@pytest.mark.parametrize("fmt", [3, 4])
+@pytest.mark.parametrize("R,H,lens,prefix", [(2, 4, [1], 0), (2, 2, [4], 1), (4, 3, [25], 30), (2, 4, [100], 155), (2, 16, [256], 424),
+                                             (2, 4, [9, 16], 5), (2, 3, [64, 100, 169], 91), (2, 2, [1, 4], 0), (1, 2, [169, 256], 255), (2, 2, [324], 640)])
+def test_f16_planes_kv_cache_append_and_attention(dev, R, H, lens, prefix, fmt):
+    """Cache formats 3 (two fp16 planes per value: the fp32 cache to 2^-22, attention on the f16 matrix cores with 3 + 3 products) and
+    4 (ONE fp16 plane: the fp16 KV cache of config P4, 2 + 2 products): append in two calls, then the block-causal attention.
+    Format 3 is held to the fp32 kernel's bar against the fp32 K / V; format 4 against the fp16-rounded K / V it stores."""
+    lib = E.load_library()
+    NP = 2 if fmt == 3 else 1
+    l = sum(lens); Ktot = prefix + l; Lp = (Ktot + 5 + 63) // 64 * 64
+    Cw = 64 * H
+    sm = torch.full((H,), math.log(4.0), device=dev)
+    kc = torch.zeros(R, H, NP, Lp, 64, device=dev, dtype=torch.int16); vc = torch.zeros(R, H, NP, 64, Lp, device=dev, dtype=torch.int16)
+    parts = []
+    for i, (n, pos0) in enumerate([(prefix, 0), (l, prefix)]):
+        if n == 0:
+            continue
+        qkv = rnd(10 + i, (R * n, 3 * Cw)).to(dev)
+        qo = torch.zeros(R, H, n, 64, device=dev)
+        E._check(lib.sdvar_op_qk_norm_append(_p(qkv), _p(sm), _p(qo), _p(kc), _p(vc), fmt, R, n, H, Lp, pos0, _st()))
+        parts.append(qkv.cpu().view(R, n, 3, H, 64).permute(2, 0, 3, 1, 4))
+    k = F.normalize(torch.cat([p[1] for p in parts], dim=2), dim=-1); v = torch.cat([p[2] for p in parts], dim=2)
+    kpl = kc.cpu().view(torch.float16).double().sum(2)[:, :, :Ktot]
+    perm = [(p & ~12) | ((p & 4) << 1) | ((p & 8) >> 1) for p in range(Ktot)]
+    vpl = vc.cpu().view(torch.float16).double().sum(2)[:, :, :, perm].transpose(2, 3)
+    if fmt == 3:
+        tol = lambda ref: torch.maximum(ref.abs() * 2.0 ** -21.9, torch.tensor(2.0 ** -24.9, dtype=torch.float64))
+        assert bool(((kpl - k.double()).abs() <= tol(k.double()) + 1e-7).all())            # + the 1-ulp fp32 differences of the normalisation
+        assert bool(((vpl - v.double()).abs() <= tol(v.double())).all())
+        kr, vr = k, v
+    else:
+        assert (kpl.float() - k.half().float()).abs().max().item() <= 1e-3 and torch.equal(vpl.float(), v.half().float())
+        kr, vr = kpl.float(), vpl.float()                                                    # what the cache holds
+    qbeg = [int(sum(lens[:j])) for j in range(len(lens))]
+    vis = [prefix + int(sum(lens[:j + 1])) for j in range(len(lens))]
+    out = torch.empty(R, l, H * 64, device=dev)
+    n = len(lens)
+    E._check(lib.sdvar_op_attention(_p(qo), _p(kc), _p(vc), fmt, _p(out), None, 0, 2, R, H, l, Lp, Ktot, n, (C.c_int32 * n)(*qbeg), (C.c_int32 * n)(*vis), _st()))
+    ref = _attn_ref(qo.cpu(), kr, vr, qbeg, vis).transpose(1, 2).reshape(R, l, H * 64)
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err <= 2e-5, err
+    M = R * l
+    outp = torch.zeros(2, H * 64 // 32, M, 32, device=dev, dtype=torch.int16)
+    E._check(lib.sdvar_op_attention(_p(qo), _p(kc), _p(vc), fmt, None, _p(outp), M * H * 64, 2, R, H, l, Lp, Ktot, n, (C.c_int32 * n)(*qbeg), (C.c_int32 * n)(*vis), _st()))
+    o = out.cpu().double()
+    assert bool(((_unplanes_h(outp.cpu()).view(R, l, H * 64) - o).abs() <= torch.maximum(o.abs() * 2.0 ** -21.9, torch.tensor(2.0 ** -24.9, dtype=torch.float64))).all())
+
+
+@pytest.mark.parametrize("fmt", [3, 4])
+def test_f16_planes_attention_forced_online_rescale(dev, fmt):
+    """Scores of +-50 with the row maximum arriving late: the running-maximum rescale and the two-plane split of P."""
+    lib = E.load_library()
+    R, H, l, Ktot, Lp = 1, 1, 40, 300, 320
+    q = F.normalize(rnd(1, (R, H, l, 64)), dim=-1) * 50.0
+    k = F.normalize(rnd(2, (R, H, Ktot, 64)), dim=-1)
+    k[0, 0, 200] = q[0, 0, 3] / 50.0
+    k[0, 0, 299] = q[0, 0, 17] / 50.0
+    v = rnd(3, (R, H, Ktot, 64))
+    NP = 2 if fmt == 3 else 1
+
+    def planes(t):
+        h = t.half(); lo = (t - h.float()).half()
+        return torch.stack([h, lo][:NP]).view(torch.int16)
+    kc = torch.zeros(R, H, NP, Lp, 64, dtype=torch.int16); vc = torch.zeros(R, H, NP, 64, Lp, dtype=torch.int16)
+    kc[:, :, :, :Ktot] = planes(k).permute(1, 2, 0, 3, 4)
+    perm = torch.tensor([(p & ~12) | ((p & 4) << 1) | ((p & 8) >> 1) for p in range(Ktot)])
+    vc[:, :, :, :, perm] = planes(v).permute(1, 2, 0, 4, 3)
+    out = torch.empty(R, l, 64, device=dev)
+    qd, kd, vd = q.to(dev), kc.to(dev).contiguous(), vc.to(dev).contiguous()
+    E._check(lib.sdvar_op_attention(_p(qd), _p(kd), _p(vd), fmt, _p(out), None, 0, 2, R, H, l, Lp, Ktot, 1, (C.c_int32 * 1)(0), (C.c_int32 * 1)(Ktot), _st()))
+    kr, vr = (k, v) if fmt == 3 else (k.half().float(), v.half().float())
+    ref = _attn_ref(q, kr, vr, [0], [Ktot]).transpose(1, 2).reshape(R, l, 64)
+    assert (out.cpu().double() - ref).abs().max().item() <= (2e-5 if fmt == 4 else 6e-5)      # scores of 50: the 2^-22 of K moves the exponent by 50 * 2^-22

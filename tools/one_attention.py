@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run ONE verify-attention shape repeatedly (timing with HIP events, or under rocprofv3 --pmc).
-python tools/one_attention.py R H l prefix fmt iters      fmt: 0 fp32 cache, 1 fp16, 2 bf16x3 planes"""
+python tools/one_attention.py R H l prefix fmt iters      fmt: 0 fp32 cache, 1 fp16, 2 bf16x3 planes, 3 f16x2 planes, 4 one fp16 plane"""
 import ctypes as C, math, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sdvar_amd import engine as E
@@ -9,8 +9,9 @@ lib = E.load_library(); dev = torch.device("cuda:0"); st = C.c_void_p(torch.cuda
 P = lambda t: C.c_void_p(t.data_ptr())
 Ktot = prefix + l; Lp = (Ktot + 63) // 64 * 64
 sm = torch.full((H,), math.log(4.0), device=dev)
-if fmt == 2:
-    kc = torch.zeros(R, H, 3, Lp, 64, device=dev, dtype=torch.int16); vc = torch.zeros(R, H, 3, 64, Lp, device=dev, dtype=torch.int16)
+if fmt >= 2:
+    NP = {2: 3, 3: 2, 4: 1}[fmt]
+    kc = torch.zeros(R, H, NP, Lp, 64, device=dev, dtype=torch.int16); vc = torch.zeros(R, H, NP, 64, Lp, device=dev, dtype=torch.int16)
 else:
     dt = torch.float16 if fmt == 1 else torch.float32
     kc = torch.zeros(R, H, Lp, 64, device=dev, dtype=dt); vc = torch.zeros_like(kc)
