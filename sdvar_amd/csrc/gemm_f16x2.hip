@@ -30,9 +30,14 @@ constexpr int HBK = 32;             // k per LDS stage
 constexpr int HROW = 40;            // padded row of the register-staged kernel, in fp16 elements (80 bytes)
 constexpr int HBN = 128;
 
+// GELU(tanh) (basic_var.py:40): 0.5 x (1 + tanh(u)) = x sigmoid(2u) = x / (1 + 2^(-2u log2 e)) with v_exp_f32 and v_rcp_f32 (1 ulp each, ~2e-7
+// relative on the result): libm's tanhf costs ~40 vector instructions per value and the epilogue of a 256 x 128 tile evaluates 64 of them per lane
+// with nothing to hide them under (12 us per round of workgroups at M = 4096, fc1)
 __device__ __forceinline__ float gelu_tanh_h(float x) {
     const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    return 0.5f * x * (1.0f + tanhf(k0 * (x + k1 * x * x * x)));
+    const float u = k0 * (x + k1 * x * x * x);
+    const float e = __builtin_amdgcn_exp2f(u * -2.8853900817779268f);        // exp(-2u); +inf for very negative x: the quotient is then 0
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
 struct GemmHArgs {
@@ -190,7 +195,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 constexpr int H2_STAGE = 4 * 128 * 32;          // fp16 elements per stage (32 KB)
 #define SDVAR_LDS_RDH(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr) : "memory")
 
-template <int EPI>
+template <int EPI, int NS>
 __global__ __launch_bounds__(512, 2) void gemm_f16x2_v2_kernel(GemmHArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint16_t hsm[];
     constexpr int BM = 128;
@@ -217,7 +222,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_v2_kernel(GemmHArgs a) {
     const char* const bw = reinterpret_cast<const char*>(a.W + (size_t)kt0 * a.N * 32);
     // DMA instruction q (0..3) of K-step t (relative) -> stage t % 3: q = 2p is X plane p, q = 2p + 1 is W plane p
     auto issue_one = [&](int t, int q) {
-        uint16_t* st = hsm + (t % 3) * H2_STAGE + swave * 512;       // + sub-array * 4096 elements
+        uint16_t* st = hsm + (t % NS) * H2_STAGE + swave * 512;      // + sub-array * 4096 elements
         const int p = q >> 1;
         if (q & 1) SDVAR_DMA16(lw, bw + ((size_t)t * a.N * 32 + p * a.wps) * 2, SDVAR_LDS_ADDR(st + (2 + p) * 4096));
         else SDVAR_DMA16(lx, bx + ((size_t)t * a.M * 32 + p * a.xps) * 2, SDVAR_LDS_ADDR(st + p * 4096));
@@ -239,13 +244,13 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_v2_kernel(GemmHArgs a) {
     const int ch0 = 8 * ((0 + lh) ^ sw), ch1 = 8 * ((2 + lh) ^ sw);
 
     issue(0);
-    if (nk > 1) issue(1);
+    if (NS == 3 && nk > 1) issue(1);
     for (int t = 0; t < nk; ++t) {
-        if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (NS == 3 && t + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        const bool pf = t + 2 < nk;
-        const uint32_t sb = (uint32_t)(uintptr_t)(lds_ptr_t)(hsm + (t % 3) * H2_STAGE);
+        const bool pf = t + NS - 1 < nk;
+        const uint32_t sb = (uint32_t)(uintptr_t)(lds_ptr_t)(hsm + (t % NS) * H2_STAGE);
         const uint32_t aa0 = sb + 2 * (offa0 + ch0), aa1 = sb + 2 * (offa0 + ch1), ab0 = sb + 2 * (offb + ch0), ab1 = sb + 2 * (offb + ch1);
         // fa[s][plane][row tile], fb[s][plane]: X plane p at +8192 p bytes, second 32-row tile at +2048; W plane p at +16384 + 8192 p
         f16x8 fa[2][2][2], fb[2][2];
@@ -262,7 +267,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_v2_kernel(GemmHArgs a) {
             for (int i = 0; i < 2; ++i) {
                 SDVAR_MFMA3(acc[i], fa[s][0][i], fa[s][1][i], fb[s][0], fb[s][1]);
                 __builtin_amdgcn_sched_barrier(0);
-                if (pf) issue_one(t + 2, 2 * s + i);          // the 4 DMA instructions of K-step t+2, one behind each MFMA group
+                if (pf) issue_one(t + NS - 1, 2 * s + i);     // the 4 DMA instructions of the K-step NS-1 ahead, one behind each MFMA group
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -288,7 +293,8 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_v2_kernel(GemmHArgs a) {
 // ---------------------------------------------------------------------------------------------------------------------
 // 256 x 128 workgroup tile, 8 waves (4 x 2) of 64 x 64 outputs, LDS-DMA into a 3-stage ring (48 KB per stage: X planes [2][256][32]
 // then W planes [2][128][32]), two K-steps in flight: a K-step holds 24 MFMAs per wave (768 cycles), less than the DMA latency
-// under load, so one K-step of lookahead (what the bf16x3 kernel uses) would expose it.
+// under load, so one K-step of lookahead (what the bf16x3 kernel uses) would expose it.  (Software-pipelining the fragment reads across the
+// K-step boundary - next tile's reads under this tile's MFMAs - was measured and changed nothing: the LDS reads are not what is exposed.)
 constexpr int H3_STAGE = 2 * (256 + 128) * 32;
 
 template <int EPI>
@@ -613,12 +619,22 @@ static void choose_cfg_h(int M, int N, int K, size_t ws_floats, int* bm_out, int
 
 static thread_local int* g_defer_h = nullptr;     // set per call by gemm_bf16x3_nt; thread-local: host threads may drive different model objects concurrently
 
+static int g_h2_stages = -1;      // ring depth of the 128 x 128 kernel: 3 = one workgroup per CU with two K-steps in flight, 2 = 64 KB of LDS, two workgroups per CU
+                                   // (SDVAR_GEMM_H2_STAGES=2/3 for A/B runs)
+
 template <int EPI>
 static int launch_h2_kernel(const GemmHArgs& a, int grid, hipStream_t stream) {
+    if (g_h2_stages < 0) { const char* e = getenv("SDVAR_GEMM_H2_STAGES"); g_h2_stages = (e && atoi(e) == 2) ? 2 : 3; }
+    if (g_h2_stages == 2) {
+        const size_t lds = 2 * (size_t)H2_STAGE * sizeof(uint16_t);      // 64 KB
+        hipLaunchKernelGGL((gemm_f16x2_v2_kernel<EPI, 2>), dim3(grid), dim3(512), lds, stream, a);
+        SDVAR_LAUNCH_CHECK();
+        return SDVAR_OK;
+    }
     const size_t lds = 3 * (size_t)H2_STAGE * sizeof(uint16_t);      // 96 KB
     static LdsOptIn opt_in;
-    SDVAR_LDS_OPT_IN(opt_in, lds, (const void*)gemm_f16x2_v2_kernel<EPI>);
-    hipLaunchKernelGGL((gemm_f16x2_v2_kernel<EPI>), dim3(grid), dim3(512), lds, stream, a);
+    SDVAR_LDS_OPT_IN(opt_in, lds, (const void*)gemm_f16x2_v2_kernel<EPI, 3>);
+    hipLaunchKernelGGL((gemm_f16x2_v2_kernel<EPI, 3>), dim3(grid), dim3(512), lds, stream, a);
     SDVAR_LAUNCH_CHECK();
     return SDVAR_OK;
 }
