@@ -55,7 +55,8 @@ int sdvar_model_bind_embed(sdvar_model_t* m, const float* class_emb, const float
                            const float* lvl_embed, const float* word_w, const float* word_b, void* stream);
 /* one AdaLNSelfAttn block (basic_var.py:128-159): ada_lin.1.{weight (6C,C), bias}, attn.mat_qkv.weight (3C,C),
  * attn.q_bias, attn.v_bias, attn.scale_mul_1H11 (H), attn.proj.{weight,bias}, ffn.fc1.{weight (4C,C),bias},
- * ffn.fc2.{weight (C,4C),bias}.  ada_w may be NULL for a shared_aln block (see sdvar_model_bind_shared_aln). */
+ * ffn.fc2.{weight (C,4C),bias}.  ada_w may be NULL for a shared_aln block (see sdvar_model_bind_shared_aln); scale_mul may be NULL for an
+ * attn_l2_norm=False model (basic_var.py:66-72: no q/k normalisation, softmax scale 0.25 / sqrt(64)). */
 int sdvar_model_bind_block(sdvar_model_t* m, int32_t block, const float* ada_w, const float* ada_b, const float* qkv_w,
                            const float* q_bias, const float* v_bias, const float* scale_mul, const float* proj_w,
                            const float* proj_b, const float* fc1_w, const float* fc1_b, const float* fc2_w,
@@ -88,6 +89,10 @@ int sdvar_embed_next(sdvar_model_t* m, const float* nxt, int32_t s_next, float* 
  * with the mask rows of var.py:108-113 derived from the stage table).  x (R, lsum, C) is the input and is CLOBBERED
  * (it is the residual stream); logits (R, lsum, V).  Requires kv_len == begin(s0); appends lsum keys. */
 int sdvar_stage_forward(sdvar_model_t* m, float* x, int32_t s0, int32_t n_stages, float* logits, void* stream);
+/* The same pass under an EXPLICIT additive attention mask instead of the block-causal rows: bias (lsum, kv_len + lsum) fp32, 0 or -inf, the
+ * reference's (1, 1, l, K) attn_bias.  For the ablation masks of the hand-off sampler (var.py:557-578 attn_bias_for_sdmasking /
+ * attn_bias_for_block, applied at var.py:777-804). */
+int sdvar_stage_forward_masked(sdvar_model_t* m, float* x, int32_t s0, int32_t n_stages, const float* bias, float* logits, void* stream);
 
 /* Final adaLN + vocabulary projection only (VAR.get_logits, var.py:119-125; basic_var.py:172-174) on a residual-stream tensor
  * x (R, l, C) -> logits (R, l, V); x is left untouched.  The hand-off sampler with a prefill mask takes its entry-stage logits from

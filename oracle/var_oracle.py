@@ -92,15 +92,17 @@ class OracleVAR:
         qkv = F.linear(h, sd[p + "attn.mat_qkv.weight"],
                        torch.cat((sd[p + "attn.q_bias"], torch.zeros(C), sd[p + "attn.v_bias"]))).view(R, l, 3, H, 64)
         q, k, v = qkv.permute(2, 0, 3, 1, 4).unbind(0)                       # (R, H, l, 64)
-        scale_mul = sd[p + "attn.scale_mul_1H11"].clamp_max(math.log(100.0)).exp()
-        q = F.normalize(q, dim=-1).mul(scale_mul)
-        k = F.normalize(k, dim=-1)
+        l2 = (p + "attn.scale_mul_1H11") in sd           # attn_l2_norm (basic_var.py:66-72, 101-105); False: plain attention, scale 0.25 / sqrt(64)
+        if l2:
+            scale_mul = sd[p + "attn.scale_mul_1H11"].clamp_max(math.log(100.0)).exp()
+            q = F.normalize(q, dim=-1).mul(scale_mul)
+            k = F.normalize(k, dim=-1)
         if self.kv_fp16:
             k, v = k.half().float(), v.half().float()
         if self.kv[i] is not None:
             k = torch.cat((self.kv[i][0], k), dim=2); v = torch.cat((self.kv[i][1], v), dim=2)
         self.kv[i] = (k, v)
-        o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask, scale=1.0).transpose(1, 2).reshape(R, l, C)
+        o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask, scale=1.0 if l2 else 0.25 / math.sqrt(64)).transpose(1, 2).reshape(R, l, C)
         x = x + F.linear(o, sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"]).mul_(g1)
         h = F.layer_norm(x, (C,), eps=1e-6).mul(s2.add(1)).add_(sh2)
         h = F.linear(F.gelu(F.linear(h, sd[p + "ffn.fc1.weight"], sd[p + "ffn.fc1.bias"]), approximate="tanh"),
@@ -119,9 +121,11 @@ class OracleVAR:
         return full[bg:ed, :ed].reshape(1, 1, ed - bg, ed).contiguous()
 
     # -- all blocks + head for one call (var.py:195-197, 119-125)
-    def forward(self, x: Tensor, cond: Tensor, s0: int, n_stages: int = 1) -> Tensor:
+    def forward(self, x: Tensor, cond: Tensor, s0: int, n_stages: int = 1, mask: Optional[Tensor] = None) -> Tensor:
+        """mask: explicit (1, 1, l, K) additive mask instead of the block-causal rows (the ablation masks of the hand-off sampler)."""
         assert self.kv_len() == self.begin(s0) - self.kv_base, (self.kv_len(), self.begin(s0), self.kv_base)
-        mask = self.chunk_mask(s0, n_stages)
+        if mask is None:
+            mask = self.chunk_mask(s0, n_stages)
         assert mask is None or self.kv_base == 0
         for i in range(self.depth):
             x = self._block(i, x, cond, mask)
@@ -316,13 +320,32 @@ def plain_ar(model: OracleVAR, quant: OracleQuant, label_B: Tensor, cfg: float, 
 
 
 # ------------------------------------------------------------------------------------------------ hand-off sampler
+def handoff_mask(model: OracleVAR, entry_num: int, sd_mask: int) -> Tensor:
+    """(1, 1, p, p) additive masks of var.py:557-578 cut to the prefix + entry stage (var.py:780-798).  sd_mask 1 / 2: attn_bias_for_sdmasking
+    (j <= i and not (same stage, i != j)); 4 / 5: attn_bias_for_block (same stage only); 2 and 5 set the entry stage's rows to 0."""
+    p, s0 = int(model.cum[entry_num]), model.begin(entry_num)
+    blk = torch.cat([torch.full((m,), i) for i, m in enumerate(model.lens)])[:p]
+    out = torch.full((p, p), -torch.inf)
+    for i in range(p):
+        for j in range(p):
+            if sd_mask in (1, 2):
+                if j > i or (blk[i] == blk[j] and i != j):
+                    continue
+            elif blk[i] != blk[j]:
+                continue
+            out[i, j] = 0.0
+    if sd_mask in (2, 5):
+        out[s0:p, :] = 0.0
+    return out.reshape(1, 1, p, p)
+
+
 def handoff(draft: OracleVAR, target: OracleVAR, quant: OracleQuant, label_B: Tensor, cfg: float, top_k: int, top_p: float, noise: NoiseFn,
             entry_num: int, sd_mask: int = 0, more_smooth: bool = False) -> ARTrace:
-    """SDVAR.sdvar_autoregressive_infer_cfg_sd_test3 (var.py:604-865) for sd_mask 0 and 3, up to the decode.  The draft samples stages
+    """SDVAR.sdvar_autoregressive_infer_cfg_sd_test3 (var.py:604-865), up to the decode (sd_mask 1, 2, 4, 5: as 3 with the explicit masks above).  The draft samples stages
     < entry_num (var.py:669-723); the target takes over the shared f_hat.  sd_mask 0: entry stage on an empty target cache (var.py:817-824).
     sd_mask 3: prefix + entry stage through the target blocks under the block-causal mask (var.py:789, 802-804), entry-stage logits from
     the INPUT token map (var.py:809-811, literal).  One noise stream, draw = stage index."""
-    assert sd_mask in (0, 3)
+    assert sd_mask in (0, 1, 2, 3, 4, 5)
     B, S, pns = label_B.shape[0], draft.S, draft.patch_nums
     tr = ARTrace()
     d_cond, d_lvl, d_x = draft.prologue(label_B)
@@ -350,7 +373,8 @@ def handoff(draft: OracleVAR, target: OracleVAR, quant: OracleQuant, label_B: Te
                     target.kv_base = target.begin(si)           # empty cache: the entry stage only sees itself
                     lg = target.forward(x, t_cond, si, 1)
                 else:
-                    target.forward(torch.cat(xs, dim=1), t_cond, 0, entry_num + 1)                # fills the cache; logits unused
+                    mask = None if sd_mask == 3 else handoff_mask(target, entry_num, sd_mask)
+                    target.forward(torch.cat(xs, dim=1), t_cond, 0, entry_num + 1, mask)          # fills the cache; logits unused
                     lg = target.head(x, t_cond)
             else:
                 lg = target.forward(x, t_cond, si, 1)

@@ -28,6 +28,8 @@ int embed_next(const float* nxt, const float* Ww, const float* bw, const float* 
 int attention_f32(const float* q, const void* kc, const void* vc, int kv_f16, float* out, uint16_t* outp, size_t ops, int pfmt, int R, int H, int l, int Lmax, int Ktot, int n_chunk, const int* qbeg, const int* vis, hipStream_t stream);
 int gemm_bf16x3_nt(const uint16_t* X, size_t xps, const uint16_t* W, size_t wps, const float* bias, float* out, int ldo, uint16_t* outp, size_t ops,
                    int M, int N, int K, int epi, const float* res, int ldres, const float* gate, int rows_per_gate, int gate_stride, int* defer, hipStream_t stream);
+int attention_masked(const float* q, const void* kc, const void* vc, int fmt, const float* bias, float* out, uint16_t* outp, size_t ops, int pfmt, int R, int H, int l,
+                     int Lmax, int Ktot, hipStream_t stream);
 int split_planes(const float* x, uint16_t* planes, int rows, int cols, size_t plane_stride, hipStream_t stream);
 int gemm_f16x2_nt(const uint16_t* X, size_t xps, const uint16_t* W, size_t wps, const float* wsi, const float* bias, float* out, int ldo, uint16_t* outp, size_t ops,
                   int M, int N, int K, int epi, const float* res, int ldres, const float* gate, int rows_per_gate, int gate_stride, int* defer, hipStream_t stream);
@@ -276,7 +278,8 @@ int sdvar_model_bind_block(sdvar_model_t* m, int32_t i, const float* ada_w, cons
                            const float* fc1_b, const float* fc2_w, const float* fc2_b, void* stream) {
     SDVAR_CHECK_ARG(m && i >= 0 && i < m->d.depth, "bind_block: block index %d", i);
     // ada_w == NULL: a shared_aln block, ada_b is its ada_gss (6C) and sdvar_model_bind_shared_aln supplies the Linear
-    SDVAR_CHECK_ARG(ada_b && qkv_w && q_bias && v_bias && scale_mul && proj_w && proj_b && fc1_w && fc1_b && fc2_w && fc2_b, "bind_block: null tensor");
+    // scale_mul == NULL: an attn_l2_norm=False model (basic_var.py:66-72): no q/k normalisation, softmax scale 0.25 / sqrt(head_dim)
+    SDVAR_CHECK_ARG(ada_b && qkv_w && q_bias && v_bias && proj_w && proj_b && fc1_w && fc1_b && fc2_w && fc2_b, "bind_block: null tensor");
     BlockW& b = m->blk[i];
     b.ada_w = ada_w; b.ada_b = ada_b; b.qkv_w = qkv_w; b.scale_mul = scale_mul; b.proj_w = proj_w; b.proj_b = proj_b;
     b.fc1_w = fc1_w; b.fc1_b = fc1_b; b.fc2_w = fc2_w; b.fc2_b = fc2_b;
@@ -401,7 +404,18 @@ int sdvar_embed_next(sdvar_model_t* m, const float* nxt, int32_t s_next, float* 
     return embed_next(nxt, m->word_w, m->word_b, m->lvl_pos, x, m->B, m->lens[s_next], m->C, begin_of(m, s_next), ltot, tok_off, (hipStream_t)stream);
 }
 
+static int stage_forward_impl(sdvar_model_t* m, float* x, int32_t s0, int32_t n, const float* bias, float* logits, void* stream);
+
 int sdvar_stage_forward(sdvar_model_t* m, float* x, int32_t s0, int32_t n, float* logits, void* stream) {
+    return stage_forward_impl(m, x, s0, n, nullptr, logits, stream);
+}
+
+int sdvar_stage_forward_masked(sdvar_model_t* m, float* x, int32_t s0, int32_t n, const float* bias, float* logits, void* stream) {
+    SDVAR_CHECK_ARG(bias, "stage_forward_masked: null mask");
+    return stage_forward_impl(m, x, s0, n, bias, logits, stream);
+}
+
+static int stage_forward_impl(sdvar_model_t* m, float* x, int32_t s0, int32_t n, const float* bias, float* logits, void* stream) {
     SDVAR_TRY(check_bound(m));
     SDVAR_CHECK_ARG(m->begun && x && logits, "stage_forward: model not begun or null buffers");
     SDVAR_CHECK_ARG(s0 >= 0 && n >= 1 && s0 + n <= m->S && n <= m->d.max_chunk_stages, "stage_forward: stages [%d,%d) invalid (S=%d, max chunk %d)", s0, s0 + n, m->S, m->d.max_chunk_stages);
@@ -437,7 +451,8 @@ int sdvar_stage_forward(sdvar_model_t* m, float* x, int32_t s0, int32_t n, float
         { ProfScope pp(3, 6 * dM * dC, 4 * 6 * dM * dC, s);
           SDVAR_TRY(qk_norm_append(m->qkv, b.scale_mul, m->qbuf, b.kc, b.vc, m->kv_fmt, R, lsum, H, m->Lkv, m->kv_len, &pq, s)); }
         { ProfScope pp(lsum <= 36 ? 8 : 1, 4.0 * R * H * 64.0 * lk, R * H * 64.0 * ((m->d.kv_dtype ? 4.0 : 8.0) * Ktot + 8.0 * lsum), s);
-          SDVAR_TRY(attention_f32(m->qbuf, b.kc, b.vc, m->kv_fmt, m->att, P ? m->att_p : nullptr, ps, PF, R, H, lsum, m->Lkv, Ktot, n, qbeg, vis, s)); }
+          if (bias) SDVAR_TRY(attention_masked(m->qbuf, b.kc, b.vc, m->kv_fmt, bias, m->att, P ? m->att_p : nullptr, ps, PF, R, H, lsum, m->Lkv, Ktot, s));
+          else SDVAR_TRY(attention_f32(m->qbuf, b.kc, b.vc, m->kv_fmt, m->att, P ? m->att_p : nullptr, ps, PF, R, H, lsum, m->Lkv, Ktot, n, qbeg, vis, s)); }
         { ProfScope pp(0, 2 * dM * dC * dC, 4 * (3 * dM * dC + dC * dC), s);
           if (P) { SDVAR_TRY(plane_gemm(m, m->att_p, ps, b.proj_wp, (size_t)C * C, b.wsc + 4, b.proj_b, x, C, nullptr, 0, M, C, C, EPI_GATED_RES, x, C, ada, lsum, 6 * C, dp, s));
                    if (defer) pend = PendingSplitK{ws, b.proj_b, ada, defer, lsum, 6 * C}; }

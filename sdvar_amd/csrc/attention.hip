@@ -245,6 +245,70 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(AttnArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Attention under an EXPLICIT additive mask, for the ablation masks of the hand-off sampler (models/var.py:557-578, 777-798: block-wise
+// patterns that the stage table of the kernels above cannot express).  bias (l, Ktot) fp32, 0 or -inf, shared by all rows and heads
+// (the reference's (1, 1, l, Ktot) attn_bias).  One wave per (query, head, row), lane = channel, any cache format: the sampler calls
+// this once per image batch (the prefix prefill), so it is written for clarity, not speed.
+__device__ __forceinline__ float kv_elem(const void* base, int fmt, bool is_v, size_t head_elems, int Lmax, int key, int c) {
+    // element (key, c) of the (row, head) slice that starts `head_elems` * planes into the cache
+    if (fmt == 0) return reinterpret_cast<const float*>(base)[head_elems + (size_t)key * 64 + c];
+    if (fmt == 1) return __half2float(reinterpret_cast<const __half*>(base)[head_elems + (size_t)key * 64 + c]);
+    const int NP = fmt == 2 ? 3 : (fmt == 3 ? 2 : 1);
+    const uint16_t* p = reinterpret_cast<const uint16_t*>(base) + head_elems * NP;
+    const size_t ps = (size_t)Lmax * 64;
+    size_t o;
+    if (is_v) { const int pos = (key & ~12) | ((key & 4) << 1) | ((key & 8) >> 1); o = (size_t)c * Lmax + pos; }     // V^T rows, bits 2 and 3 of the key swapped
+    else o = (size_t)key * 64 + c;
+    float v = 0.f;
+    for (int k = NP - 1; k >= 0; --k) {
+        const uint16_t u = p[k * ps + o];
+        v += (fmt == 2) ? __uint_as_float((uint32_t)u << 16) : (float)__builtin_bit_cast(_Float16, u);
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void attention_masked_kernel(const float* __restrict__ q, const void* kc, const void* vc, int fmt, const float* __restrict__ bias,
+                                                               float* out, uint16_t* outp, size_t ops, int pfmt, int R, int H, int l, int Lmax, int Ktot) {
+    const int lane = threadIdx.x & 63;
+    const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= (long long)R * H * l) return;
+    const int qi = (int)(item % l), h = (int)((item / l) % H), r = (int)(item / ((long long)l * H));
+    const size_t head = ((size_t)r * H + h) * (size_t)Lmax * 64;
+    const float qv = q[(((size_t)r * H + h) * l + qi) * 64 + lane];
+    float m_run = -INFINITY, l_run = 0.f, o = 0.f;
+    for (int key = 0; key < Ktot; ++key) {
+        const float b = bias[(size_t)qi * Ktot + key];
+        if (b == -INFINITY) continue;                                   // wave-uniform
+        const float sc = wave_sum(qv * kv_elem(kc, fmt, false, head, Lmax, key, lane)) + b;
+        const float m_new = fmaxf(m_run, sc);
+        const float alpha = expf(m_run - m_new), pexp = expf(sc - m_new);
+        l_run = l_run * alpha + pexp;
+        o = o * alpha + pexp * kv_elem(vc, fmt, true, head, Lmax, key, lane);
+        m_run = m_new;
+    }
+    const float res = o / l_run;
+    const int row = r * l + qi, col = h * 64 + lane;
+    if (outp) {
+        const size_t oo = kb_index(row, col, R * l);
+        if (pfmt == PLANES_F16X2) { uint16_t hh, ll; split2h(res, hh, ll); outp[oo] = hh; outp[ops + oo] = ll; }
+        else { uint16_t p0, p1, p2; split3(res, p0, p1, p2); outp[oo] = p0; outp[ops + oo] = p1; outp[2 * ops + oo] = p2; }
+    } else {
+        out[(size_t)row * (H * 64) + col] = res;
+    }
+}
+
+int attention_masked(const float* q, const void* kc, const void* vc, int fmt, const float* bias, float* out, uint16_t* outp, size_t ops, int pfmt, int R, int H, int l,
+                     int Lmax, int Ktot, hipStream_t stream) {
+    SDVAR_CHECK_ARG(q && kc && vc && bias && (out || outp), "attention_masked: null operand");
+    SDVAR_CHECK_ARG(fmt >= 0 && fmt <= 4 && R > 0 && H > 0 && l > 0 && Ktot >= l && Ktot <= Lmax, "attention_masked: fmt=%d l=%d Ktot=%d Lmax=%d", fmt, l, Ktot, Lmax);
+    SDVAR_CHECK_ARG(!outp || pfmt == PLANES_BF16X3 || pfmt == PLANES_F16X2, "attention_masked: plane format %d", pfmt);
+    const long long items = (long long)R * H * l;
+    hipLaunchKernelGGL(attention_masked_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, q, kc, vc, fmt, bias, out, outp, ops, pfmt, R, H, l, Lmax, Ktot);
+    SDVAR_LAUNCH_CHECK();
+    return SDVAR_OK;
+}
+
 int attention_bf16x3(const float* q, const void* kc, const void* vc, float* out, uint16_t* outp, size_t ops, int pfmt, int R, int H, int l, int Lp,
                      int Ktot, int n_chunk, const int* qbeg, const int* vis, hipStream_t stream);
 

@@ -195,12 +195,15 @@ __global__ __launch_bounds__(256) void qk_norm_append_kernel(const float* __rest
         const float* p = qkv + (size_t)row * 3 * C + h * 64 + lane;
         q = p[0]; k = p[C]; v = p[2 * C];
     }
-    const float qn = fmaxf(sqrtf(wave_sum(q * q)), 1e-12f);
-    const float kn = fmaxf(sqrtf(wave_sum(k * k)), 1e-12f);
-    const float sm = expf(fminf(scale_mul[h], 4.605170249938965f));    // log(100) as the reference's float32 clamp
-    q_out[(((size_t)r * H + h) * l + t) * 64 + lane] = (q / qn) * sm;
+    // attn_l2_norm=False models (scale_mul == null, basic_var.py:71-72): q and k stay as they are and the softmax scale 0.25 / sqrt(64) = 2^-5 is
+    // folded into q (exact)
+    const bool l2 = scale_mul != nullptr;
+    const float qn = l2 ? fmaxf(sqrtf(wave_sum(q * q)), 1e-12f) : 1.0f;
+    const float kn = l2 ? fmaxf(sqrtf(wave_sum(k * k)), 1e-12f) : 1.0f;
+    const float sm = l2 ? expf(fminf(scale_mul[h], 4.605170249938965f)) : 0.03125f;    // log(100) as the reference's float32 clamp
+    q_out[(((size_t)r * H + h) * l + t) * 64 + lane] = l2 ? (q / qn) * sm : q * sm;
     const size_t c = (((size_t)r * H + h) * Lmax + pos0 + t) * 64 + lane;
-    k_cache[c] = (KV)(k / kn);           // fp16 cache: round-to-nearest-even, like torch's .half()
+    k_cache[c] = (KV)(l2 ? k / kn : k);  // fp16 cache: round-to-nearest-even, like torch's .half()
     v_cache[c] = (KV)v;
 }
 
@@ -223,7 +226,8 @@ __global__ __launch_bounds__(256) void qk_norm_append_planes_kernel(const float*
     const int pb = max(P0, pos0), pe = min(P0 + 32, pos0 + l);
     const int C = H * 64;
     const size_t head = ((size_t)r * H + h) * NP * (size_t)Lp * 64, ps = (size_t)Lp * 64;
-    const float sm = expf(fminf(scale_mul[h], 4.605170249938965f));
+    const bool l2 = scale_mul != nullptr;            // attn_l2_norm=False: raw q (x 2^-5, the softmax scale) and raw k (basic_var.py:71-72)
+    const float sm = l2 ? expf(fminf(scale_mul[h], 4.605170249938965f)) : 0.03125f;
     // wave w owns positions pb + w, + 4, ... (at most 8); four of them are in flight at a time (their loads - up to 3 x split slab reads
     // each - are independent, the wave reductions are not the bottleneck)
     for (int pos4 = pb + wave; pos4 < pe; pos4 += 16) {
@@ -249,17 +253,17 @@ __global__ __launch_bounds__(256) void qk_norm_append_planes_kernel(const float*
             const int pos = pos4 + 4 * u;
             if (pos >= pe) continue;
             const int t = pos - pos0;
-            const float qn = fmaxf(sqrtf(wave_sum(q[u] * q[u])), 1e-12f);
-            const float kn = fmaxf(sqrtf(wave_sum(k[u] * k[u])), 1e-12f);
-            q_out[(((size_t)r * H + h) * l + t) * 64 + lane] = (q[u] / qn) * sm;
+            const float qn = l2 ? fmaxf(sqrtf(wave_sum(q[u] * q[u])), 1e-12f) : 1.0f;
+            const float kn = l2 ? fmaxf(sqrtf(wave_sum(k[u] * k[u])), 1e-12f) : 1.0f;
+            q_out[(((size_t)r * H + h) * l + t) * 64 + lane] = l2 ? (q[u] / qn) * sm : q[u] * sm;
             uint16_t* pk = k_cache + head + (size_t)pos * 64 + lane;
             if (fmt == 2) {
                 uint16_t k0, k1, k2;
-                split3(k[u] / kn, k0, k1, k2);
+                split3(l2 ? k[u] / kn : k[u], k0, k1, k2);
                 pk[0] = k0; pk[ps] = k1; pk[2 * ps] = k2;
             } else {
                 uint16_t kh, kl;
-                split2h(k[u] / kn, kh, kl);
+                split2h(l2 ? k[u] / kn : k[u], kh, kl);
                 pk[0] = kh;
                 if (fmt == 3) pk[ps] = kl;
             }

@@ -69,6 +69,7 @@ _SIGNATURES = {
     "sdvar_head_forward": (_I, [_P, _P, _I, _P, _P]),
     "sdvar_embed_next": (_I, [_P, _P, _I, _P, _I, _I, _P]),
     "sdvar_stage_forward": (_I, [_P, _P, _I, _I, _P, _P]),
+    "sdvar_stage_forward_masked": (_I, [_P, _P, _I, _I, _P, _P, _P]),
     "sdvar_quant_create": (_I, [_I, C.POINTER(_I), _I, _I, _I, _I, C.POINTER(_P)]),
     "sdvar_quant_destroy": (_I, [_P]),
     "sdvar_quant_bind": (_I, [_P, _P, C.POINTER(_P), C.POINTER(_P)]),
@@ -187,7 +188,8 @@ class ModelCtx:
             _check(self.lib.sdvar_model_bind_block(
                 self.h, i, None if shared else w(p + "ada_lin.1.weight"), w(p + "ada_gss") if shared else w(p + "ada_lin.1.bias"),
                 w(p + "attn.mat_qkv.weight"), w(p + "attn.q_bias"),
-                w(p + "attn.v_bias"), w(p + "attn.scale_mul_1H11"), w(p + "attn.proj.weight"), w(p + "attn.proj.bias"),
+                w(p + "attn.v_bias"), w(p + "attn.scale_mul_1H11") if (p + "attn.scale_mul_1H11") in sd else None,      # absent: attn_l2_norm=False (basic_var.py:66-72)
+                w(p + "attn.proj.weight"), w(p + "attn.proj.bias"),
                 w(p + "ffn.fc1.weight"), w(p + "ffn.fc1.bias"), w(p + "ffn.fc2.weight"), w(p + "ffn.fc2.bias"), st))
         _check(self.lib.sdvar_model_bind_head(self.h, w("head_nm.ada_lin.1.weight"), w("head_nm.ada_lin.1.bias"), w("head.weight"), w("head.bias"), st))
 
@@ -210,8 +212,12 @@ class ModelCtx:
     def embed_next(self, nxt: torch.Tensor, s_next: int, x: torch.Tensor, ltot: int, tok_off: int):
         _check(self.lib.sdvar_embed_next(self.h, _ptr(nxt), s_next, _ptr(x), ltot, tok_off, _stream()))
 
-    def forward(self, x: torch.Tensor, s0: int, n: int, logits: torch.Tensor):
-        _check(self.lib.sdvar_stage_forward(self.h, _ptr(x), s0, n, _ptr(logits), _stream()))
+    def forward(self, x: torch.Tensor, s0: int, n: int, logits: torch.Tensor, bias: Optional[torch.Tensor] = None):
+        """All blocks + head over stages s0 .. s0+n-1.  bias: explicit additive mask (l, K) instead of the block-causal rows (mask ablations)."""
+        if bias is None:
+            _check(self.lib.sdvar_stage_forward(self.h, _ptr(x), s0, n, _ptr(logits), _stream()))
+        else:
+            _check(self.lib.sdvar_stage_forward_masked(self.h, _ptr(x), s0, n, _ptr(bias), _ptr(logits), _stream()))
 
     def kv_len(self) -> int:
         return self.lib.sdvar_kv_len(self.h)
@@ -397,6 +403,23 @@ def cfg_sample(logits: torch.Tensor, B: int, l: int, V: int, t: float, top_k: in
                                 _ptr(dbg_masked) if dbg_masked is not None else None, _stream()))
 
 
+def handoff_mask(lad: Ladder, entry_num: int, sd_mask: int) -> torch.Tensor:
+    """The (pindex, pindex) additive mask of SDVAR.sdvar_autoregressive_infer_cfg_sd_test3 for sd_mask 1, 2, 4, 5 (var.py:557-578, 777-798), pindex =
+    tokens of stages 0 .. entry_num.  attn_bias_for_sdmasking: token i sees itself and every token of EARLIER stages (not its own stage's other
+    tokens); attn_bias_for_block: token i sees exactly its own stage.  Masks 2 and 5 open the entry stage's rows completely."""
+    p, s0 = lad.cum[entry_num], lad.begin(entry_num)
+    blk = torch.cat([torch.full((n,), i) for i, n in enumerate(lad.lens)])[:p]
+    bi, bj = blk.view(p, 1), blk.view(1, p)
+    if sd_mask in (1, 2):
+        ok = (bj < bi) | torch.eye(p, dtype=torch.bool)
+    else:
+        ok = bi == bj
+    m = torch.where(ok, 0.0, float("-inf")).to(torch.float32)
+    if sd_mask in (2, 5):
+        m[s0:p, :] = 0.0
+    return m.contiguous()
+
+
 GUMBEL_DRAW = 0x40000000      # Philox `draw` of a stage's gumbel noise = its sampler draw | GUMBEL_DRAW (the reference draws it right after the multinomial)
 
 
@@ -557,8 +580,8 @@ class Sampler:
         B, V, S, L, lens = labels.shape[0], t.V, lad.S, lad.L, lad.lens
         if not (0 <= entry_num <= S):
             raise SdvarError(f"entry_num {entry_num} outside [0, {S}]")
-        if sd_mask not in (0, 3):
-            raise NotImplementedError("sd_mask 1, 2, 4, 5 (block-wise ablation masks of var.py:557-578) are not built; 0 and 3 are")
+        if sd_mask not in (0, 1, 2, 3, 4, 5):
+            raise SdvarError(f"sd_mask {sd_mask}: the reference defines 0 .. 5 (var.py:777-798)")
         res = SampleResult(ids=self.ids[:B], f_hat=self.f_work[:B])
         prefill = sd_mask != 0 and entry_num < S
         pindex = lad.cum[entry_num] if entry_num < S else L
@@ -586,7 +609,8 @@ class Sampler:
                         ent = self._buf("x_entry", 2 * B * l * t.Cw)             # the entry stage's slice of the input map, kept: the forward clobbers x
                         src = x_pre[:2 * B * pindex * t.Cw].view(2 * B, pindex, t.Cw)[:, lad.begin(si):pindex]
                         ent[:2 * B * l * t.Cw].view(2 * B, l, t.Cw).copy_(src)
-                        t.forward(x_pre, 0, entry_num + 1, self._buf("logits_prefill", 2 * B * pindex * V))   # fills the cache; its logits are not used
+                        bias = None if sd_mask == 3 else handoff_mask(lad, entry_num, sd_mask).to(self.dev)         # 3 = the block-causal rows the kernels derive themselves
+                        t.forward(x_pre, 0, entry_num + 1, self._buf("logits_prefill", 2 * B * pindex * V), bias)   # fills the cache; its logits are not used
                         t.head_forward(ent, l, self.logits_t)
                     else:
                         t.kv_set_origin(si)

@@ -20,10 +20,11 @@ from .vqvae import VQVAE
 
 
 class _SelfAttention(nn.Module):                   # parameter names of basic_var.py:58-87
-    def __init__(self, C, H):
+    def __init__(self, C, H, attn_l2_norm=True):
         super().__init__()
-        self.num_heads, self.head_dim = H, C // H
-        self.scale_mul_1H11 = nn.Parameter(torch.full((1, H, 1, 1), 4.0).log())
+        self.num_heads, self.head_dim, self.attn_l2_norm = H, C // H, attn_l2_norm
+        if attn_l2_norm:                                # basic_var.py:66-72: otherwise plain scaled dot-product attention, scale 0.25 / sqrt(head_dim)
+            self.scale_mul_1H11 = nn.Parameter(torch.full((1, H, 1, 1), 4.0).log())
         self.mat_qkv = nn.Linear(C, 3 * C, bias=False)
         self.q_bias, self.v_bias = nn.Parameter(torch.zeros(C)), nn.Parameter(torch.zeros(C))
         self.register_buffer("zero_k_bias", torch.zeros(C))
@@ -44,9 +45,9 @@ class _FFN(nn.Module):
 
 
 class _Block(nn.Module):
-    def __init__(self, C, H, shared_aln=False):
+    def __init__(self, C, H, shared_aln=False, attn_l2_norm=True):
         super().__init__()
-        self.attn, self.ffn = _SelfAttention(C, H), _FFN(C)
+        self.attn, self.ffn = _SelfAttention(C, H, attn_l2_norm), _FFN(C)
         self.shared_aln = shared_aln
         if shared_aln:                                                   # basic_var.py:143-144
             self.ada_gss = nn.Parameter(torch.randn(1, 1, 6, C) / C ** 0.5)
@@ -66,8 +67,6 @@ class VAR(nn.Module):
                  patch_nums=(1, 2, 3, 4, 5, 6, 8, 10, 13, 16), flash_if_available=True, fused_if_available=True):
         super().__init__()
         assert embed_dim % num_heads == 0
-        if not attn_l2_norm:
-            raise NotImplementedError("attn_l2_norm=False is not built: the factories default to True (models/__init__.py:22)")
         if embed_dim != 64 * num_heads or num_heads != depth or mlp_ratio != 4.:
             raise NotImplementedError("the HIP path assumes head_dim 64, heads == depth, mlp_ratio 4 (models/__init__.py:26-27)")
         self.Cvae, self.V = vae_local.Cvae, vae_local.vocab_size
@@ -87,7 +86,8 @@ class VAR(nn.Module):
         self.lvl_embed = nn.Embedding(lad.S, C)
         self.shared_aln = bool(shared_aln)
         self.shared_ada_lin = nn.Sequential(nn.SiLU(inplace=False), nn.Linear(C, 6 * C)) if shared_aln else nn.Identity()   # var.py:81
-        self.blocks = nn.ModuleList([_Block(C, num_heads, shared_aln) for _ in range(depth)])
+        self.attn_l2_norm = bool(attn_l2_norm)
+        self.blocks = nn.ModuleList([_Block(C, num_heads, shared_aln, self.attn_l2_norm) for _ in range(depth)])
         lvl = torch.cat([torch.full((n,), i, dtype=torch.int64) for i, n in enumerate(lad.lens)]).view(1, self.L)
         self.register_buffer("lvl_1L", lvl)
         d = lvl.view(1, self.L, 1)
@@ -190,7 +190,7 @@ class VAR(nn.Module):
         adaLN gamma rows x init_adaln_gamma, proj / fc2 / sqrt(2 depth), zero biases.  conv_std_or_gain only concerns convolutions, of
         which a VAR has none (var.py:275)."""
         from .weights import var_state_dict
-        sd = var_state_dict(self.depth, self.patch_nums, "perf", seed, V=self.V, Cvae=self.Cvae, num_classes=self.num_classes, shared_aln=self.shared_aln,
+        sd = var_state_dict(self.depth, self.patch_nums, "perf", seed, V=self.V, Cvae=self.Cvae, num_classes=self.num_classes, shared_aln=self.shared_aln, attn_l2_norm=self.attn_l2_norm,
                             init_adaln=init_adaln, init_adaln_gamma=init_adaln_gamma, init_head=init_head, init_std=init_std)
         self.load_state_dict({k: v.to(self._device()) for k, v in sd.items()})
 
@@ -346,7 +346,8 @@ class SDVAR(nn.Module):
     def sdvar_autoregressive_infer_cfg_sd_test3(self, B: int, label_B: Optional[Union[int, torch.LongTensor]], g_seed: Optional[int] = None, cfg: float = 1.5,
                                                 top_k: int = 0, top_p: float = 0.0, more_smooth: bool = False, entry_num: int = 10, sd_mask: int = 0) -> torch.Tensor:
         """var.py:604-865: the draft samples stages 0 .. entry_num-1, the target continues from the shared f_hat.  One generator, the target
-        model's (var.py:641-642); labels as in var.py:647-656.  sd_mask 0 and 3 are built (engine.Sampler.handoff)."""
+        model's (var.py:641-642); labels as in var.py:647-656.  All six sd_mask values are built (engine.Sampler.handoff;
+        1, 2, 4, 5 run the prefill under the explicit block-wise masks of var.py:557-578)."""
         t = self.target_model
         rng = None
         if g_seed is not None:

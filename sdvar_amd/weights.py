@@ -45,7 +45,7 @@ def _tn(g: np.random.Generator, shape, std) -> torch.Tensor:
 
 
 def var_state_dict(depth: int, patch_nums: Sequence[int], mode: str = "perf", seed: int = 1234,
-                   V: int = 4096, Cvae: int = 32, num_classes: int = 1000, shared_aln: bool = False, init_adaln: float = 0.5,
+                   V: int = 4096, Cvae: int = 32, num_classes: int = 1000, shared_aln: bool = False, attn_l2_norm: bool = True, init_adaln: float = 0.5,
                    init_adaln_gamma: float = 1e-5, init_head: float = 0.02, init_std: float = -1) -> "OrderedDict[str, torch.Tensor]":
     """init_* are VAR.init_weights' arguments (var.py:261-311; factory defaults models/__init__.py:24) and shape the 'perf' init only."""
     lad = as_ladder(patch_nums)
@@ -73,8 +73,9 @@ def var_state_dict(depth: int, patch_nums: Sequence[int], mode: str = "perf", se
     w("lvl_embed.weight", (S, C), 0.5)
     for i in range(depth):
         p = f"blocks.{i}."
-        sd[p + "attn.scale_mul_1H11"] = torch.full((1, H, 1, 1), math.log(4.0)) + (
-            _n(_gen(sseed, p + "attn.scale_mul_1H11"), (1, H, 1, 1), 0.3) if stress else 0.0)
+        if attn_l2_norm:                 # basic_var.py:66-72: the parameter only exists with q/k L2 normalisation
+            sd[p + "attn.scale_mul_1H11"] = torch.full((1, H, 1, 1), math.log(4.0)) + (
+                _n(_gen(sseed, p + "attn.scale_mul_1H11"), (1, H, 1, 1), 0.3) if stress else 0.0)
         b(p + "attn.q_bias", (C,), 0.1); b(p + "attn.v_bias", (C,), 0.1)
         sd[p + "attn.zero_k_bias"] = torch.zeros(C)
         w(p + "attn.mat_qkv.weight", (3 * C, C), 1 / math.sqrt(C))

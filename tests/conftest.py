@@ -39,11 +39,11 @@ def rnd(seed, shape, scale=1.0):
 _SD_CACHE = {}
 
 
-def state_dicts(depth, patch_nums, mode="stress", seed=1234, vae=True, shared_aln=False):
+def state_dicts(depth, patch_nums, mode="stress", seed=1234, vae=True, shared_aln=False, attn_l2_norm=True):
     from sdvar_amd.weights import var_state_dict, vae_state_dict
-    key = (depth, tuple(patch_nums), mode, seed, shared_aln)
+    key = (depth, tuple(patch_nums), mode, seed, shared_aln, attn_l2_norm)
     if key not in _SD_CACHE:
-        _SD_CACHE[key] = var_state_dict(depth, patch_nums, mode, seed, shared_aln=shared_aln)
+        _SD_CACHE[key] = var_state_dict(depth, patch_nums, mode, seed, shared_aln=shared_aln, attn_l2_norm=attn_l2_norm)
     vkey = ("vae", tuple(patch_nums), mode, seed)
     if vae and vkey not in _SD_CACHE:
         _SD_CACHE[vkey] = vae_state_dict(patch_nums, mode, seed, with_encoder=False)

@@ -104,6 +104,22 @@ class PortableExponential:
         torch.Tensor.exponential_ = self.orig
 
 
+class CpuDeviceProxy:
+    """sd_test3 hard-codes `torch.device("cuda:0")` for sd_mask 1, 2, 4, 5 (var.py:737, 781-798): there is no GPU in the build container, so for
+    the duration of one call models.var sees a `torch` whose .device(...) answers CPU and which is the real torch in every other respect."""
+    class _T:
+        def __getattr__(self, n): return getattr(torch, n)
+        def device(self, *a, **k): return torch.device("cpu")
+
+    def __enter__(self):
+        self.orig = ref_var.torch
+        ref_var.torch = self._T()
+        return self
+
+    def __exit__(self, *exc):
+        ref_var.torch = self.orig
+
+
 def capture_fhat(vae):
     box = {}
     orig = vae.fhat_to_img
@@ -114,9 +130,9 @@ def capture_fhat(vae):
     return box, (lambda: setattr(vae, "fhat_to_img", orig))
 
 
-def build_ref(depth, patch_nums, mode, seed, shared_aln=False):
-    vae, var = ref_models.build_vae_var(device="cpu", patch_nums=patch_nums, depth=depth, shared_aln=shared_aln)
-    sd_var = var_state_dict(depth, patch_nums, mode, seed, shared_aln=shared_aln)
+def build_ref(depth, patch_nums, mode, seed, shared_aln=False, attn_l2_norm=True):
+    vae, var = ref_models.build_vae_var(device="cpu", patch_nums=patch_nums, depth=depth, shared_aln=shared_aln, attn_l2_norm=attn_l2_norm)
+    sd_var = var_state_dict(depth, patch_nums, mode, seed, shared_aln=shared_aln, attn_l2_norm=attn_l2_norm)
     sd_vae = vae_state_dict(patch_nums, mode, seed)
     var.load_state_dict(sd_var, strict=True)       # proves the key/shape contract of sdvar_amd.weights
     vae.load_state_dict(sd_vae, strict=True)
@@ -148,9 +164,9 @@ def pick_seed(run, start=0, tries=60):
     raise RuntimeError(f"no seed with margin >= {MIN_MARGIN}: best {best}")
 
 
-def plain_ar_fixture(name, depth, patch_nums, B, labels, cfg, top_k, top_p, g_seed, mode, wseed, store_logits_rows=2, shared_aln=False):
+def plain_ar_fixture(name, depth, patch_nums, B, labels, cfg, top_k, top_p, g_seed, mode, wseed, store_logits_rows=2, shared_aln=False, attn_l2_norm=True):
     t0 = time.time()
-    vae, var, sd_var, sd_vae = build_ref(depth, patch_nums, mode, wseed, shared_aln)
+    vae, var, sd_var, sd_vae = build_ref(depth, patch_nums, mode, wseed, shared_aln, attn_l2_norm)
     label_B = torch.tensor(labels, dtype=torch.int64)
     V = 4096
     model = orc.OracleVAR(sd_var, depth, patch_nums)
@@ -159,7 +175,7 @@ def plain_ar_fixture(name, depth, patch_nums, B, labels, cfg, top_k, top_p, g_se
         lambda d, B_, l, V_: exponential_noise(sd_, d, B_, l, V_)), keep=False).margins), start=g_seed)
     print(f"[golden] {name}: seed {g_seed} (min margin {m0:.2e})")
     out = dict(depth=depth, patch_nums=np.array(patch_nums), B=B, labels=np.array(labels), cfg=cfg, top_k=top_k, top_p=top_p,
-               g_seed=g_seed, mode=mode, wseed=wseed, shared_aln=int(shared_aln),
+               g_seed=g_seed, mode=mode, wseed=wseed, shared_aln=int(shared_aln), attn_l2_norm=int(attn_l2_norm),
                w_digest=digest(sd_var["head.weight"]), vae_digest=digest(sd_vae["quantize.embedding.weight"]))
 
     # (a) the reference with its own generator on THIS host
@@ -393,6 +409,7 @@ def handoff_fixture():
     labels = torch.tensor([3, 977])
     V = 4096
     cases = [(5, 0), (5, 3), (0, 3), (8, 0)]
+    mask_cases = [(5, 1), (5, 2), (5, 4), (5, 5)]          # block-wise ablation masks (var.py:557-578): stored with their own margins, see below
 
     def all_margins(seed):
         nf = orc.array_noise(lambda d, B_, l, V_: exponential_noise(seed, d, B_, l, V_))
@@ -418,6 +435,23 @@ def handoff_fixture():
         assert (img - orc.decode_image(sd_v, tr.f_hat)).abs().max().item() <= 1e-4
         out[f"e{entry}_m{mask}_ids"] = np.concatenate([i.numpy().astype(np.int16) for i in rec.ids], 1)
         out[f"e{entry}_m{mask}_f_hat"] = box["f_hat"].numpy()
+    # the reference's mask tensors themselves (built in SDVAR.__init__ on the CPU) against the restated construction
+    for mk, attr in ((1, "attn_bias_for_sdmasking"), (4, "attn_bias_for_block")):
+        assert torch.equal(orc.handoff_mask(ot, 9, mk), getattr(sd, attr)), attr
+    for entry, mask in mask_cases:
+        box, undo = capture_fhat(vae)
+        with Recorder() as rec, PortableMultinomial(SEED, B, V), CpuDeviceProxy():
+            sd.sdvar_autoregressive_infer_cfg_sd_test3(B=B, label_B=labels, g_seed=SEED, cfg=1.5, top_k=900, top_p=0.96, entry_num=entry, sd_mask=mask)
+        undo()
+        tr = orc.handoff(od, ot, oq, labels, 1.5, 900, 0.96, nfn, entry, mask)
+        for s in range(10):
+            assert torch.equal(rec.ids[s], tr.ids[s]), ("sd_test3 mask", entry, mask, s)
+        assert (box["f_hat"] - tr.f_hat).abs().max().item() <= 1e-5
+        out[f"e{entry}_m{mask}_ids"] = np.concatenate([i.numpy().astype(np.int16) for i in rec.ids], 1)
+        out[f"e{entry}_m{mask}_f_hat"] = box["f_hat"].numpy()
+        out[f"e{entry}_m{mask}_margin"] = min(tr.margins)
+        print(f"[golden] sd_handoff mask {mask}: ok, min margin {min(tr.margins):.2e}")
+    out["mask_cases"] = np.array(mask_cases)
     # more_smooth=True through the hand-off sampler (var.py:696-702, 838-847): both models mix the codebook softly
     box, undo = capture_fhat(vae)
     with Recorder() as rec, PortableMultinomial(SEED, B, V) as pm, PortableExponential(pm):
@@ -501,6 +535,8 @@ if __name__ == "__main__":
         plain_ar_fixture("ar_d4_256_notopkp", 4, LADDER_256, 2, [1000, 5], 1.5, 0, 0.0, 3, "stress", 1234)
     if "all" in which or "sharedaln" in which:       # SharedAdaLin models (var.py:16-19, 81): the reference built with shared_aln=True
         plain_ar_fixture("ar_d4_256_sharedaln", 4, LADDER_256, 2, [3, 977], 1.5, 900, 0.96, 0, "stress", 1234, shared_aln=True)
+    if "all" in which or "nol2" in which:            # attn_l2_norm=False (basic_var.py:66-72): plain scaled dot-product attention
+        plain_ar_fixture("ar_d4_256_nol2", 4, LADDER_256, 2, [3, 977], 1.5, 900, 0.96, 0, "stress", 1234, attn_l2_norm=False)
     if "all" in which or "sd" in which: sd_fixture()
     if "all" in which or "handoff" in which: handoff_fixture()
     if "all" in which or "smooth" in which: smooth_fixture()

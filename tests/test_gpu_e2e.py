@@ -30,12 +30,13 @@ def _flip_report(ids_hip, ids_ref, lad):
 
 
 @pytest.mark.parametrize("gm", GEMM_MODES)
-@pytest.mark.parametrize("name", ["ar_d4_256_stress", "ar_d6_256_stress", "ar_d4_512_stress", "ar_d4_256_notopkp", "ar_d4_256_sharedaln"])
+@pytest.mark.parametrize("name", ["ar_d4_256_stress", "ar_d6_256_stress", "ar_d4_512_stress", "ar_d4_256_notopkp", "ar_d4_256_sharedaln", "ar_d4_256_nol2"])
 def test_plain_ar_vs_reference_fixture(dev, name, gm):
     g = golden(name)
     depth, pns = int(g["depth"]), tuple(int(p) for p in g["patch_nums"])
     lad = as_ladder(pns)
-    sd_var, sd_vae = state_dicts(depth, pns, str(g["mode"]), int(g["wseed"]), shared_aln=bool(int(g["shared_aln"])) if "shared_aln" in g else False)
+    sd_var, sd_vae = state_dicts(depth, pns, str(g["mode"]), int(g["wseed"]), shared_aln=bool(int(g["shared_aln"])) if "shared_aln" in g else False,
+                                    attn_l2_norm=bool(int(g["attn_l2_norm"])) if "attn_l2_norm" in g else True)
     B = int(g["B"])
     ctx = E.ModelCtx(sd_var, depth, pns, B, 1, dev, gemm_mode=gm); qc = E.QuantCtx(sd_vae, pns, B, dev)
     smp = E.Sampler(ctx, qc)
@@ -393,3 +394,20 @@ def test_run_ahead_partial_batch_and_repeated_calls(dev, pair):
         b = smp.spec_decode(labels, 1.5, gamma, 900, 0.96, E.Noise("device", seed), thr=thr, run_ahead=True)
         assert torch.equal(b.ids.cpu(), ids_a), (gamma, thr)
         assert b.stats["rounds"] == st_a["rounds"] and b.stats["target_calls"] == st_a["target_calls"] and b.stats["draft_stage_calls"] == st_a["draft_stage_calls"]
+
+
+def test_attn_l2_norm_false_module_api(dev):
+    """build_vae_var(attn_l2_norm=False) (basic_var.py:66-72: no scale_mul parameter, softmax scale 0.25 / sqrt(64)) samples the ids of the
+    reference fixture through the module container."""
+    import sdvar_amd
+    g = golden("ar_d4_256_nol2")
+    pns = tuple(int(p) for p in g["patch_nums"])
+    sd_var, sd_vae = state_dicts(4, pns, str(g["mode"]), int(g["wseed"]), attn_l2_norm=False)
+    vae, var = sdvar_amd.build_vae_var(device=dev, depth=4, attn_l2_norm=False)
+    assert not any("scale_mul" in k for k in var.state_dict())
+    var.load_state_dict({k: v.to(dev) for k, v in sd_var.items()})
+    vae.load_state_dict({k: v.to(dev) for k, v in sd_vae.items()}, strict=False)
+    var.noise_kind = "host"
+    var.autoregressive_infer_cfg(B=int(g["B"]), label_B=torch.from_numpy(g["labels"]).long().to(dev), g_seed=int(g["g_seed"]), cfg=float(g["cfg"]),
+                                 top_k=int(g["top_k"]), top_p=float(g["top_p"]))
+    assert np.array_equal(var.last_result.ids.cpu().numpy(), g["ids"].astype(np.int64))

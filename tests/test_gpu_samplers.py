@@ -31,12 +31,22 @@ def pair6(dev, request):
 
 
 # ------------------------------------------------------------------------------------------------ f4: hand-off sampler
+def test_handoff_masks_match_the_reference_tensors():
+    """engine.handoff_mask == the oracle's restatement, which make_golden.py checked against the reference's own attn_bias_for_sdmasking /
+    attn_bias_for_block tensors (var.py:557-578)."""
+    lad = as_ladder(LADDER_256)
+    o = orc.OracleVAR(state_dicts(2, LADDER_256)[0], 2, LADDER_256)
+    for entry in (0, 3, 5, 9):
+        for mk in (1, 2, 4, 5):
+            assert torch.equal(E.handoff_mask(lad, entry, mk), orc.handoff_mask(o, entry, mk)[0, 0]), (entry, mk)
+
+
 def test_handoff_vs_reference_fixture(dev, pair6):
     smp, _ = pair6
     g, gc = golden("sd_handoff"), golden("sd_components")
     labels = torch.from_numpy(g["labels"]).long().to(dev)
     SEED = int(g["seed"])
-    for entry, mask in g["cases"]:
+    for entry, mask in list(g["cases"]) + list(g["mask_cases"]):          # mask_cases: sd_mask 1, 2, 4, 5 through the explicit-mask attention
         res = smp.handoff(labels, 1.5, 900, 0.96, E.Noise("host", SEED), int(entry), int(mask))
         assert np.array_equal(res.ids.cpu().numpy(), g[f"e{entry}_m{mask}_ids"].astype(np.int64)), (entry, mask)
         np.testing.assert_allclose(res.f_hat.cpu().numpy(), g[f"e{entry}_m{mask}_f_hat"], atol=1e-4)
@@ -73,8 +83,10 @@ def test_handoff_api_and_more_smooth(dev):
     ids = sd.last_result.ids.cpu().numpy()
     assert np.array_equal(ids[:, :91], g["e5_m0_smooth_ids"].astype(np.int64)[:, :91])
     assert np.abs(sd.last_result.f_hat.cpu().numpy() - g["e5_m0_smooth_f_hat"]).max() <= 0.5
-    with pytest.raises(NotImplementedError):
-        sd.sdvar_autoregressive_infer_cfg_sd_test3(B=2, label_B=labels, g_seed=SEED, entry_num=5, sd_mask=4)
+    sd.sdvar_autoregressive_infer_cfg_sd_test3(B=2, label_B=labels, g_seed=SEED, cfg=1.5, top_k=900, top_p=0.96, entry_num=5, sd_mask=4)
+    assert np.array_equal(sd.last_result.ids.cpu().numpy(), g["e5_m4_ids"].astype(np.int64))
+    with pytest.raises(E.SdvarError):
+        sd.sdvar_autoregressive_infer_cfg_sd_test3(B=2, label_B=labels, g_seed=SEED, entry_num=5, sd_mask=7)
 
 
 def test_draft_round1_reference_fixture_on_gpu(dev, pair6):
