@@ -7,9 +7,9 @@ Units and corrections as /opt/skills/guides/MI355X_MICROARCH.md prescribes: both
 requests of wide streaming reads at 64 bytes and is doubled; WRITE_SIZE is exact for 16-byte-per-lane stores."""
 import csv, glob, json, sys, collections
 
-CLASSES = [("gemm", ("gemm_bf16x3", "gemm_f32_nt")), ("splitk_reduce", ("splitk_reduce",)), ("ln_modulate", ("ln_modulate",)),
-           ("qk_norm_append", ("qk_norm_append",)), ("attention", ("attention_bf16x3", "attention_f32")), ("sampler", ("cfg_sample",)),
-           ("decoder_conv", ("conv_bf16x3", "conv_reduce")), ("decoder_rows", ("prep_planes", "gn_partial", "gn_finalize", "vae_attn", "convout", "rows_from_nchw"))]
+CLASSES = [("gemm", ("gemm_f16x2", "gemm_bf16x3", "gemm_f32_nt")), ("splitk_reduce", ("splitk_reduce",)), ("ln_modulate", ("ln_modulate",)),
+           ("qk_norm_append", ("qk_norm_append",)), ("attention", ("attention_f16x2", "attention_bf16x3", "attention_f32")), ("sampler", ("cfg_sample",)),
+           ("decoder_conv", ("conv_f16x2", "conv_bf16x3", "conv_reduce")), ("decoder_rows", ("prep_planes", "gn_partial", "gn_finalize", "vae_attn", "convout", "rows_from_nchw"))]
 
 
 def cls(name):
@@ -31,14 +31,19 @@ def load(d, counter):
     return acc
 
 
-fd, wd, out = sys.argv[1:4]
-F, W = load(fd, "FETCH_SIZE"), load(wd, "WRITE_SIZE")
-res = {"_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline "
-                "--no-extra-modes --serial-decode; KB units; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests at 64 B)"}
-for c, _ in CLASSES:
-    if c in F and c in W and F[c][0]:
-        n = F[c][0]
-        fb, wb = F[c][1] * 1024 * 2 / n, W[c][1] * 1024 / max(W[c][0], 1)
-        res[c] = {"launches": n, "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "hbm_bytes_per_launch": fb + wb}
-json.dump(res, open(out, "w"), indent=1)
-print(json.dumps(res, indent=1))
+def main():
+    fd, wd, out = sys.argv[1:4]
+    F, W = load(fd, "FETCH_SIZE"), load(wd, "WRITE_SIZE")
+    res = {"_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline "
+                    "--no-extra-modes --serial-decode; KB units; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests at 64 B)"}
+    for c, _ in CLASSES:
+        if c in F and c in W and F[c][0]:
+            n = F[c][0]
+            fb, wb = F[c][1] * 1024 * 2 / n, W[c][1] * 1024 / max(W[c][0], 1)
+            res[c] = {"launches": n, "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "hbm_bytes_per_launch": fb + wb}
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
