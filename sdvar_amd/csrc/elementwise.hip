@@ -82,7 +82,16 @@ __device__ __forceinline__ f32x4 pending_residual(const PendingSplitK& pend, f32
     const size_t slab = (size_t)rows * C, o = (size_t)row * C + 4 * idx;
     f32x4 acc = *reinterpret_cast<const f32x4*>(pend.ws + o);
     int k = 1;
-    for (; k + 3 < pend.split; k += 4) {          // four slab loads in flight, added in slice order
+    for (; k + 7 < pend.split; k += 8) {          // eight slab loads in flight, added in slice order (the order is part of the result)
+        f32x4 p[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p[u] = *reinterpret_cast<const f32x4*>(pend.ws + (size_t)(k + u) * slab + o);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = acc[e] + p[u][e];
+    }
+    for (; k + 3 < pend.split; k += 4) {
         const f32x4 p0 = *reinterpret_cast<const f32x4*>(pend.ws + (size_t)k * slab + o), p1 = *reinterpret_cast<const f32x4*>(pend.ws + (size_t)(k + 1) * slab + o);
         const f32x4 p2 = *reinterpret_cast<const f32x4*>(pend.ws + (size_t)(k + 2) * slab + o), p3 = *reinterpret_cast<const f32x4*>(pend.ws + (size_t)(k + 3) * slab + o);
 #pragma unroll
@@ -241,7 +250,15 @@ __global__ __launch_bounds__(256) void qk_norm_append_planes_kernel(const float*
             if (pend.ws) {
                 const size_t slab = (size_t)R * l * 3 * C, o = row * 3 * C + h * 64 + lane;
                 q[u] = pend.ws[o]; k[u] = pend.ws[o + C]; v[u] = pend.ws[o + 2 * C];
-                for (int s = 1; s < pend.split; ++s) { q[u] += pend.ws[s * slab + o]; k[u] += pend.ws[s * slab + o + C]; v[u] += pend.ws[s * slab + o + 2 * C]; }
+                int s = 1;
+                for (; s + 3 < pend.split; s += 4) {            // 12 independent loads in flight, summed in slice order
+                    float tq[4], tk[4], tv[4];
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) { tq[w] = pend.ws[(s + w) * slab + o]; tk[w] = pend.ws[(s + w) * slab + o + C]; tv[w] = pend.ws[(s + w) * slab + o + 2 * C]; }
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) { q[u] += tq[w]; k[u] += tk[w]; v[u] += tv[w]; }
+                }
+                for (; s < pend.split; ++s) { q[u] += pend.ws[s * slab + o]; k[u] += pend.ws[s * slab + o + C]; v[u] += pend.ws[s * slab + o + 2 * C]; }
                 q[u] += pend.bias[h * 64 + lane]; k[u] += pend.bias[C + h * 64 + lane]; v[u] += pend.bias[2 * C + h * 64 + lane];
             } else {
                 const float* p = qkv + row * 3 * C + h * 64 + lane;

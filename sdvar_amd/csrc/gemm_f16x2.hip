@@ -47,6 +47,7 @@ struct GemmHArgs {
     const float* bias; float* out; uint16_t* outp; size_t ops;
     const float* res; const float* gate;
     int M, N, K, ldo, ldres, rows_per_gate, gate_stride, split, k_per_split;
+    int dbg;                 // timing experiments only (SDVAR_GEMM_DBG, results wrong): bit 0 no DMA inside the K loop, bit 1 no barrier, bit 2 no fragment reads
     int tile_off, tile_cnt;  // 256-row kernel only: this launch covers tile ids [tile_off, tile_off + tile_cnt) (tile_cnt = 0: all); with
                              // HEPI_PARTIAL the slabs are compact [split][tile_cnt][256][128]
 };
@@ -248,16 +249,23 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_v2_kernel(GemmHArgs a) {
     for (int t = 0; t < nk; ++t) {
         if (NS == 3 && t + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        const bool pf = t + NS - 1 < nk;
+        if (!(a.dbg & 2)) __builtin_amdgcn_s_barrier();
+        const bool pf = t + NS - 1 < nk && !(a.dbg & 1);
         const uint32_t sb = (uint32_t)(uintptr_t)(lds_ptr_t)(hsm + (t % NS) * H2_STAGE);
         const uint32_t aa0 = sb + 2 * (offa0 + ch0), aa1 = sb + 2 * (offa0 + ch1), ab0 = sb + 2 * (offb + ch0), ab1 = sb + 2 * (offb + ch1);
         // fa[s][plane][row tile], fb[s][plane]: X plane p at +8192 p bytes, second 32-row tile at +2048; W plane p at +16384 + 8192 p
         f16x8 fa[2][2][2], fb[2][2];
+        if (a.dbg & 4) {
+#pragma unroll
+            for (int z = 0; z < 8; ++z) { fa[z >> 2][(z >> 1) & 1][z & 1] = __builtin_bit_cast(f16x8, f32x4{1.f, 2.f, 3.f, (float)z}); }
+#pragma unroll
+            for (int z = 0; z < 4; ++z) fb[z >> 1][z & 1] = __builtin_bit_cast(f16x8, f32x4{1.f, 2.f, 3.f, (float)z});
+        } else {
         SDVAR_LDS_RDH(fa[0][1][0], aa0, 8192);  SDVAR_LDS_RDH(fb[0][0], ab0, 16384); SDVAR_LDS_RDH(fa[0][0][0], aa0, 0);
         SDVAR_LDS_RDH(fb[0][1], ab0, 24576);    SDVAR_LDS_RDH(fa[0][1][1], aa0, 10240); SDVAR_LDS_RDH(fa[0][0][1], aa0, 2048);
         SDVAR_LDS_RDH(fa[1][1][0], aa1, 8192);  SDVAR_LDS_RDH(fb[1][0], ab1, 16384); SDVAR_LDS_RDH(fa[1][0][0], aa1, 0);
         SDVAR_LDS_RDH(fb[1][1], ab1, 24576);    SDVAR_LDS_RDH(fa[1][1][1], aa1, 10240); SDVAR_LDS_RDH(fa[1][0][1], aa1, 2048);
+        }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             if (s == 0) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
@@ -772,7 +780,8 @@ int gemm_f16x2_nt(const uint16_t* X, size_t xps, const uint16_t* W, size_t wps, 
     SDVAR_CHECK_ARG(epi == HEPI_BIAS_GELU_PLANES ? (outp != nullptr && N % 4 == 0) : (out != nullptr && ldo >= N), "gemm_f16x2: missing output");
     SDVAR_CHECK_ARG(((uintptr_t)X % 16) == 0 && ((uintptr_t)W % 16) == 0 && xps % 8 == 0 && wps % 8 == 0, "gemm_f16x2: planes must be 16-byte aligned");
     if (epi == HEPI_GATED_RES) SDVAR_CHECK_ARG(res && gate && rows_per_gate > 0 && ldres >= N, "gemm_f16x2: gated-residual epilogue needs res/gate");
-    GemmHArgs a{X, W, xps, wps, wsi, bias, out, outp, ops, res, gate, M, N, K, ldo, ldres, rows_per_gate > 0 ? rows_per_gate : 1, gate_stride, 1, K / HBK, 0, 0};
+    static const int dbg = getenv("SDVAR_GEMM_DBG") ? atoi(getenv("SDVAR_GEMM_DBG")) : 0;
+    GemmHArgs a{X, W, xps, wps, wsi, bias, out, outp, ops, res, gate, M, N, K, ldo, ldres, rows_per_gate > 0 ? rows_per_gate : 1, gate_stride, 1, K / HBK, dbg, 0, 0};
     size_t wsf = 0;
     (void)splitk_workspace(&wsf);
     int bm, split, tail = 0;
