@@ -338,8 +338,19 @@ def main():
         c = classes["attention"]
         roofline_attn = roof("attention")
         roofline_attn["regime"] = "l > 36 queries per (row, head): matrix-pipe bound"
-        roofline_attn["mfma"] = dict(achieved=c["flops"] / (c["ms"] * 1e-3) / 1e12, peak=PEAK_BF16_MFMA_TFLOPS / 6.0, unit="TFLOP/s",
-                                     frac=c["flops"] / (c["ms"] * 1e-3) / 1e12 / (PEAK_BF16_MFMA_TFLOPS / 6.0))
+        # matrix-core products per algorithmic fp32 product in the attention kernel of this configuration: bf16x3 planes 6, f16x2 planes 3, one fp16 plane
+        # (fp16 KV cache) 2, fp32 MFMA (gemm mode f32): the fp32 MFMA peak
+        if tc.gemm_mode == "f32":
+            apeak, anote = PEAK_F32_MFMA_TFLOPS, "fp32-in MFMA"
+        else:
+            nprod = 2 if conf["kv_fp16"] else (3 if tc.gemm_mode == "f16x2" else 6)
+            apeak, anote = PEAK_BF16_MFMA_TFLOPS / nprod, f"dense 16-bit MFMA peak / {nprod} plane products per fp32 product"
+        roofline_attn["mfma"] = dict(achieved=c["flops"] / (c["ms"] * 1e-3) / 1e12, peak=apeak, unit="TFLOP/s", note=anote,
+                                     frac=c["flops"] / (c["ms"] * 1e-3) / 1e12 / apeak)
+        # measured HBM traffic is per launch over ALL attention launches of the step (both regimes): compare like with like
+        n_all = c["launches"] + (classes["attention_small"]["launches"] if "attention_small" in classes else 0)
+        b_all = c["bytes"] + (classes["attention_small"]["bytes"] if "attention_small" in classes else 0.0)
+        roofline_attn["algorithmic_bytes_all_attention_launches"] = b_all / n_all
     roofline_attn_small = None
     if "attention_small" in classes:
         roofline_attn_small = roof("attention_small")
