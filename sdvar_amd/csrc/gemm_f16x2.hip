@@ -223,7 +223,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_v2_kernel(GemmHArgs a) {
     const char* const bw = reinterpret_cast<const char*>(a.W + (size_t)kt0 * a.N * 32);
     // DMA instruction q (0..3) of K-step t (relative) -> stage t % 3: q = 2p is X plane p, q = 2p + 1 is W plane p
     auto issue_one = [&](int t, int q) {
-        uint16_t* st = hsm + (t % NS) * H2_STAGE + swave * 512;      // + sub-array * 4096 elements
+        uint16_t* st = hsm + (t % (NS == 4 ? 3 : NS)) * H2_STAGE + swave * 512;      // + sub-array * 4096 elements
         const int p = q >> 1;
         if (q & 1) SDVAR_DMA16(lw, bw + ((size_t)t * a.N * 32 + p * a.wps) * 2, SDVAR_LDS_ADDR(st + (2 + p) * 4096));
         else SDVAR_DMA16(lx, bx + ((size_t)t * a.M * 32 + p * a.xps) * 2, SDVAR_LDS_ADDR(st + p * 4096));
@@ -244,6 +244,57 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_v2_kernel(GemmHArgs a) {
     const int offa0 = (wm * 64 + li) * 32, offb = (wn * 32 + li) * 32;
     const int ch0 = 8 * ((0 + lh) ^ sw), ch1 = 8 * ((2 + lh) ^ sw);
 
+    if (NS == 4) {
+        // Software-pipelined variant (template value 4 = "3 stages, pipelined reads"): ONE barrier per K-step, placed where a wave holds every fragment
+        // of tile t in registers; behind it tile t+1's first-half fragments are read into the registers the first half of tile t just freed (its
+        // second half after the second MFMA group), and the DMA of tile t+3 goes into the stage of tile t.
+        f16x8 fa[2][2][2], fb[2][2];
+        auto read_half = [&](int t, int sdx) {
+            const uint32_t sb = (uint32_t)(uintptr_t)(lds_ptr_t)(hsm + (t % 3) * H2_STAGE);
+            const uint32_t aa = sb + 2 * (offa0 + (sdx ? ch1 : ch0)), ab = sb + 2 * (offb + (sdx ? ch1 : ch0));
+            SDVAR_LDS_RDH(fa[sdx][1][0], aa, 8192);  SDVAR_LDS_RDH(fb[sdx][0], ab, 16384); SDVAR_LDS_RDH(fa[sdx][0][0], aa, 0);
+            SDVAR_LDS_RDH(fb[sdx][1], ab, 24576);    SDVAR_LDS_RDH(fa[sdx][1][1], aa, 10240); SDVAR_LDS_RDH(fa[sdx][0][1], aa, 2048);
+        };
+        auto issue3 = [&](int t, int q) {
+            uint16_t* st = hsm + (t % 3) * H2_STAGE + swave * 512;
+            const int p = q >> 1;
+            if (q & 1) SDVAR_DMA16(lw, bw + ((size_t)t * a.N * 32 + p * a.wps) * 2, SDVAR_LDS_ADDR(st + (2 + p) * 4096));
+            else SDVAR_DMA16(lx, bx + ((size_t)t * a.M * 32 + p * a.xps) * 2, SDVAR_LDS_ADDR(st + p * 4096));
+        };
+        for (int tt = 0; tt < 3 && tt < nk; ++tt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) issue3(tt, q);
+        if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        read_half(0, 0);
+        read_half(0, 1);
+        for (int t = 0; t < nk; ++t) {
+            asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { SDVAR_MFMA3(acc[i], fa[0][0][i], fa[0][1][i], fb[0][0], fb[0][1]); }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            const bool more = t + 1 < nk, pf = t + 3 < nk;
+            if (more) read_half(t + 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                SDVAR_MFMA3(acc[i], fa[1][0][i], fa[1][1][i], fb[1][0], fb[1][1]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (pf) { issue3(t + 3, 2 * i); issue3(t + 3, 2 * i + 1); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (more) read_half(t + 1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
     issue(0);
     if (NS == 3 && nk > 1) issue(1);
     for (int t = 0; t < nk; ++t) {
@@ -251,7 +302,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_v2_kernel(GemmHArgs a) {
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!(a.dbg & 2)) __builtin_amdgcn_s_barrier();
         const bool pf = t + NS - 1 < nk && !(a.dbg & 1);
-        const uint32_t sb = (uint32_t)(uintptr_t)(lds_ptr_t)(hsm + (t % NS) * H2_STAGE);
+        const uint32_t sb = (uint32_t)(uintptr_t)(lds_ptr_t)(hsm + (t % (NS == 4 ? 3 : NS)) * H2_STAGE);
         const uint32_t aa0 = sb + 2 * (offa0 + ch0), aa1 = sb + 2 * (offa0 + ch1), ab0 = sb + 2 * (offb + ch0), ab1 = sb + 2 * (offb + ch1);
         // fa[s][plane][row tile], fb[s][plane]: X plane p at +8192 p bytes, second 32-row tile at +2048; W plane p at +16384 + 8192 p
         f16x8 fa[2][2][2], fb[2][2];
@@ -279,6 +330,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_v2_kernel(GemmHArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+    }
     }
 
     const float wsi = a.wsi ? *a.wsi : 1.0f;
@@ -627,12 +679,20 @@ static void choose_cfg_h(int M, int N, int K, size_t ws_floats, int* bm_out, int
 
 static thread_local int* g_defer_h = nullptr;     // set per call by gemm_bf16x3_nt; thread-local: host threads may drive different model objects concurrently
 
-static int g_h2_stages = -1;      // ring depth of the 128 x 128 kernel: 3 = one workgroup per CU with two K-steps in flight, 2 = 64 KB of LDS, two workgroups per CU
-                                   // (SDVAR_GEMM_H2_STAGES=2/3 for A/B runs)
+static int g_h2_stages = -1;      // variant of the 128 x 128 kernel: 4 (default) = 3-stage ring with software-pipelined fragment reads (3-10 % faster than 3 on the shapes
+                                   // that use this tile); 3 = 3-stage ring, reads in front of the MFMAs; 2 = 2-stage ring, two workgroups per CU (SDVAR_GEMM_H2_STAGES for A/B runs)
 
 template <int EPI>
 static int launch_h2_kernel(const GemmHArgs& a, int grid, hipStream_t stream) {
-    if (g_h2_stages < 0) { const char* e = getenv("SDVAR_GEMM_H2_STAGES"); g_h2_stages = (e && atoi(e) == 2) ? 2 : 3; }
+    if (g_h2_stages < 0) { const char* e = getenv("SDVAR_GEMM_H2_STAGES"); g_h2_stages = (e && atoi(e) == 2) ? 2 : (e && atoi(e) == 3) ? 3 : 4; }
+    if (g_h2_stages == 4) {        // 3 stages, software-pipelined fragment reads
+        const size_t lds = 3 * (size_t)H2_STAGE * sizeof(uint16_t);
+        static LdsOptIn opt_in4;
+        SDVAR_LDS_OPT_IN(opt_in4, lds, (const void*)gemm_f16x2_v2_kernel<EPI, 4>);
+        hipLaunchKernelGGL((gemm_f16x2_v2_kernel<EPI, 4>), dim3(grid), dim3(512), lds, stream, a);
+        SDVAR_LAUNCH_CHECK();
+        return SDVAR_OK;
+    }
     if (g_h2_stages == 2) {
         const size_t lds = 2 * (size_t)H2_STAGE * sizeof(uint16_t);      // 64 KB
         hipLaunchKernelGGL((gemm_f16x2_v2_kernel<EPI, 2>), dim3(grid), dim3(512), lds, stream, a);
