@@ -48,3 +48,13 @@ def state_dicts(depth, patch_nums, mode="stress", seed=1234, vae=True, shared_al
     if vae and vkey not in _SD_CACHE:
         _SD_CACHE[vkey] = vae_state_dict(patch_nums, mode, seed, with_encoder=False)
     return _SD_CACHE[key], (_SD_CACHE[vkey] if vae else None)
+
+
+_ORACLE_CACHE = {}
+
+
+def oracle_memo(key, fn):
+    """CPU-oracle results do not depend on the GEMM mode of the HIP path under test: compute each (weights, arguments) case once per session."""
+    if key not in _ORACLE_CACHE:
+        _ORACLE_CACHE[key] = fn()
+    return _ORACLE_CACHE[key]

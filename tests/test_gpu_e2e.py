@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden, state_dicts
+from conftest import golden, oracle_memo, state_dicts
 from oracle import var_oracle as orc
 from sdvar_amd import engine as E
 from sdvar_amd.ladder import LADDER_256, as_ladder
@@ -44,8 +44,8 @@ def test_plain_ar_vs_reference_fixture(dev, name, gm):
     res = smp.plain_ar(labels, float(g["cfg"]), int(g["top_k"]), float(g["top_p"]), E.Noise("host", int(g["g_seed"])), trace=True)
     ids = res.ids.cpu().numpy()
     # diagnostic: per-stage logits error of the HIP path against the oracle fed with the HIP path's own inputs
-    tr = orc.plain_ar(orc.OracleVAR(sd_var, depth, pns), orc.OracleQuant(sd_vae, pns), labels.cpu(), float(g["cfg"]), int(g["top_k"]), float(g["top_p"]),
-                      _noise_o(int(g["g_seed"])), keep=True)
+    tr = oracle_memo(("plain", name), lambda: orc.plain_ar(orc.OracleVAR(sd_var, depth, pns), orc.OracleQuant(sd_vae, pns), labels.cpu(), float(g["cfg"]), int(g["top_k"]),
+                                                           float(g["top_p"]), _noise_o(int(g["g_seed"])), keep=True))
     errs = [float((res.trace["logits"][s].cpu() - tr.logits[s]).abs().max()) for s in range(lad.S)]
     msg = _flip_report(ids, g["ids"].astype(np.int64), lad) + f" (fixture min margin {g['min_rel_margin'].min():.1e}); per-stage max|dlogit| vs oracle {['%.1e' % e for e in errs]}"
     assert np.array_equal(ids, g["ids"].astype(np.int64)), msg
@@ -123,7 +123,7 @@ def test_spec_decode_vs_oracle(dev, pair, mode, thr, gamma):
     assert np.array_equal(ids, want_ids), _flip_report(ids, want_ids, smp.lad)
     st = res.stats
     assert [st["target_calls"], st["draft_stage_calls"], st["forced_accepts"], st["accepted_tokens"]] == list(g[f"spec_{mode}_g{gamma}_stats"])
-    tr = orc.spec_decode(od, ot, oq, labels, 1.5, gamma, 900, 0.96, _noise_o(SEED), thr=thr)
+    tr = oracle_memo(("spec", SEED, gamma, thr), lambda: orc.spec_decode(od, ot, oq, labels, 1.5, gamma, 900, 0.96, _noise_o(SEED), thr=thr))
     assert (res.f_hat.cpu() - tr.f_hat).abs().max().item() <= 1e-4
     assert [r["n_accept"] for r in st["rounds"]] == [r["n_accept"] for r in tr.stats["rounds"]]
     assert [r["matched"] for r in st["rounds"]] == [r["matched"] for r in tr.stats["rounds"]]
@@ -430,7 +430,7 @@ def test_unselected_seeds_flip_only_on_sub_margin_ties(dev, gm):
     flips = 0
     for seed in (1001, 1002, 1003, 1004):
         res = smp.plain_ar(labels.to(dev), 1.5, 900, 0.96, E.Noise("host", seed), trace=True)
-        tr = orc.plain_ar(od, oq, labels, 1.5, 900, 0.96, _noise_o(seed), keep=True)
+        tr = oracle_memo(("unselected", seed), lambda: orc.plain_ar(od, oq, labels, 1.5, 900, 0.96, _noise_o(seed), keep=True))
         ids, want = res.ids.cpu().numpy(), torch.cat(tr.ids, 1).numpy()
         if np.array_equal(ids, want):
             continue

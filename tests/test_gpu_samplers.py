@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden, state_dicts
+from conftest import golden, oracle_memo, state_dicts
 from oracle import var_oracle as orc
 from sdvar_amd import engine as E
 from sdvar_amd.ladder import LADDER_256, as_ladder
@@ -209,7 +209,8 @@ def test_spec_decode_with_rules_vs_oracle(dev, pair6, rule, thr, gamma):
     g = golden("sd_components")
     labels, SEED = torch.from_numpy(g["labels"]).long(), int(g["seed"])
     res = smp.spec_decode(labels.to(dev), 1.5, gamma, 900, 0.96, E.Noise("host", SEED), thr=thr, match=rule)
-    tr = orc.spec_decode(od, ot, oq, labels, 1.5, gamma, 900, 0.96, _noise_o(SEED), thr=thr, match=orc.MatchRule(rule.rule, rule.top_k, rule.kl_thr, rule.token_level))
+    tr = oracle_memo(("rules", SEED, gamma, thr, rule.rule, rule.top_k, rule.kl_thr, rule.token_level), lambda: orc.spec_decode(
+        od, ot, oq, labels, 1.5, gamma, 900, 0.96, _noise_o(SEED), thr=thr, match=orc.MatchRule(rule.rule, rule.top_k, rule.kl_thr, rule.token_level)))
     assert np.array_equal(res.ids.cpu().numpy(), torch.cat(tr.ids, 1).numpy())
     assert (res.f_hat.cpu() - tr.f_hat).abs().max().item() <= 1e-4
     for k in ("target_calls", "draft_stage_calls", "forced_accepts", "accepted_tokens", "gamma_final"):
