@@ -295,10 +295,13 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_v2_kernel(GemmHArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         }
     } else {
-    issue(0);
-    if (NS == 3 && nk > 1) issue(1);
+    for (int tt = 0; tt < NS - 1 && tt < nk; ++tt) issue(tt);
     for (int t = 0; t < nk; ++t) {
-        if (NS == 3 && t + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        // tile t has landed when at most the min(NS - 2, tiles behind it) newest K-steps (4 instructions each) are still in flight
+        const int behind = min(NS - 2, nk - 1 - t);
+        if (behind >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (behind == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (behind == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!(a.dbg & 2)) __builtin_amdgcn_s_barrier();
         const bool pf = t + NS - 1 < nk && !(a.dbg & 1);
@@ -684,7 +687,15 @@ static int g_h2_stages = -1;      // variant of the 128 x 128 kernel: 4 (default
 
 template <int EPI>
 static int launch_h2_kernel(const GemmHArgs& a, int grid, hipStream_t stream) {
-    if (g_h2_stages < 0) { const char* e = getenv("SDVAR_GEMM_H2_STAGES"); g_h2_stages = (e && atoi(e) == 2) ? 2 : (e && atoi(e) == 3) ? 3 : 4; }
+    if (g_h2_stages < 0) { const char* e = getenv("SDVAR_GEMM_H2_STAGES"); g_h2_stages = (e && atoi(e) == 2) ? 2 : (e && atoi(e) == 3) ? 3 : (e && atoi(e) == 5) ? 5 : 4; }
+    if (g_h2_stages == 5) {        // 5-stage ring (160 KB): four K-steps in flight
+        const size_t lds = 5 * (size_t)H2_STAGE * sizeof(uint16_t);
+        static LdsOptIn opt_in5;
+        SDVAR_LDS_OPT_IN(opt_in5, lds, (const void*)gemm_f16x2_v2_kernel<EPI, 5>);
+        hipLaunchKernelGGL((gemm_f16x2_v2_kernel<EPI, 5>), dim3(grid), dim3(512), lds, stream, a);
+        SDVAR_LAUNCH_CHECK();
+        return SDVAR_OK;
+    }
     if (g_h2_stages == 4) {        // 3 stages, software-pipelined fragment reads
         const size_t lds = 3 * (size_t)H2_STAGE * sizeof(uint16_t);
         static LdsOptIn opt_in4;
