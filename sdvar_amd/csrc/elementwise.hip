@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void qk_norm_append_planes_kernel(const float*
                                                                     int fmt) {
     __shared__ float vs[32 * 65];
     const int NP = fmt == 2 ? 3 : (fmt == 3 ? 2 : 1);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     const int h = blockIdx.y, r = blockIdx.z;
     const int P0 = (pos0 / 32 + blockIdx.x) * 32;
     const int pb = max(P0, pos0), pe = min(P0 + 32, pos0 + l);
@@ -237,54 +237,61 @@ __global__ __launch_bounds__(256) void qk_norm_append_planes_kernel(const float*
     const size_t head = ((size_t)r * H + h) * NP * (size_t)Lp * 64, ps = (size_t)Lp * 64;
     const bool l2 = scale_mul != nullptr;            // attn_l2_norm=False: raw q (x 2^-5, the softmax scale) and raw k (basic_var.py:71-72)
     const float sm = l2 ? expf(fminf(scale_mul[h], 4.605170249938965f)) : 0.03125f;
-    // wave w owns positions pb + w, + 4, ... (at most 8); four of them are in flight at a time (their loads - up to 3 x split slab reads
-    // each - are independent, the wave reductions are not the bottleneck)
-    for (int pos4 = pb + wave; pos4 < pe; pos4 += 16) {
-        float q[4], k[4], v[4];
+    // thread = (position P0 + tid / 8, channel group tid % 8: channels 8cg .. 8cg+7): the whole 32-position block is in flight at once with 16-byte
+    // loads (six per thread and slab), the q / k norms are an in-thread sum of 8 squares + three shuffle steps inside the 8-lane group
+    {
+        const int pos = P0 + (tid >> 3), cg = tid & 7;
+        const bool live = pos >= pb && pos < pe;
+        float q[8], k[8], v[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int pos = pos4 + 4 * u;
-            q[u] = k[u] = v[u] = 0.f;
-            if (pos >= pe) continue;
-            const size_t row = (size_t)r * l + (pos - pos0);
-            if (pend.ws) {
-                const size_t slab = (size_t)R * l * 3 * C, o = row * 3 * C + h * 64 + lane;
-                q[u] = pend.ws[o]; k[u] = pend.ws[o + C]; v[u] = pend.ws[o + 2 * C];
-                int s = 1;
-                for (; s + 3 < pend.split; s += 4) {            // 12 independent loads in flight, summed in slice order
-                    float tq[4], tk[4], tv[4];
+        for (int e = 0; e < 8; ++e) q[e] = k[e] = v[e] = 0.f;
+        auto add8 = [](float* d, const float* p) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
 #pragma unroll
-                    for (int w = 0; w < 4; ++w) { tq[w] = pend.ws[(s + w) * slab + o]; tk[w] = pend.ws[(s + w) * slab + o + C]; tv[w] = pend.ws[(s + w) * slab + o + 2 * C]; }
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) { q[u] += tq[w]; k[u] += tk[w]; v[u] += tv[w]; }
-                }
-                for (; s < pend.split; ++s) { q[u] += pend.ws[s * slab + o]; k[u] += pend.ws[s * slab + o + C]; v[u] += pend.ws[s * slab + o + 2 * C]; }
-                q[u] += pend.bias[h * 64 + lane]; k[u] += pend.bias[C + h * 64 + lane]; v[u] += pend.bias[2 * C + h * 64 + lane];
+            for (int e = 0; e < 4; ++e) { d[e] += a[e]; d[4 + e] += b[e]; }
+        };
+        if (live) {
+            const size_t o = ((size_t)r * l + (pos - pos0)) * 3 * C + h * 64 + 8 * cg;
+            if (pend.ws) {             // qkv[row][col] = sum_s ws[s][row][col] + bias[col], slabs added in slice order
+                const size_t slab = (size_t)R * l * 3 * C;
+                for (int s = 0; s < pend.split; ++s) { const float* p = pend.ws + (size_t)s * slab + o; add8(q, p); add8(k, p + C); add8(v, p + 2 * C); }
+                add8(q, pend.bias + h * 64 + 8 * cg); add8(k, pend.bias + C + h * 64 + 8 * cg); add8(v, pend.bias + 2 * C + h * 64 + 8 * cg);
             } else {
-                const float* p = qkv + row * 3 * C + h * 64 + lane;
-                q[u] = p[0]; k[u] = p[C]; v[u] = p[2 * C];
+                add8(q, qkv + o); add8(k, qkv + o + C); add8(v, qkv + o + 2 * C);
             }
         }
+        float sq = 0.f, sk = 0.f;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int pos = pos4 + 4 * u;
-            if (pos >= pe) continue;
-            const int t = pos - pos0;
-            const float qn = l2 ? fmaxf(sqrtf(wave_sum(q[u] * q[u])), 1e-12f) : 1.0f;
-            const float kn = l2 ? fmaxf(sqrtf(wave_sum(k[u] * k[u])), 1e-12f) : 1.0f;
-            q_out[(((size_t)r * H + h) * l + t) * 64 + lane] = l2 ? (q[u] / qn) * sm : q[u] * sm;
-            uint16_t* pk = k_cache + head + (size_t)pos * 64 + lane;
+        for (int e = 0; e < 8; ++e) { sq += q[e] * q[e]; sk += k[e] * k[e]; }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) { sq += __shfl_xor(sq, o, 64); sk += __shfl_xor(sk, o, 64); }
+        if (live) {
+            const float qn = l2 ? fmaxf(sqrtf(sq), 1e-12f) : 1.0f, kn = l2 ? fmaxf(sqrtf(sk), 1e-12f) : 1.0f;
+            f32x4 q0, q1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { q0[e] = l2 ? (q[e] / qn) * sm : q[e] * sm; q1[e] = l2 ? (q[4 + e] / qn) * sm : q[4 + e] * sm; }
+            float* pq = q_out + (((size_t)r * H + h) * l + (pos - pos0)) * 64 + 8 * cg;
+            *reinterpret_cast<f32x4*>(pq) = q0; *reinterpret_cast<f32x4*>(pq + 4) = q1;
+            uint16_t* pk = k_cache + head + (size_t)pos * 64 + 8 * cg;
+            float kn8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) kn8[e] = l2 ? k[e] / kn : k[e];
             if (fmt == 2) {
-                uint16_t k0, k1, k2;
-                split3(l2 ? k[u] / kn : k[u], k0, k1, k2);
-                pk[0] = k0; pk[ps] = k1; pk[2 * ps] = k2;
+                u32x4 a, b, cc;
+                split8_packed(kn8, a, b, cc);
+                *reinterpret_cast<u32x4*>(pk) = a; *reinterpret_cast<u32x4*>(pk + ps) = b; *reinterpret_cast<u32x4*>(pk + 2 * ps) = cc;
             } else {
-                uint16_t kh, kl;
-                split2h(l2 ? k[u] / kn : k[u], kh, kl);
-                pk[0] = kh;
-                if (fmt == 3) pk[ps] = kl;
+                uint16_t hh[8], ll[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) split2h(kn8[e], hh[e], ll[e]);
+                u32x4 a, b;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { a[e] = (uint32_t)hh[2 * e] | ((uint32_t)hh[2 * e + 1] << 16); b[e] = (uint32_t)ll[2 * e] | ((uint32_t)ll[2 * e + 1] << 16); }
+                *reinterpret_cast<u32x4*>(pk) = a;
+                if (fmt == 3) *reinterpret_cast<u32x4*>(pk + ps) = b;
             }
-            vs[(pos - P0) * 65 + lane] = v[u];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) vs[(pos - P0) * 65 + 8 * cg + e] = v[e];
         }
     }
     __syncthreads();
