@@ -78,31 +78,37 @@ __device__ __forceinline__ void ln_row_finish(const f32x4* v, int lane, int row,
 }
 
 // x[row] += (sum of K-slice slabs + bias) * gate for float4 number idx of the row (slabs summed in slice order); returns the new value
+// DEPTH = slab loads in flight at a time: 16 in the one-workgroup-per-row kernel (latency bound, registers are free), 4 in the one-wave-per-row kernel
+// (bandwidth bound at large M: occupancy matters more)
+template <int DEPTH>
 __device__ __forceinline__ f32x4 pending_residual(const PendingSplitK& pend, f32x4 xv, int row, int idx, int rows, int C) {
     const size_t slab = (size_t)rows * C, o = (size_t)row * C + 4 * idx;
+    // bias and gate first: every load of this function is independent of the others, so the whole slab sum costs one or two memory round trips
+    // (16 slabs in flight at a time), not one per group of slabs - at M = 16 the row kernel is a chain of such round trips and nothing else
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(pend.bias + 4 * idx);
+    const f32x4 gg = *reinterpret_cast<const f32x4*>(pend.gate + (size_t)(row / pend.rows_per_gate) * pend.gate_stride + 4 * idx);
     f32x4 acc = *reinterpret_cast<const f32x4*>(pend.ws + o);
     int k = 1;
-    for (; k + 7 < pend.split; k += 8) {          // eight slab loads in flight, added in slice order (the order is part of the result)
-        f32x4 p[8];
+    for (; k + DEPTH - 1 < pend.split; k += DEPTH) {        // added in slice order (the order is part of the result)
+        f32x4 p[DEPTH];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) p[u] = *reinterpret_cast<const f32x4*>(pend.ws + (size_t)(k + u) * slab + o);
+        for (int u = 0; u < DEPTH; ++u) p[u] = *reinterpret_cast<const f32x4*>(pend.ws + (size_t)(k + u) * slab + o);
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < DEPTH; ++u)
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[e] = acc[e] + p[u][e];
     }
-    for (; k + 3 < pend.split; k += 4) {
-        const f32x4 p0 = *reinterpret_cast<const f32x4*>(pend.ws + (size_t)k * slab + o), p1 = *reinterpret_cast<const f32x4*>(pend.ws + (size_t)(k + 1) * slab + o);
-        const f32x4 p2 = *reinterpret_cast<const f32x4*>(pend.ws + (size_t)(k + 2) * slab + o), p3 = *reinterpret_cast<const f32x4*>(pend.ws + (size_t)(k + 3) * slab + o);
+    if (k < pend.split) {                         // the remaining 1 .. DEPTH-1 slabs, all in flight together
+        f32x4 p[DEPTH - 1];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] = (((acc[e] + p0[e]) + p1[e]) + p2[e]) + p3[e];
+        for (int u = 0; u < DEPTH - 1; ++u) if (k + u < pend.split) p[u] = *reinterpret_cast<const f32x4*>(pend.ws + (size_t)(k + u) * slab + o);
+#pragma unroll
+        for (int u = 0; u < DEPTH - 1; ++u)
+            if (k + u < pend.split) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = acc[e] + p[u][e];
+            }
     }
-    for (; k < pend.split; ++k) {
-        const f32x4 p = *reinterpret_cast<const f32x4*>(pend.ws + (size_t)k * slab + o);
-        acc[0] += p[0]; acc[1] += p[1]; acc[2] += p[2]; acc[3] += p[3];
-    }
-    const f32x4 bb = *reinterpret_cast<const f32x4*>(pend.bias + 4 * idx);
-    const f32x4 gg = *reinterpret_cast<const f32x4*>(pend.gate + (size_t)(row / pend.rows_per_gate) * pend.gate_stride + 4 * idx);
 #pragma unroll
     for (int e = 0; e < 4; ++e) xv[e] = xv[e] + (acc[e] + bb[e]) * gg[e];
     return xv;
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(float* __restrict__ x,
         if (idx < nv) {
             v[i] = px[idx];
             if (pend.ws) {          // finish the previous block's gated residual, written back
-                v[i] = pending_residual(pend, v[i], row, idx, rows, C);
+                v[i] = pending_residual<4>(pend, v[i], row, idx, rows, C);
                 px[idx] = v[i];
             }
         }
@@ -143,7 +149,7 @@ __global__ __launch_bounds__(256) void ln_modulate_row_kernel(float* __restrict_
     const int nv = C >> 2;
     f32x4* px = reinterpret_cast<f32x4*>(x + (size_t)row * C);
     for (int idx = tid; idx < nv; idx += 256) {
-        const f32x4 nvv = pending_residual(pend, px[idx], row, idx, rows, C);
+        const f32x4 nvv = pending_residual<16>(pend, px[idx], row, idx, rows, C);
         px[idx] = nvv;
         vsm[idx] = nvv;
     }
