@@ -438,31 +438,34 @@ static int stage_forward_impl(sdvar_model_t* m, float* x, int32_t s0, int32_t n,
     PendingSplitK pend{nullptr, nullptr, nullptr, 0, 1, 0};           // unreduced gated residual waiting for the next ln_modulate
     int defer = 0;
     int* const dp = &defer;      // every split-K GEMM below leaves its K-slice sum to the row kernel that reads the result next
+    // timing experiments only (results wrong): SDVAR_SKIP_CLASS bit 0 ln_modulate, 1 qk_norm_append, 2 attention, 3 fc1, 4 QKV GEMM, 5 proj, 6 fc2 not launched
+    // (tools/micro/skip_class_exp.sh: the marginal cost of a kernel class inside the real launch sequence, without a profiler's per-kernel overhead)
+    static const int skip = getenv("SDVAR_SKIP_CLASS") ? atoi(getenv("SDVAR_SKIP_CLASS")) : 0;
     for (int i = 0; i < m->d.depth; ++i) {
         const BlockW& b = m->blk[i];
         const float* ada = m->ada + (size_t)i * m->Rmax * 6 * C;      // (R, 6C): gamma1 gamma2 scale1 scale2 shift1 shift2
-        { ProfScope pp(2, 8 * dM * dC, (P ? 10 : 8) * dM * dC, s);
+        if (!(skip & 1)) { ProfScope pp(2, 8 * dM * dC, (P ? 10 : 8) * dM * dC, s);
           SDVAR_TRY(ln_modulate(x, ada + 2 * C, ada + 4 * C, m->xn, P ? m->xn_p : nullptr, ps, M, C, lsum, 6 * C, &pend, PF, s)); pend.ws = nullptr; }
         PendingSplitK pq{nullptr, nullptr, nullptr, 0, 1, 0};
-        { ProfScope pp(0, 2 * dM * 3 * dC * dC, 4 * (dM * dC + 3 * dC * dC + 3 * dM * dC), s);
+        if (!(skip & 16)) { ProfScope pp(0, 2 * dM * 3 * dC * dC, 4 * (dM * dC + 3 * dC * dC + 3 * dM * dC), s);
           if (P) { SDVAR_TRY(plane_gemm(m, m->xn_p, ps, b.qkv_wp, (size_t)3 * C * C, b.wsc, b.qkv_bias, m->qkv, 3 * C, nullptr, 0, M, 3 * C, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, dp, s));
                    if (defer) pq = PendingSplitK{ws, b.qkv_bias, nullptr, defer, 1, 0}; }
           else SDVAR_TRY(gemm_f32_nt(m->xn, C, b.qkv_w, b.qkv_bias, m->qkv, 3 * C, M, 3 * C, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, s)); }
-        { ProfScope pp(3, 6 * dM * dC, 4 * 6 * dM * dC, s);
+        if (!(skip & 2)) { ProfScope pp(3, 6 * dM * dC, 4 * 6 * dM * dC, s);
           SDVAR_TRY(qk_norm_append(m->qkv, b.scale_mul, m->qbuf, b.kc, b.vc, m->kv_fmt, R, lsum, H, m->Lkv, m->kv_len, &pq, s)); }
-        { ProfScope pp(lsum <= 36 ? 8 : 1, 4.0 * R * H * 64.0 * lk, R * H * 64.0 * ((m->d.kv_dtype ? 4.0 : 8.0) * Ktot + 8.0 * lsum), s);
+        if (!(skip & 4)) { ProfScope pp(lsum <= 36 ? 8 : 1, 4.0 * R * H * 64.0 * lk, R * H * 64.0 * ((m->d.kv_dtype ? 4.0 : 8.0) * Ktot + 8.0 * lsum), s);
           if (bias) SDVAR_TRY(attention_masked(m->qbuf, b.kc, b.vc, m->kv_fmt, bias, m->att, P ? m->att_p : nullptr, ps, PF, R, H, lsum, m->Lkv, Ktot, s));
           else SDVAR_TRY(attention_f32(m->qbuf, b.kc, b.vc, m->kv_fmt, m->att, P ? m->att_p : nullptr, ps, PF, R, H, lsum, m->Lkv, Ktot, n, qbeg, vis, s)); }
-        { ProfScope pp(0, 2 * dM * dC * dC, 4 * (3 * dM * dC + dC * dC), s);
+        if (!(skip & 32)) { ProfScope pp(0, 2 * dM * dC * dC, 4 * (3 * dM * dC + dC * dC), s);
           if (P) { SDVAR_TRY(plane_gemm(m, m->att_p, ps, b.proj_wp, (size_t)C * C, b.wsc + 4, b.proj_b, x, C, nullptr, 0, M, C, C, EPI_GATED_RES, x, C, ada, lsum, 6 * C, dp, s));
                    if (defer) pend = PendingSplitK{ws, b.proj_b, ada, defer, lsum, 6 * C}; }
           else SDVAR_TRY(gemm_f32_nt(m->att, C, b.proj_w, b.proj_b, x, C, M, C, C, EPI_GATED_RES, x, C, ada, lsum, 6 * C, s)); }
-        { ProfScope pp(2, 8 * dM * dC, (P ? 10 : 8) * dM * dC, s);
+        if (!(skip & 1)) { ProfScope pp(2, 8 * dM * dC, (P ? 10 : 8) * dM * dC, s);
           SDVAR_TRY(ln_modulate(x, ada + 3 * C, ada + 5 * C, m->xn, P ? m->xn_p : nullptr, ps, M, C, lsum, 6 * C, &pend, PF, s)); pend.ws = nullptr; }
-        { ProfScope pp(0, 2 * dM * 4 * dC * dC, 4 * (dM * dC + 4 * dC * dC + 4 * dM * dC), s);
+        if (!(skip & 8)) { ProfScope pp(0, 2 * dM * 4 * dC * dC, 4 * (dM * dC + 4 * dC * dC + 4 * dM * dC), s);
           if (P) SDVAR_TRY(plane_gemm(m, m->xn_p, ps, b.fc1_wp, (size_t)4 * C * C, b.wsc + 8, b.fc1_b, nullptr, 0, m->hid_p, 4 * ps, M, 4 * C, C, EPI_BIAS_GELU, nullptr, 0, nullptr, 0, 0, nullptr, s));
           else SDVAR_TRY(gemm_f32_nt(m->xn, C, b.fc1_w, b.fc1_b, m->hid, 4 * C, M, 4 * C, C, EPI_BIAS_GELU, nullptr, 0, nullptr, 0, 0, s)); }
-        { ProfScope pp(0, 2 * dM * 4 * dC * dC, 4 * (4 * dM * dC + 4 * dC * dC + 2 * dM * dC), s);
+        if (!(skip & 64)) { ProfScope pp(0, 2 * dM * 4 * dC * dC, 4 * (4 * dM * dC + 4 * dC * dC + 2 * dM * dC), s);
           if (P) { SDVAR_TRY(plane_gemm(m, m->hid_p, 4 * ps, b.fc2_wp, (size_t)4 * C * C, b.wsc + 12, b.fc2_b, x, C, nullptr, 0, M, C, 4 * C, EPI_GATED_RES, x, C, ada + C, lsum, 6 * C, dp, s));
                    if (defer) pend = PendingSplitK{ws, b.fc2_b, ada + C, defer, lsum, 6 * C}; }
           else SDVAR_TRY(gemm_f32_nt(m->hid, 4 * C, b.fc2_w, b.fc2_b, x, C, M, C, 4 * C, EPI_GATED_RES, x, C, ada + C, lsum, 6 * C, s)); }

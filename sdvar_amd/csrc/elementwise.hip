@@ -29,20 +29,25 @@ struct PendingSplitK {
 // the shared_aln checkpoint of var.py:16-19, has C = 2304) so that narrow models do not pay the registers of wide ones.
 constexpr int LN_MAX_C = 3072;
 
-// LayerNorm + modulation of one row held by one wave (v[i] = float4 number lane + 64 i of the row)
+// the modulation vectors of a row, float4 number lane + 64 i: loaded FIRST by both kernels (these launches are latency bound at small M: every load
+// that does not depend on another must be in flight with it)
 template <int LN_MAX_V4>
-__device__ __forceinline__ void ln_row_finish(const f32x4* v, int lane, int row, const float* __restrict__ scale, const float* __restrict__ shift,
-                                              float* __restrict__ out, uint16_t* __restrict__ outp, size_t ops, int rows, int C, int rows_per_img,
-                                              int mod_stride, float eps, int pfmt) {
+__device__ __forceinline__ void ln_load_mod(f32x4* scv, f32x4* shv, int lane, int row, const float* __restrict__ scale, const float* __restrict__ shift,
+                                            int C, int rows_per_img, int mod_stride) {
     const int nv = C >> 2;
-    // modulation vectors first: their load latency overlaps the two wave reductions (these launches are latency-bound at small M)
     const size_t mo = (size_t)(row / rows_per_img) * mod_stride;
     const f32x4* psc = reinterpret_cast<const f32x4*>(scale + mo);
     const f32x4* psh = reinterpret_cast<const f32x4*>(shift + mo);
-    f32x4 scv[LN_MAX_V4], shv[LN_MAX_V4];
 #pragma unroll
     for (int i = 0; i < LN_MAX_V4; ++i)
         if (lane + 64 * i < nv) { scv[i] = psc[lane + 64 * i]; shv[i] = psh[lane + 64 * i]; }
+}
+
+// LayerNorm + modulation of one row held by one wave (v[i] = float4 number lane + 64 i of the row)
+template <int LN_MAX_V4>
+__device__ __forceinline__ void ln_row_finish(const f32x4* v, const f32x4* scv, const f32x4* shv, int lane, int row,
+                                              float* __restrict__ out, uint16_t* __restrict__ outp, size_t ops, int rows, int C, float eps, int pfmt) {
+    const int nv = C >> 2;
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < LN_MAX_V4; ++i)
@@ -122,7 +127,8 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(float* __restrict__ x,
     if (row >= rows) return;
     const int nv = C >> 2;
     f32x4* px = reinterpret_cast<f32x4*>(x + (size_t)row * C);
-    f32x4 v[LN_MAX_V4];
+    f32x4 v[LN_MAX_V4], scv[LN_MAX_V4], shv[LN_MAX_V4];
+    ln_load_mod<LN_MAX_V4>(scv, shv, lane, row, scale, shift, C, rows_per_img, mod_stride);
 #pragma unroll
     for (int i = 0; i < LN_MAX_V4; ++i) {
         const int idx = lane + 64 * i;
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(float* __restrict__ x,
             }
         }
     }
-    ln_row_finish<LN_MAX_V4>(v, lane, row, scale, shift, out, outp, ops, rows, C, rows_per_img, mod_stride, eps, pfmt);
+    ln_row_finish<LN_MAX_V4>(v, scv, shv, lane, row, out, outp, ops, rows, C, eps, pfmt);
 }
 
 // Same result bit for bit, one WORKGROUP per row, for a pending split-K residual at small row counts: with one wave per row
@@ -148,6 +154,8 @@ __global__ __launch_bounds__(256) void ln_modulate_row_kernel(float* __restrict_
     const int tid = threadIdx.x, row = blockIdx.x;
     const int nv = C >> 2;
     f32x4* px = reinterpret_cast<f32x4*>(x + (size_t)row * C);
+    f32x4 scv[LN_MAX_V4], shv[LN_MAX_V4];
+    if (tid < 64) ln_load_mod<LN_MAX_V4>(scv, shv, tid, row, scale, shift, C, rows_per_img, mod_stride);     // in flight with the slab loads below
     for (int idx = tid; idx < nv; idx += 256) {
         const f32x4 nvv = pending_residual<16>(pend, px[idx], row, idx, rows, C);
         px[idx] = nvv;
@@ -159,7 +167,7 @@ __global__ __launch_bounds__(256) void ln_modulate_row_kernel(float* __restrict_
 #pragma unroll
     for (int i = 0; i < LN_MAX_V4; ++i)
         if (tid + 64 * i < nv) v[i] = vsm[tid + 64 * i];
-    ln_row_finish<LN_MAX_V4>(v, tid, row, scale, shift, out, outp, ops, rows, C, rows_per_img, mod_stride, eps, pfmt);
+    ln_row_finish<LN_MAX_V4>(v, scv, shv, tid, row, out, outp, ops, rows, C, eps, pfmt);
 }
 
 int ln_modulate(float* x, const float* scale, const float* shift, float* out, uint16_t* outp, size_t ops, int rows, int C, int rows_per_img,
@@ -259,8 +267,26 @@ __global__ __launch_bounds__(256) void qk_norm_append_planes_kernel(const float*
         if (live) {
             const size_t o = ((size_t)r * l + (pos - pos0)) * 3 * C + h * 64 + 8 * cg;
             if (pend.ws) {             // qkv[row][col] = sum_s ws[s][row][col] + bias[col], slabs added in slice order
+                // four slabs (24 16-byte loads) in flight at a time, added in slice order: a load-then-add loop pays one memory round trip per slab
                 const size_t slab = (size_t)R * l * 3 * C;
-                for (int s = 0; s < pend.split; ++s) { const float* p = pend.ws + (size_t)s * slab + o; add8(q, p); add8(k, p + C); add8(v, p + 2 * C); }
+                int s = 0;
+                for (; s + 3 < pend.split; s += 4) {
+                    f32x4 t[4][6];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int w = 0; w < 3; ++w) {
+                            const float* p = pend.ws + (size_t)(s + u) * slab + o + (size_t)w * C;
+                            t[u][2 * w] = *reinterpret_cast<const f32x4*>(p); t[u][2 * w + 1] = *reinterpret_cast<const f32x4*>(p + 4);
+                        }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            q[e] += t[u][0][e]; q[4 + e] += t[u][1][e]; k[e] += t[u][2][e]; k[4 + e] += t[u][3][e]; v[e] += t[u][4][e]; v[4 + e] += t[u][5][e];
+                        }
+                }
+                for (; s < pend.split; ++s) { const float* p = pend.ws + (size_t)s * slab + o; add8(q, p); add8(k, p + C); add8(v, p + 2 * C); }
                 add8(q, pend.bias + h * 64 + 8 * cg); add8(k, pend.bias + C + h * 64 + 8 * cg); add8(v, pend.bias + 2 * C + h * 64 + 8 * cg);
             } else {
                 add8(q, qkv + o); add8(k, qkv + o + C); add8(v, qkv + o + 2 * C);

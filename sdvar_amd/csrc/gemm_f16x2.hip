@@ -18,6 +18,7 @@
 // LDS-DMA in flight (3-stage ring) instead of one.
 #include <stdio.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "common.h"
 
@@ -47,7 +48,7 @@ struct GemmHArgs {
     const float* bias; float* out; uint16_t* outp; size_t ops;
     const float* res; const float* gate;
     int M, N, K, ldo, ldres, rows_per_gate, gate_stride, split, k_per_split;
-    int dbg;                 // timing experiments only (SDVAR_GEMM_DBG, results wrong): bit 0 no DMA inside the K loop, bit 1 no barrier, bit 2 no fragment reads
+    int dbg;                 // timing experiments only (SDVAR_GEMM_DBG, results wrong): bit 0 no DMA inside the K loop, bit 1 no barrier, bit 2 no fragment reads, bit 3 no split-K reduce launch
     int tile_off, tile_cnt;  // 256-row kernel only: this launch covers tile ids [tile_off, tile_off + tile_cnt) (tile_cnt = 0: all); with
                              // HEPI_PARTIAL the slabs are compact [split][tile_cnt][256][128]
 };
@@ -213,7 +214,9 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_v2_kernel(GemmHArgs a) {
     const int wm = wave >> 2, wn = wave & 3, li = lane & 31, lh = lane >> 5;
 
     const int drow = 16 * wave + (lane >> 2);
-    const int dchunk = (lane & 3) ^ ((drow >> 2) & 3);
+    // NS == 6 (16x16x32 MFMA: a fragment is 16 rows x 4 chunks): chunk c of row r at c ^ P[(r >> 2) & 3], P = (0, 2, 3, 1) = 0x78 in 2-bit fields, which keeps each
+    // ds_read_b128 lane group ({0-3, 12-15, 20-27}, ...) on 16 different 16-byte slots of the 256-byte bank row
+    const int dchunk = (NS == 6) ? (lane & 3) ^ ((0x78 >> (2 * ((drow >> 2) & 3))) & 3) : (lane & 3) ^ ((drow >> 2) & 3);
     const int xrow = min(m0 + drow, a.M - 1), wrow = min(n0 + drow, a.N - 1);   // clamped: rows past the edge are never stored
     const int kt0 = ks * a.k_per_split;
     const int nk = min(a.K / HBK - kt0, a.k_per_split);
@@ -221,9 +224,105 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_v2_kernel(GemmHArgs a) {
     const uint32_t lx = (uint32_t)(xrow * 32 + 8 * dchunk) * 2u, lw = (uint32_t)(wrow * 32 + 8 * dchunk) * 2u;
     const char* const bx = reinterpret_cast<const char*>(a.X + (size_t)kt0 * a.M * 32);
     const char* const bw = reinterpret_cast<const char*>(a.W + (size_t)kt0 * a.N * 32);
+    if (NS == 6) {
+        // 16x16x32 variant: same ring, DMA and barrier placement as NS == 4; a wave's 64 x 32 outputs are 4 x 2 tiles of 16 x 16 (24 MFMAs of 16 cycles per
+        // K-step), fragments are whole-k32 (one ds_read_b128 each): group 0 = X row tiles 0, 1 + both W column tiles (8 reads), group 1 = X row tiles 2, 3 (4 reads);
+        // the W fragments are double-buffered because group 1 of tile t still uses them when group 0 of tile t+1 is read.
+        f32x4 c16[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) c16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int l16 = lane & 15, lc = lane >> 4;
+        // row offsets inside a sub-array are multiples of 16 rows from (wm * 64 | wn * 32) + l16, so (row >> 2) & 3 == (l16 >> 2)
+        const int rch = 8 * (lc ^ ((0x78 >> (2 * (l16 >> 2))) & 3));
+        const int oa = (wm * 64 + l16) * 32 + rch, ob = (wn * 32 + l16) * 32 + rch;
+        f16x8 xa[4][2], wb[2][2][2];          // xa[row tile][plane], wb[buffer][col tile][plane]
+        auto rd_g0 = [&](int t, int bsel) {
+            const uint32_t sb = (uint32_t)(uintptr_t)(lds_ptr_t)(hsm + (t % 3) * H2_STAGE);
+            const uint32_t aa = sb + 2 * oa, ab = sb + 2 * ob;
+            SDVAR_LDS_RDH(xa[0][1], aa, 8192);  SDVAR_LDS_RDH(wb[bsel][0][0], ab, 16384); SDVAR_LDS_RDH(xa[0][0], aa, 0);    SDVAR_LDS_RDH(wb[bsel][0][1], ab, 24576);
+            SDVAR_LDS_RDH(xa[1][1], aa, 9216);  SDVAR_LDS_RDH(wb[bsel][1][0], ab, 17408); SDVAR_LDS_RDH(xa[1][0], aa, 1024); SDVAR_LDS_RDH(wb[bsel][1][1], ab, 25600);
+        };
+        auto rd_g1 = [&](int t) {
+            const uint32_t sb = (uint32_t)(uintptr_t)(lds_ptr_t)(hsm + (t % 3) * H2_STAGE);
+            const uint32_t aa = sb + 2 * oa;
+            SDVAR_LDS_RDH(xa[2][1], aa, 10240); SDVAR_LDS_RDH(xa[2][0], aa, 2048); SDVAR_LDS_RDH(xa[3][1], aa, 11264); SDVAR_LDS_RDH(xa[3][0], aa, 3072);
+        };
+        auto issue3 = [&](int t, int q) {
+            uint16_t* st = hsm + (t % 3) * H2_STAGE + swave * 512;
+            const int p = q >> 1;
+            if (q & 1) SDVAR_DMA16(lw, bw + ((size_t)t * a.N * 32 + p * a.wps) * 2, SDVAR_LDS_ADDR(st + (2 + p) * 4096));
+            else SDVAR_DMA16(lx, bx + ((size_t)t * a.M * 32 + p * a.xps) * 2, SDVAR_LDS_ADDR(st + p * 4096));
+        };
+#define SDVAR_MFMA16(acc, A, B) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, acc, 0, 0, 0)
+        for (int tt = 0; tt < 3 && tt < nk; ++tt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) issue3(tt, q);
+        if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        rd_g0(0, 0);
+        rd_g1(0);
+        auto step = [&](int t, auto BSEL) {
+            constexpr int bs = decltype(BSEL)::value;
+            asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            // products smallest first (l.h, h.l, h.h), the four tiles of a group between two accumulations into the same tile
+#pragma unroll
+            for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) { SDVAR_MFMA16(c16[i][j], xa[i][pr == 0 ? 1 : 0], wb[bs][j][pr == 1 ? 1 : 0]); }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            const bool more = t + 1 < nk, pf = t + 3 < nk;
+            if (more) rd_g0(t + 1, bs ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int pr = 0; pr < 3; ++pr) {
+#pragma unroll
+                for (int i = 2; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) { SDVAR_MFMA16(c16[i][j], xa[i][pr == 0 ? 1 : 0], wb[bs][j][pr == 1 ? 1 : 0]); }
+                __builtin_amdgcn_sched_barrier(0);
+                if (pf && pr < 2) { issue3(t + 3, 2 * pr); issue3(t + 3, 2 * pr + 1); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (more) rd_g1(t + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        for (int t = 0; t < nk; t += 2) {
+            step(t, std::integral_constant<int, 0>{});
+            if (t + 1 < nk) step(t + 1, std::integral_constant<int, 1>{});
+        }
+#undef SDVAR_MFMA16
+        const float wsi = a.wsi ? *a.wsi : 1.0f;
+        float* outp = (EPI == HEPI_PARTIAL) ? a.out + (size_t)ks * a.M * a.ldo : a.out;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 32 + j * 16 + l16;
+            if (n >= a.N) continue;
+            const float bv = (EPI != HEPI_PARTIAL && a.bias) ? a.bias[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm * 64 + i * 16 + 4 * lc + r;
+                    if (m < a.M) h_store<EPI>(a, outp, c16[i][j][r], wsi, bv, m, n);
+                }
+        }
+        return;
+    }
     // DMA instruction q (0..3) of K-step t (relative) -> stage t % 3: q = 2p is X plane p, q = 2p + 1 is W plane p
     auto issue_one = [&](int t, int q) {
-        uint16_t* st = hsm + (t % (NS == 4 ? 3 : NS)) * H2_STAGE + swave * 512;      // + sub-array * 4096 elements
+        uint16_t* st = hsm + (t % (NS == 4 || NS == 6 ? 3 : NS)) * H2_STAGE + swave * 512;      // + sub-array * 4096 elements
         const int p = q >> 1;
         if (q & 1) SDVAR_DMA16(lw, bw + ((size_t)t * a.N * 32 + p * a.wps) * 2, SDVAR_LDS_ADDR(st + (2 + p) * 4096));
         else SDVAR_DMA16(lx, bx + ((size_t)t * a.M * 32 + p * a.xps) * 2, SDVAR_LDS_ADDR(st + p * 4096));
@@ -350,6 +449,105 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_v2_kernel(GemmHArgs a) {
                 h_store<EPI>(a, outp, acc[i][r], wsi, bv, m, n);
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Small-M kernel (M <= ~150 rows: stages 0-2, the first verify chunk): BM (32 | 64) x 128 tile, 4 waves side by side (BM x 32 outputs each), the LDS-DMA ring
+// of the 128 x 128 kernel but DEEP.  These launches stream each weight byte once and do almost no matrix work, so their time is the memory latency times
+// the number of dependent round trips: the register-staged kernel above keeps ONE K-step (32 k) in flight per workgroup and pays a round trip per K-step
+// (M = 16, N = 4096, K = 1024: 16 MB in 10 us, where a plain streaming read of 16 MB takes 4.2 us launch included: tools/micro/launch_floor.hip).
+//   stage = X planes h, l [BM][32] then W planes h, l [128][32] fp16 (20 / 24 KB), chunk swizzle as the 128 x 128 kernel;
+//   NS stages (7 / 6: 140 / 144 KB, one workgroup per CU), NS - 1 K-steps in flight = 120 KB per CU; one s_barrier per K-step, counted vmcnt waits;
+//   per K-step the 2 (BM / 16 + 8) DMA instructions (16 rows each) are dealt round-robin to the 4 waves: IPS = 5 / 6 each.
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int BM, int NS, int EPI>
+__global__ __launch_bounds__(256) void gemm_f16x2_small_kernel(GemmHArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t hsm[];
+    constexpr int TM = BM / 32, XB = BM / 16, IPS = (2 * (XB + 8)) / 4, STAGE = 2 * (BM + 128) * 32;
+    static_assert((2 * (XB + 8)) % 4 == 0 && (NS - 2) * IPS <= 63, "bad ring");
+    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + HBN - 1) / HBN, ntile = tiles_m * tiles_n;
+    const int ks = blockIdx.x / ntile;
+    const int lid = xcd_remap(blockIdx.x - ks * ntile, ntile);
+    const int tm = lid % tiles_m, tn = lid / tiles_m;         // the row tiles of one column panel are neighbours: they share the weight slice
+    const int m0 = tm * BM, n0 = tn * HBN;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kt0 = ks * a.k_per_split;
+    const int nk = min(a.K / HBK - kt0, a.k_per_split);
+
+    // this wave's DMA instructions j = 0 .. IPS-1 are q = wave + 4 j of the K-step's list: q < 2 XB: X plane q / XB, 16-row block q % XB; else W plane, block
+    const char* gb[IPS]; uint32_t vo[IPS], lo[IPS]; size_t sb[IPS];
+#pragma unroll
+    for (int j = 0; j < IPS; ++j) {
+        const int q = wave + 4 * j;
+        const bool isx = q < 2 * XB;
+        const int qq = isx ? q : q - 2 * XB;
+        const int p = isx ? qq / XB : qq / 8, b = isx ? qq % XB : qq % 8;
+        const int r16 = b * 16 + (lane >> 2);
+        const int grow = isx ? min(m0 + r16, a.M - 1) : min(n0 + r16, a.N - 1);      // clamped: rows past the edge are never stored
+        const int ch = (lane & 3) ^ ((r16 >> 2) & 3);
+        vo[j] = (uint32_t)(grow * 32 + 8 * ch) * 2u;
+        gb[j] = isx ? reinterpret_cast<const char*>(a.X + p * a.xps + (size_t)kt0 * a.M * 32) : reinterpret_cast<const char*>(a.W + p * a.wps + (size_t)kt0 * a.N * 32);
+        sb[j] = (size_t)(isx ? a.M : a.N) * 64;
+        lo[j] = (uint32_t)((isx ? p * BM * 32 : 2 * BM * 32 + p * 4096) + b * 512) * 2u;
+    }
+    auto issue = [&](int t) {
+        const uint32_t st = SDVAR_LDS_ADDR(hsm + (t % NS) * STAGE);
+#pragma unroll
+        for (int j = 0; j < IPS; ++j) SDVAR_DMA16(vo[j], gb[j] + (size_t)t * sb[j], st + lo[j]);
+    };
+
+    f32x16 acc[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const int sw = (li >> 2) & 3;
+    const int offa = li * 32, offb = 2 * BM * 32 + (wave * 32 + li) * 32;
+
+    for (int tt = 0; tt < NS - 1 && tt < nk; ++tt) issue(tt);
+    for (int t = 0; t < nk; ++t) {
+        // K-step t has landed when at most the min(NS - 2, steps behind it) newest K-steps (IPS instructions each) are still in flight
+        switch (min(NS - 2, nk - 1 - t)) {
+            case 0: wait_vmcnt<0>(); break;
+            case 1: wait_vmcnt<IPS>(); break;
+            case 2: wait_vmcnt<2 * IPS>(); break;
+            case 3: wait_vmcnt<3 * IPS>(); break;
+            case 4: wait_vmcnt<(NS > 5 ? 4 : 0) * IPS>(); break;
+            default: wait_vmcnt<(NS > 6 ? 5 : 0) * IPS>(); break;
+        }
+        __builtin_amdgcn_s_barrier();                 // every wave's part of K-step t is in LDS, and every wave is done reading the stage of K-step t - 1
+        if (t + NS - 1 < nk) issue(t + NS - 1);       // ... which K-step t + NS - 1 now overwrites
+        const uint16_t* st = hsm + (t % NS) * STAGE;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int ch = 8 * ((2 * s2 + lh) ^ sw);
+            f16x8 fa[2][TM], fb[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                fb[p] = *reinterpret_cast<const f16x8*>(st + offb + p * 4096 + ch);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[p][i] = *reinterpret_cast<const f16x8*>(st + offa + p * BM * 32 + i * 1024 + ch);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) { SDVAR_MFMA3(acc[i], fa[0][i], fa[1][i], fb[0], fb[1]); }
+        }
+    }
+
+    const float wsi = a.wsi ? *a.wsi : 1.0f;
+    const int n = n0 + wave * 32 + li;
+    if (n < a.N) {
+        const float bv = (EPI != HEPI_PARTIAL && a.bias) ? a.bias[n] : 0.f;
+        float* outp = (EPI == HEPI_PARTIAL) ? a.out + (size_t)ks * a.M * a.ldo : a.out;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m < a.M) h_store<EPI>(a, outp, acc[i][r], wsi, bv, m, n);
+            }
     }
 }
 
@@ -488,9 +686,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_h_kernel(const float* __res
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int m = (int)(i / nv), n = (int)(i % nv) * 4;
         f32x4 acc = *reinterpret_cast<const f32x4*>(ws + (size_t)m * N + n);
-        for (int s = 1; s < split; ++s) {
-            const f32x4 p = *reinterpret_cast<const f32x4*>(ws + s * slab + (size_t)m * N + n);
-            acc[0] += p[0]; acc[1] += p[1]; acc[2] += p[2]; acc[3] += p[3];
+        int s = 1;
+        for (; s + 7 < split; s += 8) {               // eight slab loads in flight, added in slice order (one round trip per group, not per slab)
+            f32x4 p[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) p[u] = *reinterpret_cast<const f32x4*>(ws + (size_t)(s + u) * slab + (size_t)m * N + n);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { acc[0] += p[u][0]; acc[1] += p[u][1]; acc[2] += p[u][2]; acc[3] += p[u][3]; }
+        }
+        if (s < split) {
+            f32x4 p[7];
+#pragma unroll
+            for (int u = 0; u < 7; ++u) if (s + u < split) p[u] = *reinterpret_cast<const f32x4*>(ws + (size_t)(s + u) * slab + (size_t)m * N + n);
+#pragma unroll
+            for (int u = 0; u < 7; ++u) if (s + u < split) { acc[0] += p[u][0]; acc[1] += p[u][1]; acc[2] += p[u][2]; acc[3] += p[u][3]; }
         }
         uint16_t pl[2][4];
 #pragma unroll
@@ -687,7 +896,15 @@ static int g_h2_stages = -1;      // variant of the 128 x 128 kernel: 4 (default
 
 template <int EPI>
 static int launch_h2_kernel(const GemmHArgs& a, int grid, hipStream_t stream) {
-    if (g_h2_stages < 0) { const char* e = getenv("SDVAR_GEMM_H2_STAGES"); g_h2_stages = (e && atoi(e) == 2) ? 2 : (e && atoi(e) == 3) ? 3 : (e && atoi(e) == 5) ? 5 : 4; }
+    if (g_h2_stages < 0) { const char* e = getenv("SDVAR_GEMM_H2_STAGES"); g_h2_stages = (e && atoi(e) == 2) ? 2 : (e && atoi(e) == 3) ? 3 : (e && atoi(e) == 5) ? 5 : (e && atoi(e) == 6) ? 6 : 4; }
+    if (g_h2_stages == 6) {        // 3 stages, software-pipelined fragment reads, 16x16x32 MFMAs
+        const size_t lds = 3 * (size_t)H2_STAGE * sizeof(uint16_t);
+        static LdsOptIn opt_in6;
+        SDVAR_LDS_OPT_IN(opt_in6, lds, (const void*)gemm_f16x2_v2_kernel<EPI, 6>);
+        hipLaunchKernelGGL((gemm_f16x2_v2_kernel<EPI, 6>), dim3(grid), dim3(512), lds, stream, a);
+        SDVAR_LAUNCH_CHECK();
+        return SDVAR_OK;
+    }
     if (g_h2_stages == 5) {        // 5-stage ring (160 KB): four K-steps in flight
         const size_t lds = 5 * (size_t)H2_STAGE * sizeof(uint16_t);
         static LdsOptIn opt_in5;
@@ -794,12 +1011,30 @@ static int launch_h3_hybrid(GemmHArgs a, int epi, int tail, hipStream_t stream) 
     return SDVAR_OK;
 }
 
+static int g_small_old = -1;       // SDVAR_GEMM_SMALL_OLD=1: the register-staged kernel for the 32- and 64-row tiles (A/B runs)
+
+template <int BM, int NS, int EPI>
+static int launch_small_kernel(const GemmHArgs& a, int grid, hipStream_t stream) {
+    const size_t lds = (size_t)NS * 2 * (BM + 128) * 32 * sizeof(uint16_t);
+    static LdsOptIn opt_in;
+    SDVAR_LDS_OPT_IN(opt_in, lds, (const void*)gemm_f16x2_small_kernel<BM, NS, EPI>);
+    hipLaunchKernelGGL((gemm_f16x2_small_kernel<BM, NS, EPI>), dim3(grid), dim3(256), lds, stream, a);
+    SDVAR_LAUNCH_CHECK();
+    return SDVAR_OK;
+}
+template <int BM, int EPI>
+static int launch_small_any(const GemmHArgs& a, int grid, hipStream_t stream) {
+    return BM == 32 ? launch_small_kernel<32, 7, EPI>(a, grid, stream) : launch_small_kernel<64, 6, EPI>(a, grid, stream);
+}
+
 template <int BM, int WAVES_M, int WAVES_N>
 static int launch_h(GemmHArgs a, int epi, int split, hipStream_t stream) {
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + HBN - 1) / HBN);
     const size_t lds = 2 * (size_t)(BM + HBN) * HROW * sizeof(uint16_t);
     dim3 block(256);
     const bool v2 = (BM == 128);
+    if (g_small_old < 0) { const char* e = getenv("SDVAR_GEMM_SMALL_OLD"); g_small_old = (e && atoi(e)) ? 1 : 0; }
+    const bool deep = !v2 && !g_small_old;
     const int nkt = a.K / HBK;
     if (split > 1) {
         size_t wsf = 0;
@@ -808,8 +1043,10 @@ static int launch_h(GemmHArgs a, int epi, int split, hipStream_t stream) {
         GemmHArgs p = a;
         p.out = ws; p.ldo = a.N; p.split = split; p.k_per_split = (nkt + split - 1) / split;
         if (v2) { int rc = launch_h2_kernel<HEPI_PARTIAL>(p, tiles * split, stream); if (rc) return rc; }
+        else if (deep) { int rc = launch_small_any<BM == 32 ? 32 : 64, HEPI_PARTIAL>(p, tiles * split, stream); if (rc) return rc; }
         else { hipLaunchKernelGGL((gemm_f16x2_kernel<BM, WAVES_M, WAVES_N, HEPI_PARTIAL>), dim3(tiles * split), block, lds, stream, p); SDVAR_LAUNCH_CHECK(); }
         if (g_defer_h) { *g_defer_h = split; return SDVAR_OK; }
+        if (a.dbg & 8) return SDVAR_OK;            // timing experiments: the slab launch alone (what a deferring caller pays)
         const size_t total = (size_t)a.M * (a.N / 4);
         const int rgrid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
         switch (epi) {
@@ -826,6 +1063,13 @@ static int launch_h(GemmHArgs a, int epi, int split, hipStream_t stream) {
             case HEPI_BIAS: return launch_h2_kernel<HEPI_BIAS>(a, tiles, stream);
             case HEPI_BIAS_GELU_PLANES: return launch_h2_kernel<HEPI_BIAS_GELU_PLANES>(a, tiles, stream);
             default: return launch_h2_kernel<HEPI_GATED_RES>(a, tiles, stream);
+        }
+    }
+    if (deep) {
+        switch (epi) {
+            case HEPI_BIAS: return launch_small_any<BM == 32 ? 32 : 64, HEPI_BIAS>(a, tiles, stream);
+            case HEPI_BIAS_GELU_PLANES: return launch_small_any<BM == 32 ? 32 : 64, HEPI_BIAS_GELU_PLANES>(a, tiles, stream);
+            default: return launch_small_any<BM == 32 ? 32 : 64, HEPI_GATED_RES>(a, tiles, stream);
         }
     }
     switch (epi) {
