@@ -591,6 +591,7 @@ float* splitk_workspace(size_t* floats);     // gemm.hip: the shared slab worksp
 
 static unsigned long long* g_dbg_stamps = nullptr;
 void debug_set_gemm_stamps(unsigned long long* p) { g_dbg_stamps = p; }
+unsigned long long* debug_get_gemm_stamps() { return g_dbg_stamps; }
 static int g_force_bm_p = 0, g_force_split_p = 0;
 void debug_set_gemm_cfg_p(int bm, int split) { g_force_bm_p = bm; g_force_split_p = split; }
 

@@ -24,6 +24,8 @@
 
 namespace sdvar {
 
+unsigned long long* debug_get_gemm_stamps();      // gemm_bf16x3.hip
+
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 enum { HEPI_BIAS = 0, HEPI_BIAS_GELU_PLANES = 1, HEPI_GATED_RES = 2, HEPI_PARTIAL = 3 };
 
@@ -48,18 +50,25 @@ struct GemmHArgs {
     const float* bias; float* out; uint16_t* outp; size_t ops;
     const float* res; const float* gate;
     int M, N, K, ldo, ldres, rows_per_gate, gate_stride, split, k_per_split;
+    int vec;                 // every pointer of the epilogue 16-byte aligned and every leading dimension a multiple of 4: 16-byte epilogue accesses
     int dbg;                 // timing experiments only (SDVAR_GEMM_DBG, results wrong): bit 0 no DMA inside the K loop, bit 1 no barrier, bit 2 no fragment reads, bit 3 no split-K reduce launch
+    unsigned long long* stamps;   // diagnostic (sdvar_debug_set_gemm_stamps; small-M and 128 x 128 kernels): 8 x u64 per workgroup = s_memrealtime (100 MHz) at
+                                  // entry / first K-step landed / loop end / exit, then s_memtime (core clock) at the same four points
     int tile_off, tile_cnt;  // 256-row kernel only: this launch covers tile ids [tile_off, tile_off + tile_cnt) (tile_cnt = 0: all); with
                              // HEPI_PARTIAL the slabs are compact [split][tile_cnt][256][128]
 };
 
-// acc += Al.Bh + Ah.Bl + Ah.Bh (smallest terms first)
-#define SDVAR_MFMA3(acc, ah, al, bh, bl)                                               \
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);                \
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);                \
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0)
+// acc += Xl.Wh + Xh.Wl + Xh.Wh (smallest terms first), TRANSPOSED: the W fragment is the MFMA's A operand and the X fragment its B operand, so the
+// accumulator holds out^T: lane li = ROW m of the 32-row tile, register r = COLUMN (r & 3) + 8 (r >> 2) + 4 lh of the 32-column tile.  A lane then owns
+// four consecutive columns per register group and every epilogue moves 16 bytes (fp32) or 8 bytes (a plane) per access, with one row index - one
+// division for the gate row - per lane and tile.  With lane = column (the untransposed product) the 128 x 128 kernel spent 5.5 (bias) / 8 (GELU -> planes) /
+// 12-14 us (gated residual) per tile in 4- and 2-byte accesses behind a 23 us K loop at K = 1024 (in-kernel stamps, tools/micro/gemm_stamps_h.py).
+#define SDVAR_MFMA3(acc, xh, xl, wh, wl)                                               \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, acc, 0, 0, 0);                \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc, 0, 0, 0);                \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, acc, 0, 0, 0)
 
-// one output element of every epilogue: v = acc * 2^-S + bias, then the epilogue's own arithmetic
+// one output element of every epilogue: v = acc * 2^-S + bias, then the epilogue's own arithmetic (the edge / unaligned path of h_store_tile)
 template <int EPI>
 __device__ __forceinline__ void h_store(const GemmHArgs& a, float* outp, float accv, float wsi, float bv, int m, int n) {
     float v = accv * wsi + bv;
@@ -71,6 +80,51 @@ __device__ __forceinline__ void h_store(const GemmHArgs& a, float* outp, float a
     } else {
         if (EPI == HEPI_GATED_RES) v = a.res[(size_t)m * a.ldres + n] + v * a.gate[(size_t)(m / a.rows_per_gate) * a.gate_stride + n];
         outp[(size_t)m * a.ldo + n] = v;
+    }
+}
+
+// One 32 x 32 accumulator tile (transposed layout, SDVAR_MFMA3): this lane's row m, columns nb + 8 g + {0..3} for g = 0..3 (nb already holds the lane
+// half's + 4 lh).  a.vec = every pointer 16-byte aligned and every leading dimension a multiple of 4 (checked by the host).
+template <int EPI>
+__device__ __forceinline__ void h_store_tile(const GemmHArgs& a, float* outp, const f32x16& acc, float wsi, int m, int nb) {
+    if (m >= a.M) return;
+    const size_t grow = (EPI == HEPI_GATED_RES) ? (size_t)(m / a.rows_per_gate) * a.gate_stride : 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int n = nb + 8 * g;
+        if (n >= a.N) continue;
+        if (!a.vec || n + 3 >= a.N) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (n + e < a.N) h_store<EPI>(a, outp, acc[4 * g + e], wsi, (EPI != HEPI_PARTIAL && a.bias) ? a.bias[n + e] : 0.f, m, n + e);
+            continue;
+        }
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[4 * g + e] * wsi;
+        if (EPI != HEPI_PARTIAL && a.bias) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] + bv[e];
+        }
+        if (EPI == HEPI_BIAS_GELU_PLANES) {
+            uint16_t h[4], l[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split2h(gelu_tanh_h(v[e]), h[e], l[e]);
+            const size_t o = kb_index(m, n, a.M);
+            uint2 wh, wl;
+            wh.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16); wh.y = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
+            wl.x = (uint32_t)l[0] | ((uint32_t)l[1] << 16); wl.y = (uint32_t)l[2] | ((uint32_t)l[3] << 16);
+            *reinterpret_cast<uint2*>(a.outp + o) = wh; *reinterpret_cast<uint2*>(a.outp + a.ops + o) = wl;
+        } else {
+            if (EPI == HEPI_GATED_RES) {
+                const f32x4 rv = *reinterpret_cast<const f32x4*>(a.res + (size_t)m * a.ldres + n);
+                const f32x4 gv = *reinterpret_cast<const f32x4*>(a.gate + grow + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = rv[e] + v[e] * gv[e];
+            }
+            *reinterpret_cast<f32x4*>(outp + (size_t)m * a.ldo + n) = v;
+        }
     }
 }
 
@@ -169,22 +223,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x2_kernel(GemmHArgs a) {
     }
 
     const float wsi = a.wsi ? *a.wsi : 1.0f;
+    float* outp = (EPI == HEPI_PARTIAL) ? a.out + (size_t)ks * a.M * a.ldo : a.out;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * WN + j * 32 + li;
-        if (n >= a.N) continue;
-        const float bv = (EPI != HEPI_PARTIAL && a.bias) ? a.bias[n] : 0.f;
-        float* outp = (EPI == HEPI_PARTIAL) ? a.out + (size_t)ks * a.M * a.ldo : a.out;
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m >= a.M) continue;
-                h_store<EPI>(a, outp, acc[i][j][r], wsi, bv, m, n);
-            }
-        }
-    }
+        for (int i = 0; i < TM; ++i) h_store_tile<EPI>(a, outp, acc[i][j], wsi, m0 + wm * WM + i * 32 + li, n0 + wn * WN + j * 32 + 4 * lh);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -214,9 +257,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_v2_kernel(GemmHArgs a) {
     const int wm = wave >> 2, wn = wave & 3, li = lane & 31, lh = lane >> 5;
 
     const int drow = 16 * wave + (lane >> 2);
-    // NS == 6 (16x16x32 MFMA: a fragment is 16 rows x 4 chunks): chunk c of row r at c ^ P[(r >> 2) & 3], P = (0, 2, 3, 1) = 0x78 in 2-bit fields, which keeps each
-    // ds_read_b128 lane group ({0-3, 12-15, 20-27}, ...) on 16 different 16-byte slots of the 256-byte bank row
-    const int dchunk = (NS == 6) ? (lane & 3) ^ ((0x78 >> (2 * ((drow >> 2) & 3))) & 3) : (lane & 3) ^ ((drow >> 2) & 3);
+    const int dchunk = (lane & 3) ^ ((drow >> 2) & 3);
     const int xrow = min(m0 + drow, a.M - 1), wrow = min(n0 + drow, a.N - 1);   // clamped: rows past the edge are never stored
     const int kt0 = ks * a.k_per_split;
     const int nk = min(a.K / HBK - kt0, a.k_per_split);
@@ -224,105 +265,9 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_v2_kernel(GemmHArgs a) {
     const uint32_t lx = (uint32_t)(xrow * 32 + 8 * dchunk) * 2u, lw = (uint32_t)(wrow * 32 + 8 * dchunk) * 2u;
     const char* const bx = reinterpret_cast<const char*>(a.X + (size_t)kt0 * a.M * 32);
     const char* const bw = reinterpret_cast<const char*>(a.W + (size_t)kt0 * a.N * 32);
-    if (NS == 6) {
-        // 16x16x32 variant: same ring, DMA and barrier placement as NS == 4; a wave's 64 x 32 outputs are 4 x 2 tiles of 16 x 16 (24 MFMAs of 16 cycles per
-        // K-step), fragments are whole-k32 (one ds_read_b128 each): group 0 = X row tiles 0, 1 + both W column tiles (8 reads), group 1 = X row tiles 2, 3 (4 reads);
-        // the W fragments are double-buffered because group 1 of tile t still uses them when group 0 of tile t+1 is read.
-        f32x4 c16[4][2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) c16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int l16 = lane & 15, lc = lane >> 4;
-        // row offsets inside a sub-array are multiples of 16 rows from (wm * 64 | wn * 32) + l16, so (row >> 2) & 3 == (l16 >> 2)
-        const int rch = 8 * (lc ^ ((0x78 >> (2 * (l16 >> 2))) & 3));
-        const int oa = (wm * 64 + l16) * 32 + rch, ob = (wn * 32 + l16) * 32 + rch;
-        f16x8 xa[4][2], wb[2][2][2];          // xa[row tile][plane], wb[buffer][col tile][plane]
-        auto rd_g0 = [&](int t, int bsel) {
-            const uint32_t sb = (uint32_t)(uintptr_t)(lds_ptr_t)(hsm + (t % 3) * H2_STAGE);
-            const uint32_t aa = sb + 2 * oa, ab = sb + 2 * ob;
-            SDVAR_LDS_RDH(xa[0][1], aa, 8192);  SDVAR_LDS_RDH(wb[bsel][0][0], ab, 16384); SDVAR_LDS_RDH(xa[0][0], aa, 0);    SDVAR_LDS_RDH(wb[bsel][0][1], ab, 24576);
-            SDVAR_LDS_RDH(xa[1][1], aa, 9216);  SDVAR_LDS_RDH(wb[bsel][1][0], ab, 17408); SDVAR_LDS_RDH(xa[1][0], aa, 1024); SDVAR_LDS_RDH(wb[bsel][1][1], ab, 25600);
-        };
-        auto rd_g1 = [&](int t) {
-            const uint32_t sb = (uint32_t)(uintptr_t)(lds_ptr_t)(hsm + (t % 3) * H2_STAGE);
-            const uint32_t aa = sb + 2 * oa;
-            SDVAR_LDS_RDH(xa[2][1], aa, 10240); SDVAR_LDS_RDH(xa[2][0], aa, 2048); SDVAR_LDS_RDH(xa[3][1], aa, 11264); SDVAR_LDS_RDH(xa[3][0], aa, 3072);
-        };
-        auto issue3 = [&](int t, int q) {
-            uint16_t* st = hsm + (t % 3) * H2_STAGE + swave * 512;
-            const int p = q >> 1;
-            if (q & 1) SDVAR_DMA16(lw, bw + ((size_t)t * a.N * 32 + p * a.wps) * 2, SDVAR_LDS_ADDR(st + (2 + p) * 4096));
-            else SDVAR_DMA16(lx, bx + ((size_t)t * a.M * 32 + p * a.xps) * 2, SDVAR_LDS_ADDR(st + p * 4096));
-        };
-#define SDVAR_MFMA16(acc, A, B) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, acc, 0, 0, 0)
-        for (int tt = 0; tt < 3 && tt < nk; ++tt)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) issue3(tt, q);
-        if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        rd_g0(0, 0);
-        rd_g1(0);
-        auto step = [&](int t, auto BSEL) {
-            constexpr int bs = decltype(BSEL)::value;
-            asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            // products smallest first (l.h, h.l, h.h), the four tiles of a group between two accumulations into the same tile
-#pragma unroll
-            for (int pr = 0; pr < 3; ++pr)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) { SDVAR_MFMA16(c16[i][j], xa[i][pr == 0 ? 1 : 0], wb[bs][j][pr == 1 ? 1 : 0]); }
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            const bool more = t + 1 < nk, pf = t + 3 < nk;
-            if (more) rd_g0(t + 1, bs ^ 1);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int pr = 0; pr < 3; ++pr) {
-#pragma unroll
-                for (int i = 2; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) { SDVAR_MFMA16(c16[i][j], xa[i][pr == 0 ? 1 : 0], wb[bs][j][pr == 1 ? 1 : 0]); }
-                __builtin_amdgcn_sched_barrier(0);
-                if (pf && pr < 2) { issue3(t + 3, 2 * pr); issue3(t + 3, 2 * pr + 1); }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (more) rd_g1(t + 1);
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        for (int t = 0; t < nk; t += 2) {
-            step(t, std::integral_constant<int, 0>{});
-            if (t + 1 < nk) step(t + 1, std::integral_constant<int, 1>{});
-        }
-#undef SDVAR_MFMA16
-        const float wsi = a.wsi ? *a.wsi : 1.0f;
-        float* outp = (EPI == HEPI_PARTIAL) ? a.out + (size_t)ks * a.M * a.ldo : a.out;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wn * 32 + j * 16 + l16;
-            if (n >= a.N) continue;
-            const float bv = (EPI != HEPI_PARTIAL && a.bias) ? a.bias[n] : 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = m0 + wm * 64 + i * 16 + 4 * lc + r;
-                    if (m < a.M) h_store<EPI>(a, outp, c16[i][j][r], wsi, bv, m, n);
-                }
-        }
-        return;
-    }
     // DMA instruction q (0..3) of K-step t (relative) -> stage t % 3: q = 2p is X plane p, q = 2p + 1 is W plane p
     auto issue_one = [&](int t, int q) {
-        uint16_t* st = hsm + (t % (NS == 4 || NS == 6 ? 3 : NS)) * H2_STAGE + swave * 512;      // + sub-array * 4096 elements
+        uint16_t* st = hsm + (t % (NS == 4 ? 3 : NS)) * H2_STAGE + swave * 512;      // + sub-array * 4096 elements
         const int p = q >> 1;
         if (q & 1) SDVAR_DMA16(lw, bw + ((size_t)t * a.N * 32 + p * a.wps) * 2, SDVAR_LDS_ADDR(st + (2 + p) * 4096));
         else SDVAR_DMA16(lx, bx + ((size_t)t * a.M * 32 + p * a.xps) * 2, SDVAR_LDS_ADDR(st + p * 4096));
@@ -343,6 +288,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_v2_kernel(GemmHArgs a) {
     const int offa0 = (wm * 64 + li) * 32, offb = (wn * 32 + li) * 32;
     const int ch0 = 8 * ((0 + lh) ^ sw), ch1 = 8 * ((2 + lh) ^ sw);
 
+    unsigned long long vsr[4] = {0, 0, 0, 0}, vsc[4] = {0, 0, 0, 0};
     if (NS == 4) {
         // Software-pipelined variant (template value 4 = "3 stages, pipelined reads"): ONE barrier per K-step, placed where a wave holds every fragment
         // of tile t in registers; behind it tile t+1's first-half fragments are read into the registers the first half of tile t just freed (its
@@ -360,6 +306,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_v2_kernel(GemmHArgs a) {
             if (q & 1) SDVAR_DMA16(lw, bw + ((size_t)t * a.N * 32 + p * a.wps) * 2, SDVAR_LDS_ADDR(st + (2 + p) * 4096));
             else SDVAR_DMA16(lx, bx + ((size_t)t * a.M * 32 + p * a.xps) * 2, SDVAR_LDS_ADDR(st + p * 4096));
         };
+        if (a.stamps) { vsr[0] = __builtin_amdgcn_s_memrealtime(); vsc[0] = __builtin_amdgcn_s_memtime(); }
         for (int tt = 0; tt < 3 && tt < nk; ++tt)
 #pragma unroll
             for (int q = 0; q < 4; ++q) issue3(tt, q);
@@ -367,6 +314,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_v2_kernel(GemmHArgs a) {
         else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        if (a.stamps) { vsr[1] = __builtin_amdgcn_s_memrealtime(); vsc[1] = __builtin_amdgcn_s_memtime(); }
         read_half(0, 0);
         read_half(0, 1);
         for (int t = 0; t < nk; ++t) {
@@ -435,20 +383,19 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_v2_kernel(GemmHArgs a) {
     }
     }
 
+    if (a.stamps) { vsr[2] = __builtin_amdgcn_s_memrealtime(); vsc[2] = __builtin_amdgcn_s_memtime(); }
     const float wsi = a.wsi ? *a.wsi : 1.0f;
-    const int n = n0 + wn * 32 + li;
-    if (n < a.N) {
-        const float bv = (EPI != HEPI_PARTIAL && a.bias) ? a.bias[n] : 0.f;
+    {
         float* outp = (EPI == HEPI_PARTIAL) ? a.out + (size_t)ks * a.M * a.ldo : a.out;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 2; ++i) h_store_tile<EPI>(a, outp, acc[i], wsi, m0 + wm * 64 + i * 32 + li, n0 + wn * 32 + 4 * lh);
+    }
+    if (a.stamps && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        vsr[3] = __builtin_amdgcn_s_memrealtime(); vsc[3] = __builtin_amdgcn_s_memtime();
+        unsigned long long* o = a.stamps + 8 * (size_t)blockIdx.x;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m >= a.M) continue;
-                h_store<EPI>(a, outp, acc[i][r], wsi, bv, m, n);
-            }
-        }
+        for (int i = 0; i < 4; ++i) { o[i] = vsr[i]; o[4 + i] = vsc[i]; }
     }
 }
 
@@ -507,6 +454,8 @@ __global__ __launch_bounds__(256) void gemm_f16x2_small_kernel(GemmHArgs a) {
     const int sw = (li >> 2) & 3;
     const int offa = li * 32, offb = 2 * BM * 32 + (wave * 32 + li) * 32;
 
+    unsigned long long sr[4] = {0, 0, 0, 0}, sc[4] = {0, 0, 0, 0};
+    if (a.stamps) { sr[0] = __builtin_amdgcn_s_memrealtime(); sc[0] = __builtin_amdgcn_s_memtime(); }
     for (int tt = 0; tt < NS - 1 && tt < nk; ++tt) issue(tt);
     for (int t = 0; t < nk; ++t) {
         // K-step t has landed when at most the min(NS - 2, steps behind it) newest K-steps (IPS instructions each) are still in flight
@@ -519,6 +468,7 @@ __global__ __launch_bounds__(256) void gemm_f16x2_small_kernel(GemmHArgs a) {
             default: wait_vmcnt<(NS > 6 ? 5 : 0) * IPS>(); break;
         }
         __builtin_amdgcn_s_barrier();                 // every wave's part of K-step t is in LDS, and every wave is done reading the stage of K-step t - 1
+        if (a.stamps && t == 0) { sr[1] = __builtin_amdgcn_s_memrealtime(); sc[1] = __builtin_amdgcn_s_memtime(); }
         if (t + NS - 1 < nk) issue(t + NS - 1);       // ... which K-step t + NS - 1 now overwrites
         const uint16_t* st = hsm + (t % NS) * STAGE;
 #pragma unroll
@@ -536,18 +486,19 @@ __global__ __launch_bounds__(256) void gemm_f16x2_small_kernel(GemmHArgs a) {
         }
     }
 
+    if (a.stamps) { sr[2] = __builtin_amdgcn_s_memrealtime(); sc[2] = __builtin_amdgcn_s_memtime(); }
     const float wsi = a.wsi ? *a.wsi : 1.0f;
-    const int n = n0 + wave * 32 + li;
-    if (n < a.N) {
-        const float bv = (EPI != HEPI_PARTIAL && a.bias) ? a.bias[n] : 0.f;
+    {
         float* outp = (EPI == HEPI_PARTIAL) ? a.out + (size_t)ks * a.M * a.ldo : a.out;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i) h_store_tile<EPI>(a, outp, acc[i], wsi, m0 + i * 32 + li, n0 + wave * 32 + 4 * lh);
+    }
+    if (a.stamps && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        sr[3] = __builtin_amdgcn_s_memrealtime(); sc[3] = __builtin_amdgcn_s_memtime();
+        unsigned long long* o = a.stamps + 8 * (size_t)blockIdx.x;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m < a.M) h_store<EPI>(a, outp, acc[i][r], wsi, bv, m, n);
-            }
+        for (int i = 0; i < 4; ++i) { o[i] = sr[i]; o[4 + i] = sc[i]; }
     }
 }
 
@@ -651,28 +602,22 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_v3_kernel(GemmHArgs a) {
     const float wsi = a.wsi ? *a.wsi : 1.0f;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + li;
-        if (n >= a.N) continue;
-        const float bv = (EPI != HEPI_PARTIAL && a.bias) ? a.bias[n] : 0.f;
         float* outp = (EPI == HEPI_PARTIAL) ? a.out + (size_t)ks * a.M * a.ldo : a.out;
-        if (EPI == HEPI_PARTIAL && a.tile_cnt > 0) {         // tail tiles of a hybrid launch: compact slab of this (slice, tile)
+        if (EPI == HEPI_PARTIAL && a.tile_cnt > 0) {         // tail tiles of a hybrid launch: compact slab [256][128] of this (slice, tile), every row stored
             float* slab = a.out + ((size_t)ks * a.tile_cnt + (lid - a.tile_off)) * (256 * 128);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    slab[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 128 + wn * 64 + j * 32 + li] = acc[i][j][r] * wsi;
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] * wsi;
+                    *reinterpret_cast<f32x4*>(slab + (wm * 64 + i * 32 + li) * 128 + wn * 64 + j * 32 + 8 * g + 4 * lh) = v;
+                }
             continue;
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m >= a.M) continue;
-                h_store<EPI>(a, outp, acc[i][j][r], wsi, bv, m, n);
-            }
-        }
+        for (int i = 0; i < 2; ++i) h_store_tile<EPI>(a, outp, acc[i][j], wsi, m0 + wm * 64 + i * 32 + li, n0 + wn * 64 + j * 32 + 4 * lh);
     }
 }
 
@@ -896,15 +841,7 @@ static int g_h2_stages = -1;      // variant of the 128 x 128 kernel: 4 (default
 
 template <int EPI>
 static int launch_h2_kernel(const GemmHArgs& a, int grid, hipStream_t stream) {
-    if (g_h2_stages < 0) { const char* e = getenv("SDVAR_GEMM_H2_STAGES"); g_h2_stages = (e && atoi(e) == 2) ? 2 : (e && atoi(e) == 3) ? 3 : (e && atoi(e) == 5) ? 5 : (e && atoi(e) == 6) ? 6 : 4; }
-    if (g_h2_stages == 6) {        // 3 stages, software-pipelined fragment reads, 16x16x32 MFMAs
-        const size_t lds = 3 * (size_t)H2_STAGE * sizeof(uint16_t);
-        static LdsOptIn opt_in6;
-        SDVAR_LDS_OPT_IN(opt_in6, lds, (const void*)gemm_f16x2_v2_kernel<EPI, 6>);
-        hipLaunchKernelGGL((gemm_f16x2_v2_kernel<EPI, 6>), dim3(grid), dim3(512), lds, stream, a);
-        SDVAR_LAUNCH_CHECK();
-        return SDVAR_OK;
-    }
+    if (g_h2_stages < 0) { const char* e = getenv("SDVAR_GEMM_H2_STAGES"); g_h2_stages = (e && atoi(e) == 2) ? 2 : (e && atoi(e) == 3) ? 3 : (e && atoi(e) == 5) ? 5 : 4; }
     if (g_h2_stages == 5) {        // 5-stage ring (160 KB): four K-steps in flight
         const size_t lds = 5 * (size_t)H2_STAGE * sizeof(uint16_t);
         static LdsOptIn opt_in5;
@@ -1096,7 +1033,10 @@ int gemm_f16x2_nt(const uint16_t* X, size_t xps, const uint16_t* W, size_t wps, 
     SDVAR_CHECK_ARG(((uintptr_t)X % 16) == 0 && ((uintptr_t)W % 16) == 0 && xps % 8 == 0 && wps % 8 == 0, "gemm_f16x2: planes must be 16-byte aligned");
     if (epi == HEPI_GATED_RES) SDVAR_CHECK_ARG(res && gate && rows_per_gate > 0 && ldres >= N, "gemm_f16x2: gated-residual epilogue needs res/gate");
     static const int dbg = getenv("SDVAR_GEMM_DBG") ? atoi(getenv("SDVAR_GEMM_DBG")) : 0;
-    GemmHArgs a{X, W, xps, wps, wsi, bias, out, outp, ops, res, gate, M, N, K, ldo, ldres, rows_per_gate > 0 ? rows_per_gate : 1, gate_stride, 1, K / HBK, dbg, 0, 0};
+    GemmHArgs a{X, W, xps, wps, wsi, bias, out, outp, ops, res, gate, M, N, K, ldo, ldres, rows_per_gate > 0 ? rows_per_gate : 1, gate_stride, 1, K / HBK, 0, dbg, debug_get_gemm_stamps(), 0, 0};
+    auto al16 = [](const void* q) { return ((uintptr_t)q % 16) == 0; };
+    a.vec = N % 4 == 0 && al16(bias) && al16(out) && al16(outp) && al16(res) && al16(gate) && ldo % 4 == 0 && ops % 4 == 0 &&
+            (epi != HEPI_GATED_RES || (ldres % 4 == 0 && gate_stride % 4 == 0));
     size_t wsf = 0;
     (void)splitk_workspace(&wsf);
     int bm, split, tail = 0;
