@@ -30,7 +30,6 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 enum { HEPI_BIAS = 0, HEPI_BIAS_GELU_PLANES = 1, HEPI_GATED_RES = 2, HEPI_PARTIAL = 3 };
 
 constexpr int HBK = 32;             // k per LDS stage
-constexpr int HROW = 40;            // padded row of the register-staged kernel, in fp16 elements (80 bytes)
 constexpr int HBN = 128;
 
 // GELU(tanh) (basic_var.py:40): 0.5 x (1 + tanh(u)) = x sigmoid(2u) = x / (1 + 2^(-2u log2 e)) with v_exp_f32 and v_rcp_f32 (1 ulp each, ~2e-7
@@ -126,108 +125,6 @@ __device__ __forceinline__ void h_store_tile(const GemmHArgs& a, float* outp, co
             *reinterpret_cast<f32x4*>(outp + (size_t)m * a.ldo + n) = v;
         }
     }
-}
-
-template <int BM, int WAVES_M, int WAVES_N, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_f16x2_kernel(GemmHArgs a) {
-    constexpr int WM = BM / WAVES_M, WN = HBN / WAVES_N, TM = WM / 32, TN = WN / 32;
-    static_assert(WAVES_M * WAVES_N == 4 && TM >= 1 && TN >= 1, "bad wave layout");
-    constexpr int XCH = (BM * 4 + 255) / 256, WCH = HBN * 4 / 256;   // 16-byte chunks per plane per thread
-    extern __shared__ __attribute__((aligned(16))) uint16_t hsm[];
-    uint16_t* sA = hsm;                       // [2][BM][HROW]
-    uint16_t* sB = hsm + 2 * BM * HROW;       // [2][HBN][HROW]
-
-    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + HBN - 1) / HBN, ntile = tiles_m * tiles_n;
-    const int ks = blockIdx.x / ntile;
-    const int lid = xcd_remap(blockIdx.x - ks * ntile, ntile);
-    const int G = 8, per_group = tiles_m * G;
-    const int g = lid / per_group, rem = lid - g * per_group;
-    const int gw = min(G, tiles_n - g * G);
-    const int tm = rem / gw, tn = g * G + rem % gw;
-    const int m0 = tm * BM, n0 = tn * HBN;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WAVES_N, wn = wave % WAVES_N, li = lane & 31, lh = lane >> 5;
-
-    f32x4 rx[2][XCH], rw[2][WCH];
-    auto load_tile = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < XCH; ++i) {
-            const int c = tid + 256 * i, row = c >> 2, col = (c & 3) * 8;
-            const int m = m0 + row;
-            const bool ok = (BM * 4 >= 256 || c < BM * 4) && m < a.M;
-#pragma unroll
-            for (int p = 0; p < 2; ++p)
-                rx[p][i] = ok ? *reinterpret_cast<const f32x4*>(a.X + p * a.xps + ((size_t)(k0 >> 5) * a.M + m) * 32 + col) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int i = 0; i < WCH; ++i) {
-            const int c = tid + 256 * i, row = c >> 2, col = (c & 3) * 8;
-            const int n = n0 + row;
-#pragma unroll
-            for (int p = 0; p < 2; ++p)
-                rw[p][i] = (n < a.N) ? *reinterpret_cast<const f32x4*>(a.W + p * a.wps + ((size_t)(k0 >> 5) * a.N + n) * 32 + col) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    };
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int i = 0; i < XCH; ++i) {
-            const int c = tid + 256 * i, row = c >> 2, col = (c & 3) * 8;
-            if (BM * 4 >= 256 || c < BM * 4) {
-#pragma unroll
-                for (int p = 0; p < 2; ++p) *reinterpret_cast<f32x4*>(sA + (p * BM + row) * HROW + col) = rx[p][i];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < WCH; ++i) {
-            const int c = tid + 256 * i, row = c >> 2, col = (c & 3) * 8;
-#pragma unroll
-            for (int p = 0; p < 2; ++p) *reinterpret_cast<f32x4*>(sB + (p * HBN + row) * HROW + col) = rw[p][i];
-        }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int kt0 = ks * a.k_per_split;
-    const int nk = min(a.K / HBK - kt0, a.k_per_split);
-    load_tile(kt0 * HBK);
-    store_tile();
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) load_tile((kt0 + kt + 1) * HBK);
-        const uint16_t* pa = sA + (wm * WM + li) * HROW + 8 * lh;
-        const uint16_t* pb = sB + (wn * WN + li) * HROW + 8 * lh;
-#pragma unroll
-        for (int s = 0; s < HBK / 16; ++s) {
-            f16x8 fa[2][TM], fb[2][TN];
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) fa[p][i] = *reinterpret_cast<const f16x8*>(pa + (p * BM + i * 32) * HROW + 16 * s);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) fb[p][j] = *reinterpret_cast<const f16x8*>(pb + (p * HBN + j * 32) * HROW + 16 * s);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) { SDVAR_MFMA3(acc[i][j], fa[0][i], fa[1][i], fb[0][j], fb[1][j]); }
-        }
-        __syncthreads();                        // every wave is done reading this stage
-        if (kt + 1 < nk) { store_tile(); __syncthreads(); }
-    }
-
-    const float wsi = a.wsi ? *a.wsi : 1.0f;
-    float* outp = (EPI == HEPI_PARTIAL) ? a.out + (size_t)ks * a.M * a.ldo : a.out;
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int i = 0; i < TM; ++i) h_store_tile<EPI>(a, outp, acc[i][j], wsi, m0 + wm * WM + i * 32 + li, n0 + wn * WN + j * 32 + 4 * lh);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -400,13 +297,15 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_v2_kernel(GemmHArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Small-M kernel (M <= ~150 rows: stages 0-2, the first verify chunk): BM (32 | 64) x 128 tile, 4 waves side by side (BM x 32 outputs each), the LDS-DMA ring
-// of the 128 x 128 kernel but DEEP.  These launches stream each weight byte once and do almost no matrix work, so their time is the memory latency times
-// the number of dependent round trips: the register-staged kernel above keeps ONE K-step (32 k) in flight per workgroup and pays a round trip per K-step
-// (M = 16, N = 4096, K = 1024: 16 MB in 10 us, where a plain streaming read of 16 MB takes 4.2 us launch included: tools/micro/launch_floor.hip).
+// Small-tile kernel (32- and 64-row tiles: stages 0-5, the first verify chunks): BM x 128 tile, 4 waves side by side (BM x 32 outputs each), the LDS-DMA
+// ring of the 128 x 128 kernel.  These launches stream each weight byte once and do little matrix work: their time is launch + first-operand latency +
+// a short K loop, so what counts is bytes in flight and resident waves, not the MFMA schedule.
 //   stage = X planes h, l [BM][32] then W planes h, l [128][32] fp16 (20 / 24 KB), chunk swizzle as the 128 x 128 kernel;
-//   NS stages (7 / 6: 140 / 144 KB, one workgroup per CU), NS - 1 K-steps in flight = 120 KB per CU; one s_barrier per K-step, counted vmcnt waits;
+//   NS = 3 stages (60 / 72 KB: two workgroups = 8 waves per CU), two K-steps in flight per workgroup; one s_barrier per K-step, counted vmcnt waits;
 //   per K-step the 2 (BM / 16 + 8) DMA instructions (16 rows each) are dealt round-robin to the 4 waves: IPS = 5 / 6 each.
+// Measured with HBM-cold weights (tools/micro/gemm_cold_mid.py, slab launch alone): against the register-staged kernel it replaces (one K-step in
+// flight, two barriers per K-step) M = 64: qkv 8.1 -> 7.0, fc1 8.8 -> 7.4, fc2 10.0 -> 8.0 us; M = 16: 5.8 -> 5.7, 6.4 -> 6.0, 8.7 -> 7.8 us; a 6- / 7-stage
+// ring with one workgroup per CU (everything in flight) was no faster at M = 16 and slower from M = 64 (one wave per SIMD).
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int BM, int NS, int EPI>
@@ -765,29 +664,33 @@ int split_planes_f16(const float* x, uint16_t* planes, int rows, int cols, size_
 
 float* splitk_workspace(size_t* floats);     // gemm.hip: the shared slab workspace
 
-// cost-model constants (see choose_cfg_h; `tools/fit_gemm_model.py profiles/r02_gemm_sweep_f16x2.jsonl 192`: geometric-mean
-// regret 4.1 %, worst case 30 %, over the d12 / d16 shapes incl. gamma = 2 chunks)
+// cost-model constants (see choose_cfg_h).  Fitted to a sweep with HBM-COLD weights (tools/micro/gemm_sweep_cold.sh: rotating weight tensors, as inside a
+// model pass; the earlier fit re-read one weight tensor out of the Infinity Cache) in which the launches whose K-slice sum a consumer kernel takes over are
+// timed as the slab launch alone and charged the consumer's slab reads instead of a reduce launch:
+// `tools/fit_gemm_model.py profiles/r02_gemm_sweep_cold_full.jsonl 192 profiles/r02_gemm_sweep_cold_slab.jsonl`: geometric-mean regret 1.1 %, worst case
+// 16 %, over the d12 / d16 shapes incl. gamma = 2 chunks (the constants before this fit: 6 % / 1.44x on the same data)
 #define CM_R256 1
 #define CM_R128 1
-#define CM_R64 3
-#define CM_R32 3
-#define CM_P256 1.1
-#define CM_P64 1.3
-#define CM_P32 1.3
+#define CM_R64 2
+#define CM_R32 2
+#define CM_P256 1.0
+#define CM_P64 1.1
+#define CM_P32 1.8
 #define CM_L1 1.0
-#define CM_L2 1.1
-#define CM_L3 1.05
-#define CM_KOVER 600.0
-#define CM_FIX 12000.0
+#define CM_L2 0.8
+#define CM_L3 1.0
+#define CM_KOVER 260.0
+#define CM_FIX 8000.0
 #define CM_FIXBM 80.0
-#define CM_RED0 2000.0
-#define CM_REDBW 8000.0
+#define CM_RED0 4000.0
+#define CM_REDBW 5000.0
+#define CM_DEFBW 2000.0     // bytes per cycle at which a deferring consumer (ln_modulate, qk_norm_append) reads the slabs: not fitted
 
 static int g_force_bm_h = 0, g_force_split_h = 0;
 void debug_set_gemm_cfg_h(int bm, int split) { g_force_bm_h = bm; g_force_split_h = split; }
 
 // same cost model as gemm_bf16x3.hip with half the matrix work per K-step: 3 MFMAs x 32 cycles per 16 k per 32x32 tile
-static void choose_cfg_h(int M, int N, int K, size_t ws_floats, int* bm_out, int* split_out, int* tail_out, bool allow_hybrid) {
+static void choose_cfg_h(int M, int N, int K, size_t ws_floats, int* bm_out, int* split_out, int* tail_out, bool allow_hybrid, bool deferred) {
     const int nkt = K / HBK, tiles_n = (N + HBN - 1) / HBN;
     double best = 1e30; int bbm = 128, bs = 1, btail = 0;
     // per row-tile constants fitted to tools/gemm_bench.py --mode bf16x3 --sweep --dump (tools/fit_gemm_model.py):
@@ -810,7 +713,7 @@ static void choose_cfg_h(int M, int N, int K, size_t ws_floats, int* bm_out, int
             const long full = per_cu / res, rem = per_cu % res;
             const double l_full = (bm == 256) ? 1.0 : lat[res < 4 ? res : 4], l_rem = (bm == 256) ? 1.0 : lat[rem < 4 ? rem : 4];
             double cyc = full * res * T * l_full + (rem ? rem * T * l_rem : 0.0);
-            if (split > 1) cyc += CM_RED0 + (double)(split + 1) * M * N * 4.0 / CM_REDBW;
+            if (split > 1) cyc += deferred ? (double)split * M * N * 4.0 / CM_DEFBW : CM_RED0 + (double)(split + 1) * M * N * 4.0 / CM_REDBW;
             if (cyc < best) { best = cyc; bbm = bm; bs = split; btail = 0; }
         }
         // hybrid for the 256-row tile: the full rounds run unsplit, only the last, partial round is split along K so that it, too,
@@ -948,8 +851,6 @@ static int launch_h3_hybrid(GemmHArgs a, int epi, int tail, hipStream_t stream) 
     return SDVAR_OK;
 }
 
-static int g_small_old = -1;       // SDVAR_GEMM_SMALL_OLD=1: the register-staged kernel for the 32- and 64-row tiles (A/B runs)
-
 template <int BM, int NS, int EPI>
 static int launch_small_kernel(const GemmHArgs& a, int grid, hipStream_t stream) {
     const size_t lds = (size_t)NS * 2 * (BM + 128) * 32 * sizeof(uint16_t);
@@ -960,18 +861,13 @@ static int launch_small_kernel(const GemmHArgs& a, int grid, hipStream_t stream)
     return SDVAR_OK;
 }
 template <int BM, int EPI>
-static int launch_small_any(const GemmHArgs& a, int grid, hipStream_t stream) {
-    return BM == 32 ? launch_small_kernel<32, 7, EPI>(a, grid, stream) : launch_small_kernel<64, 6, EPI>(a, grid, stream);
-}
+static int launch_small_any(const GemmHArgs& a, int grid, hipStream_t stream) { return launch_small_kernel<BM, 3, EPI>(a, grid, stream); }
 
-template <int BM, int WAVES_M, int WAVES_N>
+template <int BM>
 static int launch_h(GemmHArgs a, int epi, int split, hipStream_t stream) {
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + HBN - 1) / HBN);
-    const size_t lds = 2 * (size_t)(BM + HBN) * HROW * sizeof(uint16_t);
-    dim3 block(256);
-    const bool v2 = (BM == 128);
-    if (g_small_old < 0) { const char* e = getenv("SDVAR_GEMM_SMALL_OLD"); g_small_old = (e && atoi(e)) ? 1 : 0; }
-    const bool deep = !v2 && !g_small_old;
+    constexpr bool v2 = (BM == 128);
+    constexpr int SB = BM == 32 ? 32 : 64;
     const int nkt = a.K / HBK;
     if (split > 1) {
         size_t wsf = 0;
@@ -979,43 +875,18 @@ static int launch_h(GemmHArgs a, int epi, int split, hipStream_t stream) {
         if (!ws) return SDVAR_ERR_HIP;
         GemmHArgs p = a;
         p.out = ws; p.ldo = a.N; p.split = split; p.k_per_split = (nkt + split - 1) / split;
-        if (v2) { int rc = launch_h2_kernel<HEPI_PARTIAL>(p, tiles * split, stream); if (rc) return rc; }
-        else if (deep) { int rc = launch_small_any<BM == 32 ? 32 : 64, HEPI_PARTIAL>(p, tiles * split, stream); if (rc) return rc; }
-        else { hipLaunchKernelGGL((gemm_f16x2_kernel<BM, WAVES_M, WAVES_N, HEPI_PARTIAL>), dim3(tiles * split), block, lds, stream, p); SDVAR_LAUNCH_CHECK(); }
+        int rc = v2 ? launch_h2_kernel<HEPI_PARTIAL>(p, tiles * split, stream) : launch_small_any<SB, HEPI_PARTIAL>(p, tiles * split, stream);
+        if (rc) return rc;
         if (g_defer_h) { *g_defer_h = split; return SDVAR_OK; }
         if (a.dbg & 8) return SDVAR_OK;            // timing experiments: the slab launch alone (what a deferring caller pays)
-        const size_t total = (size_t)a.M * (a.N / 4);
-        const int rgrid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-        switch (epi) {
-            case HEPI_BIAS: hipLaunchKernelGGL(splitk_reduce_h_kernel<HEPI_BIAS>, dim3(rgrid), block, 0, stream, ws, split, a.bias, a.out, a.outp, a.ops, a.res, a.gate, a.M, a.N, a.ldo, a.ldres, a.rows_per_gate, a.gate_stride); break;
-            case HEPI_BIAS_GELU_PLANES: hipLaunchKernelGGL(splitk_reduce_h_kernel<HEPI_BIAS_GELU_PLANES>, dim3(rgrid), block, 0, stream, ws, split, a.bias, a.out, a.outp, a.ops, a.res, a.gate, a.M, a.N, a.ldo, a.ldres, a.rows_per_gate, a.gate_stride); break;
-            default: hipLaunchKernelGGL(splitk_reduce_h_kernel<HEPI_GATED_RES>, dim3(rgrid), block, 0, stream, ws, split, a.bias, a.out, a.outp, a.ops, a.res, a.gate, a.M, a.N, a.ldo, a.ldres, a.rows_per_gate, a.gate_stride); break;
-        }
-        SDVAR_LAUNCH_CHECK();
-        return SDVAR_OK;
+        return launch_reduce_h(a, ws, split, epi, stream);
     }
     a.split = 1; a.k_per_split = nkt;
-    if (v2) {
-        switch (epi) {
-            case HEPI_BIAS: return launch_h2_kernel<HEPI_BIAS>(a, tiles, stream);
-            case HEPI_BIAS_GELU_PLANES: return launch_h2_kernel<HEPI_BIAS_GELU_PLANES>(a, tiles, stream);
-            default: return launch_h2_kernel<HEPI_GATED_RES>(a, tiles, stream);
-        }
-    }
-    if (deep) {
-        switch (epi) {
-            case HEPI_BIAS: return launch_small_any<BM == 32 ? 32 : 64, HEPI_BIAS>(a, tiles, stream);
-            case HEPI_BIAS_GELU_PLANES: return launch_small_any<BM == 32 ? 32 : 64, HEPI_BIAS_GELU_PLANES>(a, tiles, stream);
-            default: return launch_small_any<BM == 32 ? 32 : 64, HEPI_GATED_RES>(a, tiles, stream);
-        }
-    }
     switch (epi) {
-        case HEPI_BIAS: hipLaunchKernelGGL((gemm_f16x2_kernel<BM, WAVES_M, WAVES_N, HEPI_BIAS>), dim3(tiles), block, lds, stream, a); break;
-        case HEPI_BIAS_GELU_PLANES: hipLaunchKernelGGL((gemm_f16x2_kernel<BM, WAVES_M, WAVES_N, HEPI_BIAS_GELU_PLANES>), dim3(tiles), block, lds, stream, a); break;
-        default: hipLaunchKernelGGL((gemm_f16x2_kernel<BM, WAVES_M, WAVES_N, HEPI_GATED_RES>), dim3(tiles), block, lds, stream, a); break;
+        case HEPI_BIAS: return v2 ? launch_h2_kernel<HEPI_BIAS>(a, tiles, stream) : launch_small_any<SB, HEPI_BIAS>(a, tiles, stream);
+        case HEPI_BIAS_GELU_PLANES: return v2 ? launch_h2_kernel<HEPI_BIAS_GELU_PLANES>(a, tiles, stream) : launch_small_any<SB, HEPI_BIAS_GELU_PLANES>(a, tiles, stream);
+        default: return v2 ? launch_h2_kernel<HEPI_GATED_RES>(a, tiles, stream) : launch_small_any<SB, HEPI_GATED_RES>(a, tiles, stream);
     }
-    SDVAR_LAUNCH_CHECK();
-    return SDVAR_OK;
 }
 
 // X planes [2][K/32][M][32] (plane stride xps), W planes [2][K/32][N][32] of W * 2^S (plane stride wps), wsi -> 2^-S on the device (null: 1).
@@ -1041,7 +912,7 @@ int gemm_f16x2_nt(const uint16_t* X, size_t xps, const uint16_t* W, size_t wps, 
     (void)splitk_workspace(&wsf);
     int bm, split, tail = 0;
     static const bool no_hybrid = getenv("SDVAR_GEMM_NO_HYBRID") != nullptr;       // A/B runs only
-    choose_cfg_h(M, N, K, wsf, &bm, &split, &tail, !no_hybrid);
+    choose_cfg_h(M, N, K, wsf, &bm, &split, &tail, !no_hybrid, defer != nullptr);
     if (g_force_bm_h) { bm = g_force_bm_h; tail = 0; }
     static const bool trace = getenv("SDVAR_GEMM_TRACE") != nullptr;
     if (trace) fprintf(stderr, "[gemm_f16x2] M=%d N=%d K=%d epi=%d -> bm=%d split=%d tail=%d\n", M, N, K, epi, bm, split, tail);
@@ -1055,9 +926,9 @@ int gemm_f16x2_nt(const uint16_t* X, size_t xps, const uint16_t* W, size_t wps, 
     }
     if (bm == 256 && tail > 0) return launch_h3_hybrid(a, epi, tail, stream);
     if (bm == 256) return launch_h3(a, epi, split, stream);
-    if (bm == 32) return launch_h<32, 1, 4>(a, epi, split, stream);
-    if (bm == 64) return launch_h<64, 2, 2>(a, epi, split, stream);
-    return launch_h<128, 2, 2>(a, epi, split, stream);
+    if (bm == 32) return launch_h<32>(a, epi, split, stream);
+    if (bm == 64) return launch_h<64>(a, epi, split, stream);
+    return launch_h<128>(a, epi, split, stream);
 }
 
 }  // namespace sdvar

@@ -1,12 +1,25 @@
 #!/usr/bin/env python3
 """Fit the constants of gemm_bf16x3.hip::choose_cfg_p / gemm_f16x2.hip::choose_cfg_h to a sweep dump
-(tools/gemm_bench.py --mode bf16x3|f16x2 --sweep --dump F).   python tools/fit_gemm_model.py F [ktile: 384 (bf16x3, default) | 192 (f16x2)]
-Random search minimising the geometric-mean regret (time of the model's pick / time of the best swept configuration)."""
+(tools/gemm_bench.py --mode bf16x3|f16x2 --sweep --dump F).   python tools/fit_gemm_model.py F [ktile: 384 (bf16x3, default) | 192 (f16x2)] [F_slab]
+Random search minimising the geometric-mean regret (time of the model's pick / time of the best swept configuration).
+With F_slab (tools/micro/gemm_sweep_cold.sh: the same sweep with SDVAR_GEMM_DBG=8, the slab launch alone) the launches whose K-slice sum a consumer kernel
+takes over (every op but fc1) are taken from F_slab and charged DEFER_US per slab byte for the consumer's extra reads instead of a reduce launch."""
 import json, math, random, sys
 rows = [json.loads(l) for l in open(sys.argv[1])]
 KTILE = float(sys.argv[2]) if len(sys.argv) > 2 else 384.0
+DEFBW = 2000.0                       # bytes per cycle the consumer reads slabs at (fixed, not fitted): ~4 TB/s
+for r in rows: r['deferred'] = False
+if len(sys.argv) > 3:
+    rows = [r for r in rows if r['op'] == 'fc1']
+    for l in open(sys.argv[3]):
+        r = json.loads(l)
+        if r['op'] == 'fc1': continue
+        r['deferred'] = True
+        # the consumer's slab reads, in microseconds at 2.1 GHz, so that picks are ranked by what the model pass pays
+        r['cands'] = [(t + (sp * r['M'] * r['N'] * 4.0 / DEFBW / 2100.0 if sp > 1 else 0.0), bm, sp) for t, bm, sp in r['cands']]
+        rows.append(r)
 
-def model(M, N, K, bm, split, c):
+def model(M, N, K, bm, split, c, deferred=False):
     nkt, tiles_n = K // 32, (N + 127) // 128
     res = {256: 1, 128: c['r128'], 64: c['r64'], 32: c['r32']}[bm]
     tiles = ((M + bm - 1) // bm) * tiles_n
@@ -20,7 +33,7 @@ def model(M, N, K, bm, split, c):
     lr = 1.0 if bm == 256 else lat[min(rem, 4)]
     cyc = full * res * T * lf + (rem * T * lr if rem else 0)
     if split > 1:
-        cyc += c['red0'] + (split + 1) * M * N * 4.0 / c['redbw']
+        cyc += split * M * N * 4.0 / DEFBW if deferred else c['red0'] + (split + 1) * M * N * 4.0 / c['redbw']
     return cyc
 
 def regret(c, verbose=False):
@@ -28,7 +41,7 @@ def regret(c, verbose=False):
     for r in rows:
         cands = r['cands']
         best = min(t for t, _, _ in cands)
-        pick = min(cands, key=lambda x: model(r['M'], r['N'], r['K'], x[1], x[2], c))
+        pick = min(cands, key=lambda x: model(r['M'], r['N'], r['K'], x[1], x[2], c, r['deferred']))
         reg = pick[0] / best
         tot += math.log(reg); worst = max(worst, reg)
         if verbose and reg > 1.08:
@@ -36,9 +49,9 @@ def regret(c, verbose=False):
     return math.exp(tot / len(rows)), worst
 
 base = dict(r128=2, r64=2, r32=4, p256=1.0, p64=1.2, p32=1.2, kover=600, fix=8000, fixbm=80, l1=1.5, l2=1.4, l3=1.05, red0=4000, redbw=5000)
-space = dict(p256=[0.8, 0.85, 0.9, 0.95, 1.0, 1.1], p64=[1.0, 1.1, 1.2, 1.3], p32=[1.1, 1.2, 1.3, 1.5], kover=[100, 260, 400, 600, 900, 1200],
-             fix=[1500, 3000, 5000, 8000, 12000], fixbm=[0, 20, 40, 80], l1=[1.0, 1.2, 1.5, 2.0], l2=[1.0, 1.1, 1.2, 1.4], l3=[1.0, 1.05, 1.1],
-             red0=[2000, 4000, 6000, 10000], redbw=[1800, 3000, 5000, 8000], r128=[1, 2], r64=[2, 3], r32=[3, 4])
+space = dict(p256=[0.8, 0.85, 0.9, 0.95, 1.0, 1.1, 1.2], p64=[0.9, 1.0, 1.1, 1.2, 1.3, 1.5], p32=[0.9, 1.0, 1.1, 1.2, 1.3, 1.5, 1.8], kover=[100, 260, 400, 600, 900, 1200, 1600],
+             fix=[1500, 3000, 5000, 8000, 12000, 16000], fixbm=[0, 20, 40, 80], l1=[0.6, 0.8, 1.0, 1.2, 1.5, 2.0], l2=[0.6, 0.7, 0.8, 1.0, 1.1, 1.2, 1.4], l3=[1.0, 1.05, 1.1],
+             red0=[2000, 4000, 6000, 10000, 14000], redbw=[1800, 3000, 5000, 8000], r128=[1, 2], r64=[2, 3], r32=[2, 3, 4])
 random.seed(0)
 best = (regret(base)[0], base)
 print('start', regret(base))

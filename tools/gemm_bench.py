@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--mode", default="f32", choices=["f32", "bf16x3", "f16x2"])
     ap.add_argument("--dump", default="", help="append the full sweep table (JSON lines) to this file")
     ap.add_argument("--sweep", action="store_true", help="time every (row tile, K slices) candidate per shape")
+    ap.add_argument("--cold", action="store_true", help="f16x2: rotate through ~600 MB of weight tensors per shape so that every launch streams its weights from HBM, "
+                    "as inside a model pass (the default re-reads one tensor, which stays in the 256 MB Infinity Cache)")
     a = ap.parse_args()
     lib = E.load_library()
     dev = torch.device("cuda:0")
@@ -43,12 +45,15 @@ def main():
                 E._check(lib.sdvar_op_split_planes(C.c_void_p(W.data_ptr()), C.c_void_p(Wp.data_ptr()), N, K, N * K, st))
                 outp = torch.empty(3, M, N, dtype=torch.int16, device=dev)
             if a.mode == "f16x2":
-                Xp = torch.empty(2, M, K, dtype=torch.int16, device=dev); Wp = torch.empty(2, N, K, dtype=torch.int16, device=dev); wsc = torch.zeros(4, device=dev)
+                Xp = torch.empty(2, M, K, dtype=torch.int16, device=dev); wsc = torch.zeros(4, device=dev)
                 E._check(lib.sdvar_op_split_planes_f16(C.c_void_p(X.data_ptr()), C.c_void_p(Xp.data_ptr()), M, K, M * K, None, st))
-                E._check(lib.sdvar_op_split_planes_f16(C.c_void_p(W.data_ptr()), C.c_void_p(Wp.data_ptr()), N, K, N * K, C.c_void_p(wsc.data_ptr()), st))
+                Wps = [torch.empty(2, N, K, dtype=torch.int16, device=dev) for _ in range(max(2, int(600e6 / (N * K * 4))) if a.cold else 1)]
+                for Wp in Wps: E._check(lib.sdvar_op_split_planes_f16(C.c_void_p(W.data_ptr()), C.c_void_p(Wp.data_ptr()), N, K, N * K, C.c_void_p(wsc.data_ptr()), st))
                 outp = torch.empty(2, M, N, dtype=torch.int16, device=dev)
+            calls = [0]
             def run():
                 if a.mode == "f16x2":
+                    calls[0] += 1; Wp = Wps[calls[0] % len(Wps)]
                     E._check(lib.sdvar_op_gemm_f16x2(C.c_void_p(Xp.data_ptr()), M * K, C.c_void_p(Wp.data_ptr()), N * K, C.c_void_p(wsc.data_ptr()), C.c_void_p(b.data_ptr()),
                                                      C.c_void_p(out.data_ptr()), N, C.c_void_p(outp.data_ptr()), M * N, M, N, K, epi,
                                                      C.c_void_p(out.data_ptr()) if epi == 2 else None, N, C.c_void_p(gate.data_ptr()) if epi == 2 else None, l, 6 * Cw, st))
@@ -64,9 +69,10 @@ def main():
                 for _ in range(3): run()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                for _ in range(a.iters): run()
+                n = max(a.iters, 2 * len(Wps)) if a.mode == "f16x2" and a.cold else a.iters
+                for _ in range(n): run()
                 e1.record(); torch.cuda.synchronize()
-                return e0.elapsed_time(e1) * 1e3 / a.iters
+                return e0.elapsed_time(e1) * 1e3 / n
             us = timeit()
             if a.sweep:
                 res = []
@@ -79,7 +85,8 @@ def main():
                 if a.dump:
                     import json
                     with open(a.dump, "a") as f:
-                        f.write(json.dumps(dict(mode=a.mode, op=name, M=M, N=N, K=K, auto_us=us, cands=[(t, bm, sp) for t, bm, sp in res])) + "\n")
+                        f.write(json.dumps(dict(mode=a.mode, op=name, M=M, N=N, K=K, auto_us=us, cold=bool(a.cold), slab_only=bool(int(os.environ.get("SDVAR_GEMM_DBG", "0")) & 8),
+                                                cands=[(t, bm, sp) for t, bm, sp in res])) + "\n")
                 res.sort()
                 print(f"   sweep {name} M={M}: auto {us:.1f}us; best " + ", ".join(f"{t:.1f}us(bm{bm},s{sp})" for t, bm, sp in res[:4]))
             fl = 2.0 * M * N * K
