@@ -19,7 +19,9 @@ int ln_modulate(float* x, const float* scale, const float* shift, float* out, ui
 float* splitk_workspace(size_t* floats);
 float* set_splitk_workspace(float* p);
 size_t splitk_workspace_floats();
-int qk_norm_append(const float* qkv, const float* scale_mul, float* q_out, void* k_cache, void* v_cache, int kv_f16, int R, int l, int H, int Lmax, int pos0, const PendingSplitK* pend, hipStream_t stream);
+int qk_norm_append(const float* qkv, const float* scale_mul, float* q_out, void* k_cache, void* v_cache, int kv_f16, int R, int l, int H, int Lmax, int pos0, const PendingSplitK* pend, int v_only, hipStream_t stream);
+int gemm_f16x2_qkv(const uint16_t* X, size_t xps, const uint16_t* W, size_t wps, const float* wsi, const float* bias, float* out, int ldo, int M, int N, int K,
+                   const float* scale_mul, float* q_out, void* k_cache, int l, int H, int Lp, int pos0, int kv_fmt, int* defer, int* fused, hipStream_t stream);
 int silu_rows(const float* x, float* y, int n, hipStream_t stream);
 int add_row_vector(const float* src, const float* vec, float* out, int rows, int cols, hipStream_t stream);
 int prologue(const long long* labels, const float* class_emb, const float* pos_start, const float* lvl_pos, float* cond, float* x0, int B, int C, int num_classes, hipStream_t stream);
@@ -447,12 +449,17 @@ static int stage_forward_impl(sdvar_model_t* m, float* x, int32_t s0, int32_t n,
         if (!(skip & 1)) { ProfScope pp(2, 8 * dM * dC, (P ? 10 : 8) * dM * dC, s);
           SDVAR_TRY(ln_modulate(x, ada + 2 * C, ada + 4 * C, m->xn, P ? m->xn_p : nullptr, ps, M, C, lsum, 6 * C, &pend, PF, s)); pend.ws = nullptr; }
         PendingSplitK pq{nullptr, nullptr, nullptr, 0, 1, 0};
+        int qk_fused = 0;        // the QKV launch came out unsplit and finished q and k in its epilogue (f16x2 planes cache): only V^T is left for qk_norm_append
         if (!(skip & 16)) { ProfScope pp(0, 2 * dM * 3 * dC * dC, 4 * (dM * dC + 3 * dC * dC + 3 * dM * dC), s);
-          if (P) { SDVAR_TRY(plane_gemm(m, m->xn_p, ps, b.qkv_wp, (size_t)3 * C * C, b.wsc, b.qkv_bias, m->qkv, 3 * C, nullptr, 0, M, 3 * C, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, dp, s));
+          if (P && m->d.gemm_mode == 2 && (m->kv_fmt == 3 || m->kv_fmt == 4)) {
+                   SDVAR_TRY(gemm_f16x2_qkv(m->xn_p, ps, b.qkv_wp, (size_t)3 * C * C, b.wsc + 1, b.qkv_bias, m->qkv, 3 * C, M, 3 * C, C, b.scale_mul, m->qbuf, b.kc, lsum, H, m->Lkv,
+                                            m->kv_len, m->kv_fmt, dp, &qk_fused, s));
+                   if (defer) pq = PendingSplitK{ws, b.qkv_bias, nullptr, defer, 1, 0}; }
+          else if (P) { SDVAR_TRY(plane_gemm(m, m->xn_p, ps, b.qkv_wp, (size_t)3 * C * C, b.wsc, b.qkv_bias, m->qkv, 3 * C, nullptr, 0, M, 3 * C, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, dp, s));
                    if (defer) pq = PendingSplitK{ws, b.qkv_bias, nullptr, defer, 1, 0}; }
           else SDVAR_TRY(gemm_f32_nt(m->xn, C, b.qkv_w, b.qkv_bias, m->qkv, 3 * C, M, 3 * C, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, s)); }
         if (!(skip & 2)) { ProfScope pp(3, 6 * dM * dC, 4 * 6 * dM * dC, s);
-          SDVAR_TRY(qk_norm_append(m->qkv, b.scale_mul, m->qbuf, b.kc, b.vc, m->kv_fmt, R, lsum, H, m->Lkv, m->kv_len, &pq, s)); }
+          SDVAR_TRY(qk_norm_append(m->qkv, b.scale_mul, m->qbuf, b.kc, b.vc, m->kv_fmt, R, lsum, H, m->Lkv, m->kv_len, &pq, qk_fused, s)); }
         if (!(skip & 4)) { ProfScope pp(lsum <= 36 ? 8 : 1, 4.0 * R * H * 64.0 * lk, R * H * 64.0 * ((m->d.kv_dtype ? 4.0 : 8.0) * Ktot + 8.0 * lsum), s);
           if (bias) SDVAR_TRY(attention_masked(m->qbuf, b.kc, b.vc, m->kv_fmt, bias, m->att, P ? m->att_p : nullptr, ps, PF, R, H, lsum, m->Lkv, Ktot, s));
           else SDVAR_TRY(attention_f32(m->qbuf, b.kc, b.vc, m->kv_fmt, m->att, P ? m->att_p : nullptr, ps, PF, R, H, lsum, m->Lkv, Ktot, n, qbeg, vis, s)); }
@@ -672,7 +679,7 @@ int sdvar_op_gemm_bf16x3(const uint16_t* Xp, uint64_t x_plane_stride, const uint
 }
 int sdvar_op_qk_norm_append(const float* qkv, const float* scale_mul, float* q_out, void* k_cache, void* v_cache, int32_t kv_f16, int32_t R, int32_t l,
                             int32_t H, int32_t Lmax, int32_t pos0, void* stream) {
-    return qk_norm_append(qkv, scale_mul, q_out, k_cache, v_cache, kv_f16, R, l, H, Lmax, pos0, nullptr, (hipStream_t)stream);
+    return qk_norm_append(qkv, scale_mul, q_out, k_cache, v_cache, kv_f16, R, l, H, Lmax, pos0, nullptr, 0, (hipStream_t)stream);
 }
 int sdvar_op_attention(const float* q, const void* kc, const void* vc, int32_t kv_f16, float* out, uint16_t* out_planes, uint64_t plane_stride, int32_t plane_format,
                        int32_t R, int32_t H, int32_t l, int32_t Lmax, int32_t Ktot, int32_t n, const int32_t* qbeg, const int32_t* vis, void* stream) {

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void qk_norm_append_kernel(const float* __rest
 __global__ __launch_bounds__(256) void qk_norm_append_planes_kernel(const float* __restrict__ qkv, const float* __restrict__ scale_mul,
                                                                     float* __restrict__ q_out, uint16_t* __restrict__ k_cache,
                                                                     uint16_t* __restrict__ v_cache, int R, int l, int H, int Lp, int pos0, PendingSplitK pend,
-                                                                    int fmt) {
+                                                                    int fmt, int v_only) {
     __shared__ float vs[32 * 65];
     const int NP = fmt == 2 ? 3 : (fmt == 3 ? 2 : 1);
     const int tid = threadIdx.x;
@@ -289,7 +289,8 @@ __global__ __launch_bounds__(256) void qk_norm_append_planes_kernel(const float*
                 for (; s < pend.split; ++s) { const float* p = pend.ws + (size_t)s * slab + o; add8(q, p); add8(k, p + C); add8(v, p + 2 * C); }
                 add8(q, pend.bias + h * 64 + 8 * cg); add8(k, pend.bias + C + h * 64 + 8 * cg); add8(v, pend.bias + 2 * C + h * 64 + 8 * cg);
             } else {
-                add8(q, qkv + o); add8(k, qkv + o + C); add8(v, qkv + o + 2 * C);
+                if (!v_only) { add8(q, qkv + o); add8(k, qkv + o + C); }
+                add8(v, qkv + o + 2 * C);
             }
         }
         float sq = 0.f, sk = 0.f;
@@ -297,7 +298,10 @@ __global__ __launch_bounds__(256) void qk_norm_append_planes_kernel(const float*
         for (int e = 0; e < 8; ++e) { sq += q[e] * q[e]; sk += k[e] * k[e]; }
 #pragma unroll
         for (int o = 1; o < 8; o <<= 1) { sq += __shfl_xor(sq, o, 64); sk += __shfl_xor(sk, o, 64); }
-        if (live) {
+        if (live && v_only) {           // q and k left the QKV GEMM's epilogue finished (gemm_f16x2.hip HEPI_QKV): only V^T is written here
+#pragma unroll
+            for (int e = 0; e < 8; ++e) vs[(pos - P0) * 65 + 8 * cg + e] = v[e];
+        } else if (live) {
             const float qn = l2 ? fmaxf(sqrtf(sq), 1e-12f) : 1.0f, kn = l2 ? fmaxf(sqrtf(sk), 1e-12f) : 1.0f;
             f32x4 q0, q1;
 #pragma unroll
@@ -377,7 +381,7 @@ __global__ __launch_bounds__(256) void qk_norm_append_planes_kernel(const float*
 }
 
 int qk_norm_append(const float* qkv, const float* scale_mul, float* q_out, void* k_cache, void* v_cache, int kv_f16, int R, int l, int H,
-                   int Lmax, int pos0, const PendingSplitK* pend, hipStream_t stream) {
+                   int Lmax, int pos0, const PendingSplitK* pend, int v_only, hipStream_t stream) {
     PendingSplitK pd{nullptr, nullptr, nullptr, 0, 1, 0};
     if (pend && pend->ws) { SDVAR_CHECK_ARG(pend->bias && pend->split >= 1, "qk_norm_append: bad pending split-K descriptor"); pd = *pend; }
     SDVAR_CHECK_ARG(R > 0 && l > 0 && H > 0 && pos0 >= 0 && pos0 + l <= Lmax, "qk_norm_append: cache overflow pos0=%d l=%d Lmax=%d", pos0, l, Lmax);
@@ -385,7 +389,9 @@ int qk_norm_append(const float* qkv, const float* scale_mul, float* q_out, void*
     SDVAR_CHECK_ARG(kv_f16 >= 0 && kv_f16 <= 4, "qk_norm_append: cache format %d (0 = fp32, 1 = fp16, 2 = bf16x3 planes, 3 = f16x2 planes, 4 = one fp16 plane)", kv_f16);
     if (kv_f16 >= 2) {
         SDVAR_CHECK_ARG(Lmax % 64 == 0, "qk_norm_append: the planes KV formats need Lmax %% 64 == 0 (got %d)", Lmax);
-        hipLaunchKernelGGL(qk_norm_append_planes_kernel, dim3((unsigned)((pos0 + l + 31) / 32 - pos0 / 32), H, R), dim3(256), 0, stream, qkv, scale_mul, q_out, (uint16_t*)k_cache, (uint16_t*)v_cache, R, l, H, Lmax, pos0, pd, kv_f16);
+        SDVAR_CHECK_ARG(!v_only || !pd.ws, "qk_norm_append: the v-only pass takes a finished qkv buffer");
+        hipLaunchKernelGGL(qk_norm_append_planes_kernel, dim3((unsigned)((pos0 + l + 31) / 32 - pos0 / 32), H, R), dim3(256), 0, stream, qkv, scale_mul, q_out, (uint16_t*)k_cache, (uint16_t*)v_cache, R, l, H, Lmax, pos0, pd, kv_f16, v_only);
+    } else if (v_only) { set_error("qk_norm_append: the v-only pass exists for the planes cache formats only"); return SDVAR_ERR_ARG;
     } else if (kv_f16) hipLaunchKernelGGL(qk_norm_append_kernel<__half>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, qkv, scale_mul, q_out, (__half*)k_cache, (__half*)v_cache, R, l, H, Lmax, pos0, pd);
     else hipLaunchKernelGGL(qk_norm_append_kernel<float>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, qkv, scale_mul, q_out, (float*)k_cache, (float*)v_cache, R, l, H, Lmax, pos0, pd);
     SDVAR_LAUNCH_CHECK();

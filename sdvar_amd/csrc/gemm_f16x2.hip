@@ -27,7 +27,7 @@ namespace sdvar {
 unsigned long long* debug_get_gemm_stamps();      // gemm_bf16x3.hip
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-enum { HEPI_BIAS = 0, HEPI_BIAS_GELU_PLANES = 1, HEPI_GATED_RES = 2, HEPI_PARTIAL = 3 };
+enum { HEPI_BIAS = 0, HEPI_BIAS_GELU_PLANES = 1, HEPI_GATED_RES = 2, HEPI_PARTIAL = 3, HEPI_QKV = 4 };
 
 constexpr int HBK = 32;             // k per LDS stage
 constexpr int HBN = 128;
@@ -42,6 +42,16 @@ __device__ __forceinline__ float gelu_tanh_h(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+// HEPI_QKV (the unsplit QKV launch of a transformer block, N = 3 H 64): the q and k thirds leave the epilogue finished - bias, per-head L2 norm, q scale
+// (basic_var.py:101-109), q as fp32 (R, H, l, 64), k as planes of the KV cache at positions pos0 + t - and only v goes to `out` (fp32, bias added) for
+// qk_norm_append's v-only pass, which owns the transposed V^T layout.  Replaces the fp32 round trip of q and k through HBM and two thirds of
+// qk_norm_append's traffic (the launch is HBM bound from M = 1024).
+struct QkvEpi {
+    const float* scale_mul;      // (H) or null: attn_l2_norm=False (q x 2^-5, raw k)
+    float* q_out; uint16_t* k_cache;
+    int l, H, Lp, pos0, fmt;     // tokens per row of the CFG batch, heads, cache rows, first position, cache format (3: two fp16 planes, 4: one)
+};
+
 struct GemmHArgs {
     const uint16_t* X; const uint16_t* W;        // K-blocked planes [2][K/32][M][32], [2][K/32][N][32]
     size_t xps, wps;                             // plane strides in elements
@@ -53,6 +63,7 @@ struct GemmHArgs {
     int dbg;                 // timing experiments only (SDVAR_GEMM_DBG, results wrong): bit 0 no DMA inside the K loop, bit 1 no barrier, bit 2 no fragment reads, bit 3 no split-K reduce launch
     unsigned long long* stamps;   // diagnostic (sdvar_debug_set_gemm_stamps; small-M and 128 x 128 kernels): 8 x u64 per workgroup = s_memrealtime (100 MHz) at
                                   // entry / first K-step landed / loop end / exit, then s_memtime (core clock) at the same four points
+    QkvEpi qk;               // HEPI_QKV only
     int tile_off, tile_cnt;  // 256-row kernel only: this launch covers tile ids [tile_off, tile_off + tile_cnt) (tile_cnt = 0: all); with
                              // HEPI_PARTIAL the slabs are compact [split][tile_cnt][256][128]
 };
@@ -80,6 +91,59 @@ __device__ __forceinline__ void h_store(const GemmHArgs& a, float* outp, float a
         if (EPI == HEPI_GATED_RES) v = a.res[(size_t)m * a.ldres + n] + v * a.gate[(size_t)(m / a.rows_per_gate) * a.gate_stride + n];
         outp[(size_t)m * a.ldo + n] = v;
     }
+}
+
+// HEPI_QKV, one lane's share of one (row m, head): `v` = the NT 32-column tiles' 16 values each (bias added), channel of v[j][4 g + e] = 32 j + 8 g + 4 lh + e
+// (+ cbase for a wave that owns only the upper half of the head); sq = the head's full sum of squares of the row.  which: 0 q, 1 k.
+template <int NT>
+__device__ __forceinline__ void qk_store_row(const GemmHArgs& a, const f32x16* v, float sq, int which, int h, int m, int lh, int cbase) {
+    if (m >= a.M) return;
+    const QkvEpi& e = a.qk;
+    const bool l2 = e.scale_mul != nullptr;
+    const float nrm = l2 ? fmaxf(sqrtf(sq), 1e-12f) : 1.0f;
+    const int r = m / e.l, t = m - r * e.l;
+    if (which == 0) {
+        const float sm = l2 ? expf(fminf(e.scale_mul[h], 4.605170249938965f)) : 0.03125f;     // log(100) as the reference's float32 clamp
+        float* pq = e.q_out + (((size_t)r * e.H + h) * e.l + t) * 64 + cbase + 4 * lh;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 o;
+#pragma unroll
+                for (int x = 0; x < 4; ++x) o[x] = l2 ? (v[j][4 * g + x] / nrm) * sm : v[j][4 * g + x] * sm;
+                *reinterpret_cast<f32x4*>(pq + 32 * j + 8 * g) = o;
+            }
+    } else {
+        const int NP = e.fmt == 3 ? 2 : 1;
+        const size_t ps = (size_t)e.Lp * 64;
+        uint16_t* pk = e.k_cache + ((size_t)r * e.H + h) * NP * ps + (size_t)(e.pos0 + t) * 64 + cbase + 4 * lh;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint16_t hh[4], ll[4];
+#pragma unroll
+                for (int x = 0; x < 4; ++x) split2h(l2 ? v[j][4 * g + x] / nrm : v[j][4 * g + x], hh[x], ll[x]);
+                uint2 wh, wl;
+                wh.x = (uint32_t)hh[0] | ((uint32_t)hh[1] << 16); wh.y = (uint32_t)hh[2] | ((uint32_t)hh[3] << 16);
+                wl.x = (uint32_t)ll[0] | ((uint32_t)ll[1] << 16); wl.y = (uint32_t)ll[2] | ((uint32_t)ll[3] << 16);
+                *reinterpret_cast<uint2*>(pk + 32 * j + 8 * g) = wh;
+                if (e.fmt == 3) *reinterpret_cast<uint2*>(pk + ps + 32 * j + 8 * g) = wl;
+            }
+    }
+}
+
+// acc * 2^-S + bias for one 32-column tile whose first column (of this lane half) is nb; returns the lane's sum of squares
+__device__ __forceinline__ float qk_bias_sq(const GemmHArgs& a, const f32x16& acc, f32x16& out, float wsi, int nb) {
+    float sq = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 bv = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + nb + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int x = 0; x < 4; ++x) { const float t = acc[4 * g + x] * wsi + bv[x]; out[4 * g + x] = t; sq += t * t; }
+    }
+    return sq;
 }
 
 // One 32 x 32 accumulator tile (transposed layout, SDVAR_MFMA3): this lane's row m, columns nb + 8 g + {0..3} for g = 0..3 (nb already holds the lane
@@ -282,7 +346,31 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_v2_kernel(GemmHArgs a) {
 
     if (a.stamps) { vsr[2] = __builtin_amdgcn_s_memrealtime(); vsc[2] = __builtin_amdgcn_s_memtime(); }
     const float wsi = a.wsi ? *a.wsi : 1.0f;
-    {
+    if (EPI == HEPI_QKV) {
+        // the 128 columns of a tile lie inside one of the q / k / v thirds (H 64 is a multiple of 128 or the launcher does not pick this epilogue); a head
+        // is the 64 columns of the wave pair (wn, wn ^ 1): the row norms are exchanged through LDS (free: the ring's last reads are behind the barrier)
+        const int Cq = a.qk.H * 64, which = n0 / Cq, nh = n0 - which * Cq + (wn >> 1) * 64, h = nh >> 6;
+        if (which == 2) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) h_store_tile<HEPI_BIAS>(a, a.out, acc[i], wsi, m0 + wm * 64 + i * 32 + li, n0 + wn * 32 + 4 * lh);
+        } else {
+            float* ex = reinterpret_cast<float*>(hsm);           // [4 wn][128 rows]
+            f32x16 v[2]; float sq[2];
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                sq[i] = qk_bias_sq(a, acc[i], v[i], wsi, n0 + wn * 32 + 4 * lh);
+                sq[i] += __shfl_xor(sq[i], 32, 64);
+                if (lh == 0) ex[wn * 128 + wm * 64 + i * 32 + li] = sq[i];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float tot = (wn & 1) ? ex[(wn ^ 1) * 128 + wm * 64 + i * 32 + li] + sq[i] : sq[i] + ex[(wn ^ 1) * 128 + wm * 64 + i * 32 + li];   // lower half first in both waves
+                qk_store_row<1>(a, &v[i], tot, which, h, m0 + wm * 64 + i * 32 + li, lh, (wn & 1) * 32);
+            }
+        }
+    } else {
         float* outp = (EPI == HEPI_PARTIAL) ? a.out + (size_t)ks * a.M * a.ldo : a.out;
 #pragma unroll
         for (int i = 0; i < 2; ++i) h_store_tile<EPI>(a, outp, acc[i], wsi, m0 + wm * 64 + i * 32 + li, n0 + wn * 32 + 4 * lh);
@@ -387,7 +475,29 @@ __global__ __launch_bounds__(256) void gemm_f16x2_small_kernel(GemmHArgs a) {
 
     if (a.stamps) { sr[2] = __builtin_amdgcn_s_memrealtime(); sc[2] = __builtin_amdgcn_s_memtime(); }
     const float wsi = a.wsi ? *a.wsi : 1.0f;
-    {
+    if (EPI == HEPI_QKV) {             // as the 128 x 128 kernel: a head is the 64 columns of the wave pair (wave, wave ^ 1)
+        const int Cq = a.qk.H * 64, which = n0 / Cq, nh = n0 - which * Cq + (wave >> 1) * 64, h = nh >> 6;
+        if (which == 2) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) h_store_tile<HEPI_BIAS>(a, a.out, acc[i], wsi, m0 + i * 32 + li, n0 + wave * 32 + 4 * lh);
+        } else {
+            float* ex = reinterpret_cast<float*>(hsm);           // [4 waves][BM rows]
+            f32x16 v[TM]; float sq[TM];
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                sq[i] = qk_bias_sq(a, acc[i], v[i], wsi, n0 + wave * 32 + 4 * lh);
+                sq[i] += __shfl_xor(sq[i], 32, 64);
+                if (lh == 0) ex[wave * BM + i * 32 + li] = sq[i];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const float other = ex[(wave ^ 1) * BM + i * 32 + li];
+                qk_store_row<1>(a, &v[i], (wave & 1) ? other + sq[i] : sq[i] + other, which, h, m0 + i * 32 + li, lh, (wave & 1) * 32);
+            }
+        }
+    } else {
         float* outp = (EPI == HEPI_PARTIAL) ? a.out + (size_t)ks * a.M * a.ldo : a.out;
 #pragma unroll
         for (int i = 0; i < TM; ++i) h_store_tile<EPI>(a, outp, acc[i], wsi, m0 + i * 32 + li, n0 + wave * 32 + 4 * lh);
@@ -499,6 +609,24 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_v3_kernel(GemmHArgs a) {
     }
 
     const float wsi = a.wsi ? *a.wsi : 1.0f;
+    if (EPI == HEPI_QKV) {             // a wave's 64 columns are one head of q, k or v
+        const int Cq = a.qk.H * 64, which = n0 / Cq, nh = n0 - which * Cq + wn * 64, h = nh >> 6;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + wm * 64 + i * 32 + li;
+            if (which == 2) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) h_store_tile<HEPI_BIAS>(a, a.out, acc[i][j], wsi, m, n0 + wn * 64 + j * 32 + 4 * lh);
+            } else {
+                f32x16 v[2];
+                float sq = qk_bias_sq(a, acc[i][0], v[0], wsi, n0 + wn * 64 + 4 * lh);
+                sq += qk_bias_sq(a, acc[i][1], v[1], wsi, n0 + wn * 64 + 32 + 4 * lh);
+                sq += __shfl_xor(sq, 32, 64);
+                qk_store_row<2>(a, v, sq, which, h, m, lh, 0);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         float* outp = (EPI == HEPI_PARTIAL) ? a.out + (size_t)ks * a.M * a.ldo : a.out;
@@ -894,6 +1022,28 @@ static int launch_h(GemmHArgs a, int epi, int split, hipStream_t stream) {
 // defer: as gemm_bf16x3_nt (the slabs already carry the 2^-S factor).
 int gemm_f16x2_nt(const uint16_t* X, size_t xps, const uint16_t* W, size_t wps, const float* wsi, const float* bias, float* out, int ldo, uint16_t* outp, size_t ops,
                   int M, int N, int K, int epi, const float* res, int ldres, const float* gate, int rows_per_gate, int gate_stride, int* defer,
+                  hipStream_t stream);
+static thread_local const QkvEpi* g_qkv_epi = nullptr;      // set by gemm_f16x2_qkv around its call of gemm_f16x2_nt
+static thread_local int* g_qkv_fused = nullptr;
+
+// The QKV launch of a transformer block: as gemm_f16x2_nt(epi 0, out = the (M, 3 H 64) fp32 qkv buffer, defer), but when the launch comes out UNSPLIT the
+// q and k thirds are finished in the epilogue (QkvEpi) and *fused = 1: the caller then runs qk_norm_append's v-only pass.  Otherwise *fused = 0 and the
+// result is in `out` (or in the slabs, *defer > 0) as before.
+int gemm_f16x2_qkv(const uint16_t* X, size_t xps, const uint16_t* W, size_t wps, const float* wsi, const float* bias, float* out, int ldo, int M, int N, int K,
+                   const float* scale_mul, float* q_out, void* k_cache, int l, int H, int Lp, int pos0, int kv_fmt, int* defer, int* fused, hipStream_t stream) {
+    SDVAR_CHECK_ARG(fused && defer && q_out && k_cache && l > 0 && H > 0 && N == 3 * H * 64 && M % l == 0, "gemm_f16x2_qkv: bad arguments (M=%d N=%d l=%d H=%d)", M, N, l, H);
+    *fused = 0;
+    static const bool off = getenv("SDVAR_NO_QKV_FUSE") != nullptr;          // A/B runs
+    const QkvEpi e{scale_mul, q_out, (uint16_t*)k_cache, l, H, Lp, pos0, kv_fmt};
+    const bool ok = !off && (kv_fmt == 3 || kv_fmt == 4) && (H * 64) % 128 == 0 && ((uintptr_t)q_out % 16) == 0 && ((uintptr_t)k_cache % 16) == 0 && Lp % 8 == 0;
+    g_qkv_epi = ok ? &e : nullptr; g_qkv_fused = fused;
+    const int rc = gemm_f16x2_nt(X, xps, W, wps, wsi, bias, out, ldo, nullptr, 0, M, N, K, HEPI_BIAS, nullptr, 0, nullptr, 1, 0, defer, stream);
+    g_qkv_epi = nullptr; g_qkv_fused = nullptr;
+    return rc;
+}
+
+int gemm_f16x2_nt(const uint16_t* X, size_t xps, const uint16_t* W, size_t wps, const float* wsi, const float* bias, float* out, int ldo, uint16_t* outp, size_t ops,
+                  int M, int N, int K, int epi, const float* res, int ldres, const float* gate, int rows_per_gate, int gate_stride, int* defer,
                   hipStream_t stream) {
     g_defer_h = defer;
     if (defer) *defer = 0;
@@ -904,7 +1054,7 @@ int gemm_f16x2_nt(const uint16_t* X, size_t xps, const uint16_t* W, size_t wps, 
     SDVAR_CHECK_ARG(((uintptr_t)X % 16) == 0 && ((uintptr_t)W % 16) == 0 && xps % 8 == 0 && wps % 8 == 0, "gemm_f16x2: planes must be 16-byte aligned");
     if (epi == HEPI_GATED_RES) SDVAR_CHECK_ARG(res && gate && rows_per_gate > 0 && ldres >= N, "gemm_f16x2: gated-residual epilogue needs res/gate");
     static const int dbg = getenv("SDVAR_GEMM_DBG") ? atoi(getenv("SDVAR_GEMM_DBG")) : 0;
-    GemmHArgs a{X, W, xps, wps, wsi, bias, out, outp, ops, res, gate, M, N, K, ldo, ldres, rows_per_gate > 0 ? rows_per_gate : 1, gate_stride, 1, K / HBK, 0, dbg, debug_get_gemm_stamps(), 0, 0};
+    GemmHArgs a{X, W, xps, wps, wsi, bias, out, outp, ops, res, gate, M, N, K, ldo, ldres, rows_per_gate > 0 ? rows_per_gate : 1, gate_stride, 1, K / HBK, 0, dbg, debug_get_gemm_stamps(), QkvEpi{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0}, 0, 0};
     auto al16 = [](const void* q) { return ((uintptr_t)q % 16) == 0; };
     a.vec = N % 4 == 0 && al16(bias) && al16(out) && al16(outp) && al16(res) && al16(gate) && ldo % 4 == 0 && ops % 4 == 0 &&
             (epi != HEPI_GATED_RES || (ldres % 4 == 0 && gate_stride % 4 == 0));
@@ -912,7 +1062,9 @@ int gemm_f16x2_nt(const uint16_t* X, size_t xps, const uint16_t* W, size_t wps, 
     (void)splitk_workspace(&wsf);
     int bm, split, tail = 0;
     static const bool no_hybrid = getenv("SDVAR_GEMM_NO_HYBRID") != nullptr;       // A/B runs only
-    choose_cfg_h(M, N, K, wsf, &bm, &split, &tail, !no_hybrid, defer != nullptr);
+    // a QKV launch that can finish q and k in its epilogue stays off the hybrid tail split (whose tail tiles go through slabs): the fused epilogue saves more
+    const bool qkv = g_qkv_epi != nullptr && a.vec;
+    choose_cfg_h(M, N, K, wsf, &bm, &split, &tail, !no_hybrid && !qkv, defer != nullptr);
     if (g_force_bm_h) { bm = g_force_bm_h; tail = 0; }
     static const bool trace = getenv("SDVAR_GEMM_TRACE") != nullptr;
     if (trace) fprintf(stderr, "[gemm_f16x2] M=%d N=%d K=%d epi=%d -> bm=%d split=%d tail=%d\n", M, N, K, epi, bm, split, tail);
@@ -923,6 +1075,14 @@ int gemm_f16x2_nt(const uint16_t* X, size_t xps, const uint16_t* W, size_t wps, 
         while (split > 1 && (size_t)split * M * N > wsf) --split;
         const int kps = (nkt + split - 1) / split;
         split = (nkt + kps - 1) / kps;
+    }
+    if (qkv && split == 1 && tail == 0) {
+        a.qk = *g_qkv_epi; a.split = 1; a.k_per_split = K / HBK;
+        *g_qkv_fused = 1;
+        if (bm == 256) return launch_h3_kernel<HEPI_QKV>(a, ((M + 255) / 256) * ((N + HBN - 1) / HBN), stream);
+        if (bm == 128) return launch_h2_kernel<HEPI_QKV>(a, ((M + 127) / 128) * ((N + HBN - 1) / HBN), stream);
+        if (bm == 64) return launch_small_any<64, HEPI_QKV>(a, ((M + 63) / 64) * ((N + HBN - 1) / HBN), stream);
+        return launch_small_any<32, HEPI_QKV>(a, ((M + 31) / 32) * ((N + HBN - 1) / HBN), stream);
     }
     if (bm == 256 && tail > 0) return launch_h3_hybrid(a, epi, tail, stream);
     if (bm == 256) return launch_h3(a, epi, split, stream);
