@@ -213,6 +213,9 @@ int sdvar_op_conv_planes(const uint16_t* x_planes, uint64_t x_plane_stride, uint
                          int32_t Cin, int32_t taps, float* workspace, uint64_t workspace_floats, int32_t force_split, void* stream);
 /* tuning aid (tools/gemm_bench.py --sweep): force the GEMM row tile (32/64/128) and K-slice count; 0 = automatic */
 int sdvar_debug_set_gemm_cfg(int32_t bm, int32_t split);
+/* test aid: 0 = the QKV launch of sdvar_stage_forward never finishes q and k in its epilogue (qk_norm_append does all three), 1 (default) = it does
+ * whenever the launch comes out unsplit on the f16x2 planes cache */
+int sdvar_debug_set_qkv_fuse(int32_t on);
 /* diagnostic: per-workgroup stamps of the LDS-DMA GEMM kernels; NULL disables.  bf16x3 kernel: 4 x u64 per workgroup (s_memtime at entry, main loop
  * start, main loop end, exit); f16x2 small-M and 128 x 128 kernels: 8 x u64 (s_memrealtime at entry, first K-step landed, loop end, exit; then s_memtime) */
 int sdvar_debug_set_gemm_stamps(uint64_t* stamps);

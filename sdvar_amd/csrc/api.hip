@@ -40,6 +40,7 @@ int weight_scale_f16(const float* w, size_t n, float* sc, hipStream_t stream);
 void debug_set_gemm_cfg_h(int bm, int split);
 void debug_set_gemm_cfg_p(int bm, int split);
 void debug_set_gemm_stamps(unsigned long long* p);
+void debug_set_qkv_fuse(int on);
 int cfg_sample(const float* logits, int B, int l, int V, float one_plus_t, float t, int top_k, int use_top_p, float top_p_thr, const float* q, uint64_t seed,
                uint32_t draw, uint32_t image_offset, long long* ids, int ids_stride, float* dbg_masked, hipStream_t stream);
 int noise_fill(float* q, int B, int l, int V, uint64_t seed, uint32_t draw, uint32_t image_offset, hipStream_t stream);
@@ -701,6 +702,8 @@ int sdvar_debug_set_gemm_cfg(int32_t bm, int32_t split) {
     debug_set_gemm_cfg_h(bm, split);
     return SDVAR_OK;
 }
+
+int sdvar_debug_set_qkv_fuse(int32_t on) { debug_set_qkv_fuse(on); return SDVAR_OK; }
 
 int sdvar_debug_set_gemm_stamps(uint64_t* stamps) { debug_set_gemm_stamps((unsigned long long*)stamps); return SDVAR_OK; }
 

@@ -1023,6 +1023,8 @@ static int launch_h(GemmHArgs a, int epi, int split, hipStream_t stream) {
 int gemm_f16x2_nt(const uint16_t* X, size_t xps, const uint16_t* W, size_t wps, const float* wsi, const float* bias, float* out, int ldo, uint16_t* outp, size_t ops,
                   int M, int N, int K, int epi, const float* res, int ldres, const float* gate, int rows_per_gate, int gate_stride, int* defer,
                   hipStream_t stream);
+static bool g_qkv_fuse_off = false;
+void debug_set_qkv_fuse(int on) { g_qkv_fuse_off = !on; }
 static thread_local const QkvEpi* g_qkv_epi = nullptr;      // set by gemm_f16x2_qkv around its call of gemm_f16x2_nt
 static thread_local int* g_qkv_fused = nullptr;
 
@@ -1033,7 +1035,8 @@ int gemm_f16x2_qkv(const uint16_t* X, size_t xps, const uint16_t* W, size_t wps,
                    const float* scale_mul, float* q_out, void* k_cache, int l, int H, int Lp, int pos0, int kv_fmt, int* defer, int* fused, hipStream_t stream) {
     SDVAR_CHECK_ARG(fused && defer && q_out && k_cache && l > 0 && H > 0 && N == 3 * H * 64 && M % l == 0, "gemm_f16x2_qkv: bad arguments (M=%d N=%d l=%d H=%d)", M, N, l, H);
     *fused = 0;
-    static const bool off = getenv("SDVAR_NO_QKV_FUSE") != nullptr;          // A/B runs
+    static const bool env_off = getenv("SDVAR_NO_QKV_FUSE") != nullptr;      // A/B runs
+    const bool off = env_off || g_qkv_fuse_off;
     const QkvEpi e{scale_mul, q_out, (uint16_t*)k_cache, l, H, Lp, pos0, kv_fmt};
     const bool ok = !off && (kv_fmt == 3 || kv_fmt == 4) && (H * 64) % 128 == 0 && ((uintptr_t)q_out % 16) == 0 && ((uintptr_t)k_cache % 16) == 0 && Lp % 8 == 0;
     g_qkv_epi = ok ? &e : nullptr; g_qkv_fused = fused;

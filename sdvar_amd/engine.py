@@ -99,6 +99,7 @@ _SIGNATURES = {
     "sdvar_op_noise_fill": (_I, [_P, _I, _I, _I, _U64, _U32, _U32, _P]),
     "sdvar_debug_set_gemm_cfg": (_I, [_I, _I]),
     "sdvar_debug_set_gemm_stamps": (_I, [_P]),
+    "sdvar_debug_set_qkv_fuse": (_I, [_I]),
     "sdvar_prof_enable": (_I, [_I]),
     "sdvar_prof_collect": (_I, [C.POINTER(_D), C.POINTER(C.c_int64), C.POINTER(_D), C.POINTER(_D)]),
 }

@@ -197,3 +197,39 @@ def test_d36_shared_aln_width(dev):
     assert torch.equal(ids_a, b.ids) and torch.equal(lg_a, b.trace["logits"][3]) and torch.isfinite(lg_a).all() and lg_a.std().item() > 0.1
     _chunk_vs_stagewise(smp, labels, 2, 2)
     tc.close(); qc.close(); torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("kv_fp16", [False, True])
+def test_qkv_epilogue_equals_qk_norm_append(dev, kv_fp16):
+    """From M = 1024 rows the QKV launch of a block is unsplit and finishes q and k in its epilogue (gemm_f16x2.hip HEPI_QKV; qk_norm_append then runs its
+    v-only pass).  Same stages with the epilogue switched off: logits within 2e-5 of the logits' scale, both cache formats (two fp16 planes / one)."""
+    pns, B, depth = LADDER_256, 8, 16
+    lad = as_ladder(pns)
+    sd = var_state_dict_device(depth, pns, dev, mode="stress")
+    tc = E.ModelCtx(sd, depth, pns, B, 2, dev, kv_fp16=kv_fp16)
+    assert tc.gemm_mode == "f16x2"
+    labels = torch.arange(B, device=dev) % 1000
+    g = torch.Generator(device="cpu").manual_seed(3)
+    xs = [torch.randn(2 * B * lad.lens[s] * tc.Cw, generator=g).to(dev) for s in range(lad.S)]
+    lg = torch.empty(2 * B * (lad.lens[-1] + lad.lens[-2]) * tc.V, device=dev)
+
+    def run(fuse, chunked):
+        E._check(tc.lib.sdvar_debug_set_qkv_fuse(1 if fuse else 0))
+        try:
+            tc.begin(labels); out = []
+            for s in range(lad.S - 2):
+                tc.forward(xs[s].clone(), s, 1, lg)           # the residual stream is updated in place
+            if chunked:                                 # the last two stages as one gamma = 2 chunk (6800 rows)
+                tc.forward(torch.cat([xs[-2].view(2 * B, -1), xs[-1].view(2 * B, -1)], 1).contiguous().view(-1), lad.S - 2, 2, lg)
+                out.append(lg[:2 * B * (lad.lens[-1] + lad.lens[-2]) * tc.V].clone())
+            else:
+                for s in (lad.S - 2, lad.S - 1):
+                    tc.forward(xs[s].clone(), s, 1, lg); out.append(lg[:2 * B * lad.lens[s] * tc.V].clone())
+            return out
+        finally:
+            E._check(tc.lib.sdvar_debug_set_qkv_fuse(1))
+    for chunked in (False, True):
+        a, b = run(True, chunked), run(False, chunked)
+        for x, y in zip(a, b):
+            assert torch.isfinite(x).all() and (x - y).abs().max().item() <= 2e-5 * max(1.0, y.abs().max().item())
+    tc.close(); torch.cuda.empty_cache()

@@ -540,7 +540,7 @@ def test_gemm_f16x2_epilogues(dev, M, N, K, epi):
                                          (300, 256, 96, 1), (300, 256, 96, 3)])
 @pytest.mark.parametrize("epi", [0, 1, 2])
 def test_gemm_f16x2_kernels_forced_tile(dev, M, N, K, split, epi, bm):
-    """Every f16x2 kernel (register-staged 32/64-row tiles, LDS-DMA 128x128 and 256x128 with their 3-stage rings) on ragged edges, K loops
+    """Every f16x2 kernel (LDS-DMA 32/64-row tiles, 128x128 and 256x128, all with 3-stage rings) on ragged edges, K loops
     of 1 .. 128 steps (ring fill / drain paths) and split-K."""
     lib = E.load_library()
     X, W, b = rnd(1, (M, K)), rnd(2, (N, K), 1 / math.sqrt(K)), rnd(3, (N,)).to(dev)
@@ -563,6 +563,32 @@ def test_gemm_f16x2_kernels_forced_tile(dev, M, N, K, split, epi, bm):
         got = out.cpu().double()
     err = (got - ref).abs().max().item()
     assert err <= 2e-5 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("bm", [32, 64, 128, 256])
+@pytest.mark.parametrize("epi", [0, 2])
+def test_gemm_f16x2_unaligned_epilogue(dev, bm, epi):
+    """The epilogues move 16 bytes per access when every pointer and leading dimension allows it; odd leading dimensions and a bias / gate / res pointer off
+    the 16-byte grid take the element-wise path of the same kernels."""
+    lib = E.load_library()
+    M, N, K = 150, 260, 96
+    X, W = rnd(1, (M, K)), rnd(2, (N, K), 1 / math.sqrt(K))
+    (Xp, _), (Wp, sc) = _planes_h(X, dev), _planes_h(W, dev, scaled=True)
+    bbuf, resb, gbuf = rnd(3, (N + 1,)).to(dev), rnd(4, (M, N + 3)).to(dev), rnd(5, (M, 2 * N + 1)).to(dev)
+    b = bbuf[1:]                                       # 4 bytes off the 16-byte grid
+    out = resb.clone() if epi == 2 else torch.full((M, N + 3), float("nan"), device=dev)
+    E._check(lib.sdvar_debug_set_gemm_cfg(bm, 1))
+    try:
+        E._check(lib.sdvar_op_gemm_f16x2(_p(Xp), M * K, _p(Wp), N * K, _p(sc), _p(b), _p(out), N + 3, None, 0, M, N, K, epi, _p(out) if epi == 2 else None, N + 3,
+                                         _p(gbuf) if epi == 2 else None, 1, 2 * N + 1, _st()))
+    finally:
+        E._check(lib.sdvar_debug_set_gemm_cfg(0, 0))
+    ref = X.double() @ W.double().t() + b.cpu().double()
+    if epi == 2:
+        ref = resb.cpu()[:, :N].double() + ref * gbuf.cpu()[:, :N].double()
+    got = out.cpu()[:, :N].double()
+    assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    if epi == 0: assert torch.isnan(out[:, N:]).all()           # the padding columns of the rows are not touched
 
 
 @pytest.mark.parametrize("M,N,K,epi", [(2704, 3072, 1024, 0), (4096, 2304, 768, 0), (2704, 4096, 1024, 1), (4096, 3072, 768, 2), (2500, 3072, 256, 0)])
