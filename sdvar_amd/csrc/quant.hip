@@ -52,11 +52,23 @@ __global__ __launch_bounds__(256) void quant_up_kernel(const long long* __restri
 // phi (b, co): f_hat[b][co] += 0.5*up[b][co] + 0.5*(bias[co] + sum_{ci,dy,dx} w[co][ci][dy][dx] up[b][ci][Y+dy-1][X+dx-1])
 // f_out = f_in + Phi mix (f_in == f_out: the in-place form of quant.py:191; distinct buffers keep the per-stage snapshots of a draft round
 // without extra copies)
+// STAGED: the image's up-sampled planes (Cv HW^2 floats: 32 KB at HW = 16, 128 KB at 32) and the output channel's 9 Cv weights are copied to LDS
+// first - every one of them is read HW^2 / 9 times by the workgroup - and the 288 multiply-adds of a pixel (same order as the unstaged form, so the
+// results are the same bits) read LDS: 31.6 -> 7 us per launch at HW = 16, on the serial path between two stages.
+template <bool STAGED>
 __global__ __launch_bounds__(256) void quant_phi_kernel(const float* __restrict__ up, const float* __restrict__ w, const float* __restrict__ bias,
                                                         const float* f_in, float* f_hat, int HW, int Cv) {
+    extern __shared__ __attribute__((aligned(16))) float psm[];
     const int co = blockIdx.x, b = blockIdx.y;
     const float* ub = up + (size_t)b * Cv * HW * HW;
     const float* wc = w + (size_t)co * Cv * 9;
+    if (STAGED) {
+        const int n4 = Cv * HW * HW / 4;                // HW * HW is a multiple of 4 on this path (host)
+        for (int i = threadIdx.x; i < n4; i += blockDim.x) reinterpret_cast<f32x4*>(psm)[i] = reinterpret_cast<const f32x4*>(ub)[i];
+        for (int i = threadIdx.x; i < 9 * Cv; i += blockDim.x) psm[Cv * HW * HW + i] = wc[i];
+        __syncthreads();
+        ub = psm; wc = psm + Cv * HW * HW;
+    }
     for (int e = threadIdx.x; e < HW * HW; e += blockDim.x) {
         const int Y = e / HW, X = e % HW;
         float acc = 0.f;
@@ -115,7 +127,12 @@ int quant_next(const long long* ids, int ids_stride, const float* hvec, const fl
     const size_t lds_up = (size_t)(pn * pn + HW * pn) * sizeof(float);
     hipLaunchKernelGGL(quant_up_kernel, dim3(Cv, B), dim3(256), lds_up, stream, ids, ids_stride, codebook, hvec, Wup, up_scratch, pn, HW, Cv, last);
     SDVAR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(quant_phi_kernel, dim3(Cv, B), dim3(256), 0, stream, up_scratch, phi_w, phi_b, f_in ? f_in : f_hat, f_hat, HW, Cv);
+    const size_t lds_phi = ((size_t)Cv * HW * HW + 9 * (size_t)Cv) * sizeof(float);
+    if ((HW * HW) % 4 == 0 && lds_phi <= 140 * 1024 && ((uintptr_t)up_scratch % 16) == 0) {
+        static LdsOptIn opt_in;
+        SDVAR_LDS_OPT_IN(opt_in, 140 * 1024, (const void*)quant_phi_kernel<true>);       // once per device: the largest size this path takes
+        hipLaunchKernelGGL(quant_phi_kernel<true>, dim3(Cv, B), dim3(256), lds_phi, stream, up_scratch, phi_w, phi_b, f_in ? f_in : f_hat, f_hat, HW, Cv);
+    } else hipLaunchKernelGGL(quant_phi_kernel<false>, dim3(Cv, B), dim3(256), 0, stream, up_scratch, phi_w, phi_b, f_in ? f_in : f_hat, f_hat, HW, Cv);
     SDVAR_LAUNCH_CHECK();
     if (!last) {
         SDVAR_CHECK_ARG(Wdn && nxt && pn_next > 0 && pn_next <= HW, "quant_next: missing down table");
