@@ -13,12 +13,13 @@
 // values are all below ~1e-3 lose relative precision (absolute error stays 2^-25): the bf16x3 mode has no such limit.
 //
 // Operands are PLANAR and K-blocked: planes[2][K/32][rows][32] fp16 (common.h kb_index); producers (ln_modulate, attention, the fc1
-// GELU epilogue) write them directly.  Kernels, tiling, split-K, deferral and the hybrid tail split are those of gemm_bf16x3.hip with
-// 2 planes / 3 products per k16-step; because a K-step now holds half the matrix work, the 256-row kernel keeps TWO K-steps of
-// LDS-DMA in flight (3-stage ring) instead of one.
+// GELU epilogue) write them directly.  Tiling, split-K, deferral and the hybrid tail split are those of gemm_bf16x3.hip with 2 planes /
+// 3 products per k16-step; because a K-step now holds half the matrix work, the 256-row kernel keeps TWO K-steps of LDS-DMA in flight
+// (3-stage ring) instead of one.  What differs from gemm_bf16x3.hip: the 32- and 64-row tiles are an LDS-DMA ring too
+// (gemm_f16x2_small_kernel), the accumulators are transposed (SDVAR_MFMA3: 16-byte epilogue accesses), the unsplit QKV launch of a
+// block finishes q and k in its epilogue (HEPI_QKV), and the cost model is fitted to HBM-cold weights with a deferral-aware split cost.
 #include <stdio.h>
 #include <stdlib.h>
-#include <type_traits>
 
 #include "common.h"
 
