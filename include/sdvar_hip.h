@@ -216,6 +216,17 @@ int sdvar_debug_set_gemm_cfg(int32_t bm, int32_t split);
 /* test aid: 0 = the QKV launch of sdvar_stage_forward never finishes q and k in its epilogue (qk_norm_append does all three), 1 (default) = it does
  * whenever the launch comes out unsplit on the f16x2 planes cache */
 int sdvar_debug_set_qkv_fuse(int32_t on);
+/* test aid: out4 = {row tile (32/64/128/256) of the LAST f16x2 GEMM call of this host thread, its K split, number of launches that took the hybrid tail
+ * split since the last read, number of QKV launches that finished q and k in their epilogue since the last read}; reading resets the two counters.
+ * Tests assert with it that the path they mean to cover is the one that ran. */
+int sdvar_debug_get_gemm_cfg(int32_t* out4);
+/* f16x2 guard (debug, off by default; mode f16x2 only).  The f16x2 operand format of the default GEMM mode saturates finite activations at +-65504 and loses
+ * relative precision below ~1e-3 (the reference computes these GEMMs in fp32: basic_var.py:44-52, 87-119).  With the guard on, every producer of GEMM operand
+ * planes inside sdvar_stage_forward (ln_modulate, attention, the fc1 GELU epilogue) is followed by a counting pass over the plane it wrote.
+ * sdvar_debug_get_f16x2_guard synchronises the device and returns out4 = {elements seen, saturated (|h| == 65504), NaN / Inf, tiny (0 < |h| < 2^-10)};
+ * reset != 0 zeroes the counters.  A non-zero `saturated` or `NaN` count means the run left the range f16x2 is exact in: use gemm_mode bf16x3 (no range limit). */
+int sdvar_debug_set_f16x2_guard(int32_t on);
+int sdvar_debug_get_f16x2_guard(uint64_t* out4, int32_t reset);
 /* diagnostic: per-workgroup stamps of the LDS-DMA GEMM kernels; NULL disables.  bf16x3 kernel: 4 x u64 per workgroup (s_memtime at entry, main loop
  * start, main loop end, exit); f16x2 small-M and 128 x 128 kernels: 8 x u64 (s_memrealtime at entry, first K-step landed, loop end, exit; then s_memtime) */
 int sdvar_debug_set_gemm_stamps(uint64_t* stamps);

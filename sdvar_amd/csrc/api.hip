@@ -41,6 +41,8 @@ void debug_set_gemm_cfg_h(int bm, int split);
 void debug_set_gemm_cfg_p(int bm, int split);
 void debug_set_gemm_stamps(unsigned long long* p);
 void debug_set_qkv_fuse(int on);
+void debug_get_gemm_cfg_h(int* out);
+int planes_guard(const uint16_t* h_plane, size_t n, unsigned long long* cnt, hipStream_t stream);
 int cfg_sample(const float* logits, int B, int l, int V, float one_plus_t, float t, int top_k, int use_top_p, float top_p_thr, const float* q, uint64_t seed,
                uint32_t draw, uint32_t image_offset, long long* ids, int ids_stride, float* dbg_masked, hipStream_t stream);
 int noise_fill(float* q, int B, int l, int V, uint64_t seed, uint32_t draw, uint32_t image_offset, hipStream_t stream);
@@ -84,6 +86,14 @@ struct ProfScope {
         g_prof.push_back(r);
     }
 };
+
+// f16x2 guard (debug switch, off by default): see elementwise.hip planes_guard_kernel
+static bool g_guard_on = false;
+static unsigned long long* g_guard_cnt = nullptr;       // device, 4 counters
+static int guard_planes(const uint16_t* h_plane, size_t n, hipStream_t s) {
+    if (!g_guard_on || !g_guard_cnt) return SDVAR_OK;
+    return planes_guard(h_plane, n, g_guard_cnt, s);
+}
 
 struct WsScope {         // routes the split-K slabs of every GEMM below to the model's own workspace for the duration of a call
     float* old;
@@ -434,6 +444,7 @@ static int stage_forward_impl(sdvar_model_t* m, float* x, int32_t s0, int32_t n,
     const bool P = m->d.gemm_mode >= 1;                               // split-operand GEMMs: inputs travel as planes
     const int PF = m->d.gemm_mode == 2 ? PLANES_F16X2 : PLANES_BF16X3;
     const size_t ps = (size_t)M * C;                                  // plane stride of this call's (M, C) activations
+    const bool G2 = g_guard_on && m->d.gemm_mode == 2;                // f16x2 guard: count saturated / NaN / tiny operand elements behind every producer
     // In bf16x3 mode a split-K GEMM feeding a row kernel leaves its K-slice slabs in the shared workspace and the consumer
     // (qk_norm_append for QKV; the next ln_modulate for the two gated-residual GEMMs) sums them: no reduce launches.
     size_t wsf = 0;
@@ -443,12 +454,19 @@ static int stage_forward_impl(sdvar_model_t* m, float* x, int32_t s0, int32_t n,
     int* const dp = &defer;      // every split-K GEMM below leaves its K-slice sum to the row kernel that reads the result next
     // timing experiments only (results wrong): SDVAR_SKIP_CLASS bit 0 ln_modulate, 1 qk_norm_append, 2 attention, 3 fc1, 4 QKV GEMM, 5 proj, 6 fc2 not launched
     // (tools/micro/skip_class_exp.sh: the marginal cost of a kernel class inside the real launch sequence, without a profiler's per-kernel overhead)
+#ifdef SDVAR_TIMING_EXPERIMENTS       // make EXTRA=-DSDVAR_TIMING_EXPERIMENTS: never in the product library
     static const int skip = getenv("SDVAR_SKIP_CLASS") ? atoi(getenv("SDVAR_SKIP_CLASS")) : 0;
+    static const bool warned = (skip && fprintf(stderr, "[sdvar] SDVAR_SKIP_CLASS=%d: timing experiment build, results are WRONG\n", skip), true);
+    (void)warned;
+#else
+    constexpr int skip = 0;
+#endif
     for (int i = 0; i < m->d.depth; ++i) {
         const BlockW& b = m->blk[i];
         const float* ada = m->ada + (size_t)i * m->Rmax * 6 * C;      // (R, 6C): gamma1 gamma2 scale1 scale2 shift1 shift2
         if (!(skip & 1)) { ProfScope pp(2, 8 * dM * dC, (P ? 10 : 8) * dM * dC, s);
           SDVAR_TRY(ln_modulate(x, ada + 2 * C, ada + 4 * C, m->xn, P ? m->xn_p : nullptr, ps, M, C, lsum, 6 * C, &pend, PF, s)); pend.ws = nullptr; }
+        if (G2) SDVAR_TRY(guard_planes(m->xn_p, ps, s));
         PendingSplitK pq{nullptr, nullptr, nullptr, 0, 1, 0};
         int qk_fused = 0;        // the QKV launch came out unsplit and finished q and k in its epilogue (f16x2 planes cache): only V^T is left for qk_norm_append
         if (!(skip & 16)) { ProfScope pp(0, 2 * dM * 3 * dC * dC, 4 * (dM * dC + 3 * dC * dC + 3 * dM * dC), s);
@@ -464,15 +482,18 @@ static int stage_forward_impl(sdvar_model_t* m, float* x, int32_t s0, int32_t n,
         if (!(skip & 4)) { ProfScope pp(lsum <= 36 ? 8 : 1, 4.0 * R * H * 64.0 * lk, R * H * 64.0 * ((m->d.kv_dtype ? 4.0 : 8.0) * Ktot + 8.0 * lsum), s);
           if (bias) SDVAR_TRY(attention_masked(m->qbuf, b.kc, b.vc, m->kv_fmt, bias, m->att, P ? m->att_p : nullptr, ps, PF, R, H, lsum, m->Lkv, Ktot, s));
           else SDVAR_TRY(attention_f32(m->qbuf, b.kc, b.vc, m->kv_fmt, m->att, P ? m->att_p : nullptr, ps, PF, R, H, lsum, m->Lkv, Ktot, n, qbeg, vis, s)); }
+        if (G2) SDVAR_TRY(guard_planes(m->att_p, ps, s));
         if (!(skip & 32)) { ProfScope pp(0, 2 * dM * dC * dC, 4 * (3 * dM * dC + dC * dC), s);
           if (P) { SDVAR_TRY(plane_gemm(m, m->att_p, ps, b.proj_wp, (size_t)C * C, b.wsc + 4, b.proj_b, x, C, nullptr, 0, M, C, C, EPI_GATED_RES, x, C, ada, lsum, 6 * C, dp, s));
                    if (defer) pend = PendingSplitK{ws, b.proj_b, ada, defer, lsum, 6 * C}; }
           else SDVAR_TRY(gemm_f32_nt(m->att, C, b.proj_w, b.proj_b, x, C, M, C, C, EPI_GATED_RES, x, C, ada, lsum, 6 * C, s)); }
         if (!(skip & 1)) { ProfScope pp(2, 8 * dM * dC, (P ? 10 : 8) * dM * dC, s);
           SDVAR_TRY(ln_modulate(x, ada + 3 * C, ada + 5 * C, m->xn, P ? m->xn_p : nullptr, ps, M, C, lsum, 6 * C, &pend, PF, s)); pend.ws = nullptr; }
+        if (G2) SDVAR_TRY(guard_planes(m->xn_p, ps, s));
         if (!(skip & 8)) { ProfScope pp(0, 2 * dM * 4 * dC * dC, 4 * (dM * dC + 4 * dC * dC + 4 * dM * dC), s);
           if (P) SDVAR_TRY(plane_gemm(m, m->xn_p, ps, b.fc1_wp, (size_t)4 * C * C, b.wsc + 8, b.fc1_b, nullptr, 0, m->hid_p, 4 * ps, M, 4 * C, C, EPI_BIAS_GELU, nullptr, 0, nullptr, 0, 0, nullptr, s));
           else SDVAR_TRY(gemm_f32_nt(m->xn, C, b.fc1_w, b.fc1_b, m->hid, 4 * C, M, 4 * C, C, EPI_BIAS_GELU, nullptr, 0, nullptr, 0, 0, s)); }
+        if (G2) SDVAR_TRY(guard_planes(m->hid_p, 4 * ps, s));
         if (!(skip & 64)) { ProfScope pp(0, 2 * dM * 4 * dC * dC, 4 * (4 * dM * dC + 4 * dC * dC + 2 * dM * dC), s);
           if (P) { SDVAR_TRY(plane_gemm(m, m->hid_p, 4 * ps, b.fc2_wp, (size_t)4 * C * C, b.wsc + 12, b.fc2_b, x, C, nullptr, 0, M, C, 4 * C, EPI_GATED_RES, x, C, ada + C, lsum, 6 * C, dp, s));
                    if (defer) pend = PendingSplitK{ws, b.fc2_b, ada + C, defer, lsum, 6 * C}; }
@@ -480,6 +501,7 @@ static int stage_forward_impl(sdvar_model_t* m, float* x, int32_t s0, int32_t n,
     }
     { ProfScope pp(2, 8 * dM * dC, (P ? 10 : 8) * dM * dC, s);      // also finishes the last block's fc2 residual when it was left split
       SDVAR_TRY(ln_modulate(x, m->ada_head, m->ada_head + C, m->xn, P ? m->xn_p : nullptr, ps, M, C, lsum, 2 * C, &pend, PF, s)); pend.ws = nullptr; }
+    if (G2) SDVAR_TRY(guard_planes(m->xn_p, ps, s));
     { ProfScope pp(0, 2 * dM * dC * V, 4 * (dM * dC + dC * V + dM * V), s);
       if (P) SDVAR_TRY(plane_gemm(m, m->xn_p, ps, m->head_wp, (size_t)V * C, m->head_wsc, m->head_b, logits, V, nullptr, 0, M, V, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, nullptr, s));
       else SDVAR_TRY(gemm_f32_nt(m->xn, C, m->head_w, m->head_b, logits, V, M, V, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, s)); }
@@ -704,6 +726,32 @@ int sdvar_debug_set_gemm_cfg(int32_t bm, int32_t split) {
 }
 
 int sdvar_debug_set_qkv_fuse(int32_t on) { debug_set_qkv_fuse(on); return SDVAR_OK; }
+
+int sdvar_debug_get_gemm_cfg(int32_t* out4) {
+    SDVAR_CHECK_ARG(out4, "debug_get_gemm_cfg: null");
+    int v[4]; debug_get_gemm_cfg_h(v);
+    for (int i = 0; i < 4; ++i) out4[i] = v[i];
+    return SDVAR_OK;
+}
+
+int sdvar_debug_set_f16x2_guard(int32_t on) {
+    if (on && !g_guard_cnt) {
+        SDVAR_HIP(hipMalloc((void**)&g_guard_cnt, 4 * sizeof(unsigned long long)));
+        SDVAR_HIP(hipMemset(g_guard_cnt, 0, 4 * sizeof(unsigned long long)));
+    }
+    g_guard_on = on != 0;
+    return SDVAR_OK;
+}
+
+int sdvar_debug_get_f16x2_guard(uint64_t* out4, int32_t reset) {
+    SDVAR_CHECK_ARG(out4, "debug_get_f16x2_guard: null");
+    for (int i = 0; i < 4; ++i) out4[i] = 0;
+    if (!g_guard_cnt) return SDVAR_OK;
+    SDVAR_HIP(hipDeviceSynchronize());
+    SDVAR_HIP(hipMemcpy(out4, g_guard_cnt, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (reset) SDVAR_HIP(hipMemset(g_guard_cnt, 0, 4 * sizeof(unsigned long long)));
+    return SDVAR_OK;
+}
 
 int sdvar_debug_set_gemm_stamps(uint64_t* stamps) { debug_set_gemm_stamps((unsigned long long*)stamps); return SDVAR_OK; }
 

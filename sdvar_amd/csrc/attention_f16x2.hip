@@ -46,7 +46,7 @@ struct AttnHArgs {
 __device__ __forceinline__ void split8h(const float* v, f16x8& h, f16x8& l) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const float x = fminf(fmaxf(v[e], -65504.0f), 65504.0f);
+        const float x = clamp_f16_range(v[e]);            // NaN stays NaN (common.h)
         const _Float16 hh = (_Float16)x;
         h[e] = hh; l[e] = (_Float16)(x - (float)hh);
     }

@@ -92,10 +92,15 @@ __device__ __forceinline__ void split3(float x, uint16_t& p0, uint16_t& p1, uint
     p0 = (uint16_t)(u0 >> 16); p1 = (uint16_t)(u1 >> 16); p2 = (uint16_t)(__float_as_uint(r2) >> 16);
 }
 
-// ---- fp32 -> two fp16 planes (f16x2 operands, gemm_f16x2.hip): h = fp16(x) round-to-nearest, l = fp16(x - h); x saturates at the
-// fp16 range instead of turning into inf - inf = NaN
+// ---- fp32 -> two fp16 planes (f16x2 operands, gemm_f16x2.hip): h = fp16(x) round-to-nearest, l = fp16(x - h); a finite x saturates at the
+// fp16 range instead of turning into inf - inf = NaN, and a NaN stays a NaN in both planes (v_max / v_min return their non-NaN operand: a bare
+// clamp would turn an upstream divergence into a finite -65504).  Saturated / NaN elements are counted by the f16x2 guard (api.hip).
+__device__ __forceinline__ float clamp_f16_range(float x) {
+    const float c = fminf(fmaxf(x, -65504.0f), 65504.0f);
+    return x != x ? x : c;
+}
 __device__ __forceinline__ void split2h(float x, uint16_t& h, uint16_t& l) {
-    x = fminf(fmaxf(x, -65504.0f), 65504.0f);
+    x = clamp_f16_range(x);
     const _Float16 hh = (_Float16)x;
     const _Float16 ll = (_Float16)(x - (float)hh);
     h = __builtin_bit_cast(uint16_t, hh); l = __builtin_bit_cast(uint16_t, ll);

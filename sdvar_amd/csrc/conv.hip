@@ -19,6 +19,13 @@
 
 #include "common.h"
 
+// result-corrupting timing switches (SDVAR_CONV_DBG) exist only in -DSDVAR_TIMING_EXPERIMENTS builds (make EXTRA=-DSDVAR_TIMING_EXPERIMENTS)
+#ifdef SDVAR_TIMING_EXPERIMENTS
+#define SDVAR_CDBG(a, bit) ((a).dbg & (bit))
+#else
+#define SDVAR_CDBG(a, bit) 0
+#endif
+
 namespace sdvar {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -81,14 +88,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[5
                 const int hw = a.ih * a.iw, b = m / hw, rem = m - b * hw, y = rem / a.iw, x = rem - y * a.iw;
                 orow = ((size_t)(b * 2 * a.ih + 2 * y + (phase >> 1)) * (2 * a.iw) + 2 * x + (phase & 1));
             }
-            if (!(a.dbg & 4)) outp[orow * a.ldo + n] = v;
+            if (!SDVAR_CDBG(a, 4)) outp[orow * a.ldo + n] = v;
             acc[j][r] = v;
         }
     }
     // GroupNorm statistics of the tile just written (the next layer's norm): per column sum / sum of squares over the 256 rows
     // (all of one image: the host enables this only when H W is a multiple of 256), reduced lane -> wave -> workgroup through
     // LDS in a fixed order, then per group in fp64.  Saves a full read of the activation tensor per normalisation.
-    if (EPI != CEPI_PARTIAL && a.gn_part && !(a.dbg & 2)) {
+    if (EPI != CEPI_PARTIAL && a.gn_part && !SDVAR_CDBG(a, 2)) {
         float* red = reinterpret_cast<float*>(csm);          // [2][8][160]
         __syncthreads();                                     // every wave is done with the operand stages
 #pragma unroll
@@ -355,7 +362,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(ConvArgs a) {
             }
         }
     }
-    if (a.dbg & 1) return;
+    if (SDVAR_CDBG(a, 1)) return;
     conv_epilogue<EPI>(a, acc, a.wsi ? *a.wsi : 1.0f, m0, n0, tm, ks, phase, wave, li, lh, tid, csm);
 }
 
@@ -469,8 +476,12 @@ int conv_planes(const uint16_t* X, size_t xps, size_t x_rows, int x_row0, const 
     SDVAR_CHECK_ARG(pfmt == PLANES_BF16X3 || pfmt == PLANES_F16X2, "conv: plane format %d", pfmt);
     const bool F16 = pfmt == PLANES_F16X2;
     ConvArgs a{X, W, xps, wps, x_rows, x_row0, F16 ? wsi : nullptr, bias, res, out, M, N, Cin / 32, taps, H, Wd, N, 1, taps * (Cin / 32), nullptr, 1, up_phase, w_phase_stride, 0};
+#ifdef SDVAR_TIMING_EXPERIMENTS
     static const int conv_dbg = getenv("SDVAR_CONV_DBG") ? atoi(getenv("SDVAR_CONV_DBG")) : 0;
     a.dbg = conv_dbg;
+#else
+    a.dbg = 0;
+#endif
     const int nkt = taps * (Cin / 32);
     const int tiles = ((M + CBM - 1) / CBM) * ((N + CBN - 1) / CBN);
     int split = up_phase >= 0 ? 1 : force_split > 0 ? force_split : conv_choose_split(M, N, nkt, ws ? ws_floats : 0, F16 ? 1200.0 : 2100.0);

@@ -398,6 +398,38 @@ int qk_norm_append(const float* qkv, const float* scale_mul, float* q_out, void*
     return SDVAR_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ f16x2 guard (debug)
+// The f16x2 operand format saturates finite activations at +-65504 and loses relative precision below ~1e-3 (gemm_f16x2.hip header).  With the guard
+// switched on (sdvar_debug_set_f16x2_guard) every producer of GEMM operand planes in stage_forward is followed by this pass over the HIGH plane it
+// wrote: cnt[0] += elements seen, cnt[1] += |h| == 65504 (saturated, or exactly the largest fp16 number), cnt[2] += NaN / Inf, cnt[3] += 0 < |h| < 2^-10
+// (the low plane of such a value is subnormal or zero: relative error above 2^-22).  Off by default: one extra read of the plane per producer.
+__global__ __launch_bounds__(256) void planes_guard_kernel(const uint16_t* __restrict__ h, size_t n8, unsigned long long* cnt) {
+    unsigned int sat = 0, bad = 0, tiny = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        const u32x4 w = *reinterpret_cast<const u32x4*>(h + 8 * i);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const uint32_t a = ((w[e >> 1] >> (16 * (e & 1))) & 0x7FFFu);
+            sat += a == 0x7BFFu; bad += a >= 0x7C00u; tiny += (a != 0u && a < 0x1400u);
+        }
+    }
+    sat = (unsigned int)wave_sum((float)sat); bad = (unsigned int)wave_sum((float)bad); tiny = (unsigned int)wave_sum((float)tiny);     // < 2^24 per wave: exact in fp32
+    if ((threadIdx.x & 63) == 0) {
+        if (sat) atomicAdd(cnt + 1, (unsigned long long)sat);
+        if (bad) atomicAdd(cnt + 2, (unsigned long long)bad);
+        if (tiny) atomicAdd(cnt + 3, (unsigned long long)tiny);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(cnt, (unsigned long long)n8 * 8ull);
+}
+
+int planes_guard(const uint16_t* h_plane, size_t n, unsigned long long* cnt, hipStream_t stream) {
+    SDVAR_CHECK_ARG(h_plane && cnt && n % 8 == 0 && ((uintptr_t)h_plane % 16) == 0, "planes_guard: plane must be 16-byte aligned with a multiple of 8 elements");
+    const size_t n8 = n / 8, blocks = (n8 + 255) / 256;
+    hipLaunchKernelGGL(planes_guard_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, stream, h_plane, n8, cnt);
+    SDVAR_LAUNCH_CHECK();
+    return SDVAR_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ small helpers
 __global__ void silu_kernel(const float* __restrict__ x, float* __restrict__ y, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -791,8 +791,13 @@ int gemm_bf16x3_nt(const uint16_t* X, size_t xps, const uint16_t* W, size_t wps,
     SDVAR_CHECK_ARG(epi == PEPI_BIAS_GELU_PLANES ? (outp != nullptr && N % 4 == 0) : (out != nullptr && ldo >= N), "gemm_bf16x3: missing output");
     SDVAR_CHECK_ARG(((uintptr_t)X % 16) == 0 && ((uintptr_t)W % 16) == 0 && xps % 8 == 0 && wps % 8 == 0, "gemm_bf16x3: planes must be 16-byte aligned");
     if (epi == PEPI_GATED_RES) SDVAR_CHECK_ARG(res && gate && rows_per_gate > 0 && ldres >= N, "gemm_bf16x3: gated-residual epilogue needs res/gate");
+#ifdef SDVAR_TIMING_EXPERIMENTS       // results wrong: every workgroup streams tile (0, 0)
+    static const int same_tile = getenv("SDVAR_DEBUG_SAME_TILE") ? atoi(getenv("SDVAR_DEBUG_SAME_TILE")) : 0;
+#else
+    const int same_tile = 0;
+#endif
     GemmPArgs a{X, W, xps, wps, bias, out, outp, ops, res, gate, M, N, K, ldo, ldres, rows_per_gate > 0 ? rows_per_gate : 1, gate_stride, 1, K / PBK,
-                g_dbg_stamps, getenv("SDVAR_DEBUG_SAME_TILE") ? atoi(getenv("SDVAR_DEBUG_SAME_TILE")) : 0, 0, 0};
+                g_dbg_stamps, same_tile, 0, 0};
     size_t wsf = 0;
     (void)splitk_workspace(&wsf);
     int bm, split, tail = 0;

@@ -30,6 +30,15 @@ unsigned long long* debug_get_gemm_stamps();      // gemm_bf16x3.hip
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 enum { HEPI_BIAS = 0, HEPI_BIAS_GELU_PLANES = 1, HEPI_GATED_RES = 2, HEPI_PARTIAL = 3, HEPI_QKV = 4 };
 
+// Result-corrupting timing switches (SDVAR_GEMM_DBG: skip the in-loop DMA / barrier / fragment reads / reduce launch) exist only in builds made with
+// -DSDVAR_TIMING_EXPERIMENTS (make EXTRA=-DSDVAR_TIMING_EXPERIMENTS, tools/micro/gemm_dbg_exp.sh): the product library carries neither the branches
+// nor the environment variable.
+#ifdef SDVAR_TIMING_EXPERIMENTS
+#define SDVAR_DBG(a, bit) ((a).dbg & (bit))
+#else
+#define SDVAR_DBG(a, bit) 0
+#endif
+
 constexpr int HBK = 32;             // k per LDS stage
 constexpr int HBN = 128;
 
@@ -312,13 +321,13 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_v2_kernel(GemmHArgs a) {
         else if (behind == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else if (behind == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (!(a.dbg & 2)) __builtin_amdgcn_s_barrier();
-        const bool pf = t + NS - 1 < nk && !(a.dbg & 1);
+        if (!SDVAR_DBG(a, 2)) __builtin_amdgcn_s_barrier();
+        const bool pf = t + NS - 1 < nk && !SDVAR_DBG(a, 1);
         const uint32_t sb = (uint32_t)(uintptr_t)(lds_ptr_t)(hsm + (t % (NS == 4 ? 3 : NS)) * H2_STAGE);
         const uint32_t aa0 = sb + 2 * (offa0 + ch0), aa1 = sb + 2 * (offa0 + ch1), ab0 = sb + 2 * (offb + ch0), ab1 = sb + 2 * (offb + ch1);
         // fa[s][plane][row tile], fb[s][plane]: X plane p at +8192 p bytes, second 32-row tile at +2048; W plane p at +16384 + 8192 p
         f16x8 fa[2][2][2], fb[2][2];
-        if (a.dbg & 4) {
+        if (SDVAR_DBG(a, 4)) {
 #pragma unroll
             for (int z = 0; z < 8; ++z) { fa[z >> 2][(z >> 1) & 1][z & 1] = __builtin_bit_cast(f16x8, f32x4{1.f, 2.f, 3.f, (float)z}); }
 #pragma unroll
@@ -817,6 +826,10 @@ float* splitk_workspace(size_t* floats);     // gemm.hip: the shared slab worksp
 
 static int g_force_bm_h = 0, g_force_split_h = 0;
 void debug_set_gemm_cfg_h(int bm, int split) { g_force_bm_h = bm; g_force_split_h = split; }
+// test aid: {row tile of the last gemm_f16x2_nt call of this host thread, its K split, launches that took the hybrid tail split since the last read,
+// QKV launches that finished q and k in their epilogue since the last read} - tests assert that the path they mean to cover is the one that ran
+static thread_local int g_last_cfg_h[4] = {0, 0, 0, 0};
+void debug_get_gemm_cfg_h(int* out) { for (int i = 0; i < 4; ++i) out[i] = g_last_cfg_h[i]; g_last_cfg_h[2] = g_last_cfg_h[3] = 0; }
 
 // same cost model as gemm_bf16x3.hip with half the matrix work per K-step: 3 MFMAs x 32 cycles per 16 k per 32x32 tile
 static void choose_cfg_h(int M, int N, int K, size_t ws_floats, int* bm_out, int* split_out, int* tail_out, bool allow_hybrid, bool deferred) {
@@ -1007,7 +1020,7 @@ static int launch_h(GemmHArgs a, int epi, int split, hipStream_t stream) {
         int rc = v2 ? launch_h2_kernel<HEPI_PARTIAL>(p, tiles * split, stream) : launch_small_any<SB, HEPI_PARTIAL>(p, tiles * split, stream);
         if (rc) return rc;
         if (g_defer_h) { *g_defer_h = split; return SDVAR_OK; }
-        if (a.dbg & 8) return SDVAR_OK;            // timing experiments: the slab launch alone (what a deferring caller pays)
+        if (SDVAR_DBG(a, 8)) return SDVAR_OK;      // timing experiments: the slab launch alone (what a deferring caller pays)
         return launch_reduce_h(a, ws, split, epi, stream);
     }
     a.split = 1; a.k_per_split = nkt;
@@ -1057,7 +1070,13 @@ int gemm_f16x2_nt(const uint16_t* X, size_t xps, const uint16_t* W, size_t wps, 
     SDVAR_CHECK_ARG(epi == HEPI_BIAS_GELU_PLANES ? (outp != nullptr && N % 4 == 0) : (out != nullptr && ldo >= N), "gemm_f16x2: missing output");
     SDVAR_CHECK_ARG(((uintptr_t)X % 16) == 0 && ((uintptr_t)W % 16) == 0 && xps % 8 == 0 && wps % 8 == 0, "gemm_f16x2: planes must be 16-byte aligned");
     if (epi == HEPI_GATED_RES) SDVAR_CHECK_ARG(res && gate && rows_per_gate > 0 && ldres >= N, "gemm_f16x2: gated-residual epilogue needs res/gate");
+#ifdef SDVAR_TIMING_EXPERIMENTS
     static const int dbg = getenv("SDVAR_GEMM_DBG") ? atoi(getenv("SDVAR_GEMM_DBG")) : 0;
+    static const bool warned = (dbg && fprintf(stderr, "[sdvar] SDVAR_GEMM_DBG=%d: timing experiment build, GEMM results are WRONG\n", dbg), true);
+    (void)warned;
+#else
+    const int dbg = 0;
+#endif
     GemmHArgs a{X, W, xps, wps, wsi, bias, out, outp, ops, res, gate, M, N, K, ldo, ldres, rows_per_gate > 0 ? rows_per_gate : 1, gate_stride, 1, K / HBK, 0, dbg, debug_get_gemm_stamps(), QkvEpi{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0}, 0, 0};
     auto al16 = [](const void* q) { return ((uintptr_t)q % 16) == 0; };
     a.vec = N % 4 == 0 && al16(bias) && al16(out) && al16(outp) && al16(res) && al16(gate) && ldo % 4 == 0 && ops % 4 == 0 &&
@@ -1080,6 +1099,7 @@ int gemm_f16x2_nt(const uint16_t* X, size_t xps, const uint16_t* W, size_t wps, 
         const int kps = (nkt + split - 1) / split;
         split = (nkt + kps - 1) / kps;
     }
+    g_last_cfg_h[0] = bm; g_last_cfg_h[1] = split; g_last_cfg_h[2] += (bm == 256 && tail > 0) ? 1 : 0; g_last_cfg_h[3] += (qkv && split == 1 && tail == 0) ? 1 : 0;
     if (qkv && split == 1 && tail == 0) {
         a.qk = *g_qkv_epi; a.split = 1; a.k_per_split = K / HBK;
         *g_qkv_fused = 1;

@@ -513,12 +513,15 @@ __global__ __launch_bounds__(256) void verify_match_kernel(AcceptArgs a) {
     const long long did = a.draft_ids[(size_t)b * a.ids_stride + tok];
     bool match;
     if (a.mode == 1) {              // top-k membership: count entries strictly above the draft token's score
-        const float xd = __fsub_rn(__fmul_rn(opt, pc[did]), __fmul_rn(tt, pu[did]));
+        // the ids may come straight from a caller (SDVAR.advanced_token_matching): an id outside [0, V) matches nothing and is never dereferenced
+        const bool valid = did >= 0 && did < (long long)V;            // block-uniform
+        const long long sid = valid ? did : 0;
+        const float xd = __fsub_rn(__fmul_rn(opt, pc[sid]), __fmul_rn(tt, pu[sid]));
         int above = 0;
 #pragma unroll
         for (int i = 0; i < VPT; ++i) above += (x[i] > xd) ? 1 : 0;
         const double tot = block_sum_d((double)above, redd);
-        match = tot < (double)a.top_k;
+        match = valid && tot < (double)a.top_k;
     } else if (a.mode == 2) {       // KL(p_target || p_draft) over the two CFG distributions of this token
         const int lj = a.qbeg[st + 1] - a.qbeg[st], ti = tok - a.qbeg[st];
         const float* dc = a.draft_logits + a.dl_off[st] + ((size_t)b * lj + ti) * V;

@@ -100,6 +100,9 @@ _SIGNATURES = {
     "sdvar_debug_set_gemm_cfg": (_I, [_I, _I]),
     "sdvar_debug_set_gemm_stamps": (_I, [_P]),
     "sdvar_debug_set_qkv_fuse": (_I, [_I]),
+    "sdvar_debug_get_gemm_cfg": (_I, [C.POINTER(_I)]),
+    "sdvar_debug_set_f16x2_guard": (_I, [_I]),
+    "sdvar_debug_get_f16x2_guard": (_I, [C.POINTER(_U64), _I]),
     "sdvar_prof_enable": (_I, [_I]),
     "sdvar_prof_collect": (_I, [C.POINTER(_D), C.POINTER(C.c_int64), C.POINTER(_D), C.POINTER(_D)]),
 }
@@ -458,6 +461,33 @@ def verify_accept(logits: torch.Tensor, B: int, lens: Sequence[int], V: int, ts:
                                       o(draft_logits), _ptr(counts), o(argmax_out), o(match_out), o(corrected_out), _stream()))
 
 
+def last_gemm_cfg() -> Dict[str, int]:
+    """Test aid: row tile and K split of the last f16x2 GEMM call of this thread, and how many launches since the last read took the hybrid tail split /
+    finished q and k in the QKV epilogue (reading resets the two counters)."""
+    v = (_I * 4)()
+    _check(load_library().sdvar_debug_get_gemm_cfg(v))
+    return dict(bm=v[0], split=v[1], tail_launches=v[2], fused_qkv_launches=v[3])
+
+
+_GUARD_ON = False
+
+
+def f16x2_guard(on: bool):
+    """Debug switch (mode f16x2): count saturated / non-finite / tiny elements of every GEMM operand plane written inside stage_forward.
+    While it is on, every sampler call ends with a device sync and reports the counters of that call in `SampleResult.stats["f16x2_guard"]`."""
+    global _GUARD_ON
+    _check(load_library().sdvar_debug_set_f16x2_guard(1 if on else 0))
+    _GUARD_ON = bool(on)
+    if on:
+        f16x2_guard_collect(reset=True)
+
+
+def f16x2_guard_collect(reset: bool = True) -> Dict[str, int]:
+    v = (_U64 * 4)()
+    _check(load_library().sdvar_debug_get_f16x2_guard(v, 1 if reset else 0))
+    return dict(elements=int(v[0]), saturated=int(v[1]), non_finite=int(v[2]), tiny=int(v[3]))
+
+
 def prof_enable(on: bool):
     _check(load_library().sdvar_prof_enable(1 if on else 0))
 
@@ -567,6 +597,8 @@ class Sampler:
                     m.embed_next(self.nxt[0], si + 1, self.x_t, lad.lens[si + 1], 0)
             m.kv_set_len(0)
         res.stats = dict(target_calls=S, draft_stage_calls=0, forced_accepts=0, accepted_tokens=0)
+        if _GUARD_ON:
+            res.stats["f16x2_guard"] = f16x2_guard_collect()
         return res
 
     # ---- SDVAR.sdvar_autoregressive_infer_cfg_sd_test3 (var.py:604-865): the draft samples stages < entry_num, the target the rest
@@ -704,8 +736,10 @@ class Sampler:
         c = self.counts_host.tolist()
         if st.accept_scope == "global":            # batch-wide decision across ranks (reference-literal for one big batch)
             from . import dist as D
-            n, matched, _ = D.global_accept(c[:g], c[17:17 + g], st.thr, self.dev)
-            return n, matched
+            n, _, _ = D.global_accept(c[:g], c[17:17 + g], st.thr, self.dev)
+            # the DECISION is global; the counts handed back stay this rank's own: every statistic built from them (accepted / corrected tokens,
+            # rounds[].matched) is per rank and summed once by dist.gather_counters - global counts here would be added world-size times
+            return n, c[:g]
         return c[16], c[:g]
 
     def spec_correct(self, st: "SpecState", n_acc: int, matched: Sequence[int]) -> int:
@@ -784,6 +818,8 @@ class Sampler:
             optimistic = n_acc == g and not forced
             self.spec_commit(st, n_acc, forced, acc_tok)
         self.spec_end(st)
+        if _GUARD_ON:
+            res.stats["f16x2_guard"] = f16x2_guard_collect()
         return res
 
     def _ensure_second_stream(self):

@@ -1,3 +1,4 @@
+# needs a timing-experiment build of the library: make -C sdvar_amd/csrc clean all EXTRA=-DSDVAR_TIMING_EXPERIMENTS (the product build has no such switches)
 for d in 0 1 2 4 5 7; do echo "dbg=$d"; SDVAR_GEMM_DBG=$d python - <<'PY'
 import ctypes as C, torch, sys, os
 sys.path.insert(0, os.getcwd())

@@ -1,3 +1,4 @@
+# needs a timing-experiment build of the library: make -C sdvar_amd/csrc clean all EXTRA=-DSDVAR_TIMING_EXPERIMENTS (the product build has no such switches)
 # the sweep the f16x2 cost model is fitted to: HBM-cold weights, d12 and d16, single stages and gamma = 2 chunks; the launches whose K-slice sum the
 # consumer takes over (qkv, proj, fc2) are timed as the slab launch alone (SDVAR_GEMM_DBG=8), fc1 with its reduce launch
 out=${1:-gpurun_out/sweep_cold}
