@@ -46,6 +46,7 @@ def host_cores():
 CONFIGS = {
     "P1": dict(dd=12, dt=16, ladder="256", B=8, cfg=1.5, kv_fp16=False, name="VAR-d16 256^2 B=8, d12 draft + d16 verify"),
     "P2": dict(dd=16, dt=24, ladder="256", B=16, cfg=1.5, kv_fp16=False, name="VAR-d24 256^2 B=16, d16 draft + d24 verify"),
+    "P3": dict(dd=16, dt=30, ladder="256", B=8, cfg=1.5, kv_fp16=False, name="VAR-d30 256^2 B=64 over 8 GPUs = B=8 per GPU (draft unspecified in BASELINE.json: d16), batch split, counters gathered over RCCL"),
     "P4": dict(dd=16, dt=30, ladder="512", B=8, cfg=3.0, kv_fp16=True, name="VAR-d30 512^2 B=8, cfg 3.0, fp16 KV cache (draft unspecified in BASELINE.json: d16)"),
 }
 
@@ -60,7 +61,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="P1", choices=sorted(CONFIGS), help="BASELINE.json configuration (P1 = configs[1], the one `metric` is quoted on; "
-                    "P2 / P4 = configs[2] / configs[4], parity cases with a bench row)")
+                    "P2 / P3 / P4 = configs[2] / configs[3] (one rank's share: run with --gpus 8 for the whole config) / configs[4], parity cases with a bench row)")
     ap.add_argument("--batch", type=int, default=None, help="images per GPU (default: the configuration's)")
     ap.add_argument("--depth-draft", type=int, default=None)
     ap.add_argument("--depth-target", type=int, default=None)
@@ -293,6 +294,52 @@ def main():
             for m in mods:
                 m.invalidate_engine()
             del sdv, mods
+        # (c) speculation against not speculating, per acceptance mode (>= 1 means the draft -> verify loop pays on this hardware at this batch)
+        plain = extra["plain_target_ar"]["images_per_s"]
+        extra["speculation_gain"] = dict({m: extra[m]["images_per_s"] / plain for m in ("accept_all", "reject_all", "natural") if m in extra}, **{args.mode: value / plain},
+                                         note="images/s of the speculative sampler / images/s of plain_target_ar, same GPU, same decode overlap; with a d12 draft in front of a d16 target "
+                                              "(43 % of its flops) and the large stages matrix-pipe bound at B=8, chunked verification cannot recover the draft's cost: see DESIGN.md section 5")
+        if rank == 0 and world == 1 and args.config == "P1":
+            # (d) SURVEY App. C.2: draft == target weights, top_k = 1 - the one random-weight setting whose NATURAL acceptance is not degenerate (I1: everything accepted)
+            dc_same = E.ModelCtx(sd_t, args.depth_target, pns, B, 1, dev, gemm_mode=args.gemm_mode, kv_fp16=conf["kv_fp16"])
+            smp_same = E.Sampler(tc, qc, dc_same)
+            def same_step(seed):
+                res = smp_same.spec_decode(labels, CFG, args.gamma, 1, 0.0, E.Noise("device", seed, image_offset=lo), thr=0.5)
+                state["st"] = dict(res.stats)
+                j = state["i"] & 1; state["i"] += 1
+                if dec_done[j] is not None:
+                    main_stream.wait_event(dec_done[j])
+                fh_buf[j].copy_(res.f_hat)
+                ready = torch.cuda.Event(); ready.record(main_stream); dec_stream.wait_event(ready)
+                with torch.cuda.stream(dec_stream):
+                    decode(fh_buf[j]).add_(1).mul_(0.5)
+                    dec_done[j] = torch.cuda.Event(); dec_done[j].record(dec_stream)
+            dts, n = rate(same_step)
+            stx = state["st"]
+            extra["identical_draft_top1"] = dict(images_per_s=B * n / dts, mean_accepted_tokens_per_step=stx["accepted_tokens"] / max(1, stx["target_calls"]), target_calls=stx["target_calls"],
+                                                 forced_accepts=stx["forced_accepts"], note=f"draft = the d{args.depth_target} target's own weights, top_k=1 (greedy), natural threshold 0.5: every stage is accepted (invariant I1)")
+            log(f"identical draft, top_k=1: {extra['identical_draft_top1']['images_per_s']:.2f} images/s, {extra['identical_draft_top1']['mean_accepted_tokens_per_step']:.1f} accepted tokens/step")
+            dc_same.close(); del smp_same
+            # (e) the exact split-operand mode (bf16x3: no range limit on the activations; f16x2 saturates at +-65504), same loop
+            if tc.gemm_mode != "bf16x3":
+                dcx = E.ModelCtx(sd_d, args.depth_draft, pns, B, 1, dev, gemm_mode="bf16x3", kv_fp16=conf["kv_fp16"])
+                tcx = E.ModelCtx(sd_t, args.depth_target, pns, B, max(args.gamma, 1), dev, gemm_mode="bf16x3", kv_fp16=conf["kv_fp16"])
+                smpx = E.Sampler(tcx, qc, dcx)
+                def exact_step(seed):
+                    res = smpx.spec_decode(labels, CFG, args.gamma, 900, 0.96, E.Noise("device", seed, image_offset=lo), thr=thr[args.mode])
+                    j = state["i"] & 1; state["i"] += 1
+                    if dec_done[j] is not None:
+                        main_stream.wait_event(dec_done[j])
+                    fh_buf[j].copy_(res.f_hat)
+                    ready = torch.cuda.Event(); ready.record(main_stream); dec_stream.wait_event(ready)
+                    with torch.cuda.stream(dec_stream):
+                        decode(fh_buf[j]).add_(1).mul_(0.5)
+                        dec_done[j] = torch.cuda.Event(); dec_done[j].record(dec_stream)
+                dtx, n = rate(exact_step)
+                extra["bf16x3"] = dict(images_per_s=B * n / dtx, note="the same loop with gemm_mode bf16x3 (operands split EXACTLY into 3 bf16 planes, 6 MFMA products per fp32 product): "
+                                                                      "the mode without f16x2's activation range limit")
+                log(f"bf16x3 (exact split) mode: {extra['bf16x3']['images_per_s']:.2f} images/s")
+                dcx.close(); tcx.close(); del smpx
 
     # ---- roofline leg: HIP events around every launch of one step (launch stream = torch's current stream)
     drain(); torch.cuda.synchronize()
@@ -369,6 +416,7 @@ def main():
                                f"verifier {'in lock-step with' if args.no_run_ahead else 'one round behind'} the draft once gamma = 1", "parallelism": f"{world} independent batch shards"},
         "mean_accepted_tokens_per_step": agg["mean_accepted_tokens_per_step"],
         "target_calls": agg["target_calls"], "draft_stage_calls": agg["draft_stage_calls"], "forced_accepts": agg["forced_accepts"],
+        "per_rank_counters": dict(keys=list(D.COUNTER_KEYS), rows=agg["per_rank"], note="all-gathered over the process group (RCCL on the GPU box): one row per rank"),
         "images_per_s_no_decode": B * world * nd_steps / dt_nd,
         "decode_ms_per_batch": dec_ms, "decoder_tflops_algorithmic": dec_tflops, "decoder": "pytorch-miopen" if args.torch_decode else "hip (csrc/conv.hip, csrc/vae.hip)",
         "modes": extra, "roofline_note": "roofline / kernel_class_ms_per_step come from one step with every kernel alone on the GPU (no draft/verify or decode overlap)", "roofline": roofline, "roofline_verify_attention": roofline_attn, "roofline_verify_attention_short_stages": roofline_attn_small, "kernel_class_ms_per_step": class_ms,

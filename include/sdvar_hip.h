@@ -211,7 +211,8 @@ int sdvar_op_vae_prep(const float* in, const float* stats, const float* gamma, c
 int sdvar_op_conv_planes(const uint16_t* x_planes, uint64_t x_plane_stride, uint64_t x_rows, int32_t x_row0, const uint16_t* w_planes, uint64_t w_plane_stride,
                          int32_t plane_format, const float* w_scale, const float* bias, const float* res, float* out, int32_t B, int32_t H, int32_t W, int32_t N,
                          int32_t Cin, int32_t taps, float* workspace, uint64_t workspace_floats, int32_t force_split, void* stream);
-/* tuning aid (tools/gemm_bench.py --sweep): force the GEMM row tile (32/64/128) and K-slice count; 0 = automatic */
+/* tuning / test aid (tools/gemm_bench.py --sweep): force the GEMM row tile (32/64/128/256) and K-slice count; 0 = automatic.  f16x2 mode only: bm 512 = the
+ * 256 x 256 tile kernel; bm 256 with split = -T forces the hybrid tail split T ways on shapes that have a partial last round. */
 int sdvar_debug_set_gemm_cfg(int32_t bm, int32_t split);
 /* test aid: 0 = the QKV launch of sdvar_stage_forward never finishes q and k in its epilogue (qk_norm_append does all three), 1 (default) = it does
  * whenever the launch comes out unsplit on the f16x2 planes cache */

@@ -21,7 +21,7 @@ float* set_splitk_workspace(float* p);
 size_t splitk_workspace_floats();
 int qk_norm_append(const float* qkv, const float* scale_mul, float* q_out, void* k_cache, void* v_cache, int kv_f16, int R, int l, int H, int Lmax, int pos0, const PendingSplitK* pend, int v_only, hipStream_t stream);
 int gemm_f16x2_qkv(const uint16_t* X, size_t xps, const uint16_t* W, size_t wps, const float* wsi, const float* bias, float* out, int ldo, int M, int N, int K,
-                   const float* scale_mul, float* q_out, void* k_cache, int l, int H, int Lp, int pos0, int kv_fmt, int* defer, int* fused, hipStream_t stream);
+                   const float* scale_mul, float* q_out, void* k_cache, void* v_cache, int l, int H, int Lp, int pos0, int kv_fmt, int* defer, int* fused, hipStream_t stream);
 int silu_rows(const float* x, float* y, int n, hipStream_t stream);
 int add_row_vector(const float* src, const float* vec, float* out, int rows, int cols, hipStream_t stream);
 int prologue(const long long* labels, const float* class_emb, const float* pos_start, const float* lvl_pos, float* cond, float* x0, int B, int C, int num_classes, hipStream_t stream);
@@ -468,17 +468,17 @@ static int stage_forward_impl(sdvar_model_t* m, float* x, int32_t s0, int32_t n,
           SDVAR_TRY(ln_modulate(x, ada + 2 * C, ada + 4 * C, m->xn, P ? m->xn_p : nullptr, ps, M, C, lsum, 6 * C, &pend, PF, s)); pend.ws = nullptr; }
         if (G2) SDVAR_TRY(guard_planes(m->xn_p, ps, s));
         PendingSplitK pq{nullptr, nullptr, nullptr, 0, 1, 0};
-        int qk_fused = 0;        // the QKV launch came out unsplit and finished q and k in its epilogue (f16x2 planes cache): only V^T is left for qk_norm_append
+        int qk_fused = 0;        // the QKV launch came out unsplit and finished q, k and v in its epilogue (f16x2 planes cache): no qk_norm_append
         if (!(skip & 16)) { ProfScope pp(0, 2 * dM * 3 * dC * dC, 4 * (dM * dC + 3 * dC * dC + 3 * dM * dC), s);
           if (P && m->d.gemm_mode == 2 && (m->kv_fmt == 3 || m->kv_fmt == 4)) {
-                   SDVAR_TRY(gemm_f16x2_qkv(m->xn_p, ps, b.qkv_wp, (size_t)3 * C * C, b.wsc + 1, b.qkv_bias, m->qkv, 3 * C, M, 3 * C, C, b.scale_mul, m->qbuf, b.kc, lsum, H, m->Lkv,
+                   SDVAR_TRY(gemm_f16x2_qkv(m->xn_p, ps, b.qkv_wp, (size_t)3 * C * C, b.wsc + 1, b.qkv_bias, m->qkv, 3 * C, M, 3 * C, C, b.scale_mul, m->qbuf, b.kc, b.vc, lsum, H, m->Lkv,
                                             m->kv_len, m->kv_fmt, dp, &qk_fused, s));
                    if (defer) pq = PendingSplitK{ws, b.qkv_bias, nullptr, defer, 1, 0}; }
           else if (P) { SDVAR_TRY(plane_gemm(m, m->xn_p, ps, b.qkv_wp, (size_t)3 * C * C, b.wsc, b.qkv_bias, m->qkv, 3 * C, nullptr, 0, M, 3 * C, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, dp, s));
                    if (defer) pq = PendingSplitK{ws, b.qkv_bias, nullptr, defer, 1, 0}; }
           else SDVAR_TRY(gemm_f32_nt(m->xn, C, b.qkv_w, b.qkv_bias, m->qkv, 3 * C, M, 3 * C, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, s)); }
-        if (!(skip & 2)) { ProfScope pp(3, 6 * dM * dC, 4 * 6 * dM * dC, s);
-          SDVAR_TRY(qk_norm_append(m->qkv, b.scale_mul, m->qbuf, b.kc, b.vc, m->kv_fmt, R, lsum, H, m->Lkv, m->kv_len, &pq, qk_fused, s)); }
+        if (!(skip & 2) && !qk_fused) { ProfScope pp(3, 6 * dM * dC, 4 * 6 * dM * dC, s);      // an unsplit QKV launch has finished q, k and v in its epilogue
+          SDVAR_TRY(qk_norm_append(m->qkv, b.scale_mul, m->qbuf, b.kc, b.vc, m->kv_fmt, R, lsum, H, m->Lkv, m->kv_len, &pq, 0, s)); }
         if (!(skip & 4)) { ProfScope pp(lsum <= 36 ? 8 : 1, 4.0 * R * H * 64.0 * lk, R * H * 64.0 * ((m->d.kv_dtype ? 4.0 : 8.0) * Ktot + 8.0 * lsum), s);
           if (bias) SDVAR_TRY(attention_masked(m->qbuf, b.kc, b.vc, m->kv_fmt, bias, m->att, P ? m->att_p : nullptr, ps, PF, R, H, lsum, m->Lkv, Ktot, s));
           else SDVAR_TRY(attention_f32(m->qbuf, b.kc, b.vc, m->kv_fmt, m->att, P ? m->att_p : nullptr, ps, PF, R, H, lsum, m->Lkv, Ktot, n, qbeg, vis, s)); }
@@ -717,10 +717,11 @@ int sdvar_op_noise_fill(float* q, int32_t B, int32_t l, int32_t V, uint64_t seed
 }
 
 int sdvar_debug_set_gemm_cfg(int32_t bm, int32_t split) {
-    SDVAR_CHECK_ARG(bm == 0 || bm == 32 || bm == 64 || bm == 128 || bm == 256, "debug_set_gemm_cfg: bm %d", bm);
-    SDVAR_CHECK_ARG(split >= 0 && split <= 64, "debug_set_gemm_cfg: split %d", split);
-    debug_set_gemm_cfg(bm, split);
-    debug_set_gemm_cfg_p(bm, split);
+    // f16x2 only: bm 512 = the 256 x 256 tile kernel; bm 256 with split -T = hybrid tail split T ways (the other GEMM modes take bm 256 / split 0 for those)
+    SDVAR_CHECK_ARG(bm == 0 || bm == 32 || bm == 64 || bm == 128 || bm == 256 || bm == 512, "debug_set_gemm_cfg: bm %d", bm);
+    SDVAR_CHECK_ARG(split >= -64 && split <= 64 && (split >= 0 || bm == 256), "debug_set_gemm_cfg: split %d", split);
+    debug_set_gemm_cfg(bm == 512 ? 256 : bm, split < 0 ? 0 : split);
+    debug_set_gemm_cfg_p(bm == 512 ? 256 : bm, split < 0 ? 0 : split);
     debug_set_gemm_cfg_h(bm, split);
     return SDVAR_OK;
 }

@@ -258,8 +258,8 @@ __device__ __forceinline__ float kv_elem(const void* base, int fmt, bool is_v, s
     const uint16_t* p = reinterpret_cast<const uint16_t*>(base) + head_elems * NP;
     const size_t ps = (size_t)Lmax * 64;
     size_t o;
-    if (is_v) { const int pos = (key & ~12) | ((key & 4) << 1) | ((key & 8) >> 1); o = (size_t)c * Lmax + pos; }     // V^T rows, bits 2 and 3 of the key swapped
-    else o = (size_t)key * 64 + c;
+    if (is_v && fmt == 2) { const int pos = (key & ~12) | ((key & 4) << 1) | ((key & 8) >> 1); o = (size_t)c * Lmax + pos; }     // bf16x3 planes: V^T rows, bits 2 and 3 of the key swapped
+    else o = (size_t)key * 64 + c;                  // K of every planes format, and V of the fp16-plane formats 3 / 4 (row-major like K)
     float v = 0.f;
     for (int k = NP - 1; k >= 0; --k) {
         const uint16_t u = p[k * ps + o];

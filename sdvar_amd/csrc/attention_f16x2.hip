@@ -11,10 +11,16 @@
 //
 // KV cache (Lp = Lmax rounded up to a multiple of 64, zero-initialised by the owner):
 //     kc  [R][H][NKP][Lp][64]  fp16   K planes, one 128-byte row per key
-//     vc  [R][H][NKP][64][Lp]  fp16   V^T planes, one row per channel; inside every block of 16 keys the position of key
-//                                     b3 b2 b1 b0 is b2 b3 b1 b0 (the order in which a lane's score registers hold their keys)
-// Mapping (wave64): workgroup = 4 waves = 128 queries of one (row, head); tiles of 32 keys x (NKP K planes + NKP V^T planes) are
-// DMA'd (global_load_lds, 16 B per lane) into a 3-stage ring (16 KB per stage at NKP = 2), XOR-swizzled as in attention_bf16x3.hip.
+//     vc  [R][H][NKP][Lp][64]  fp16   V planes, the SAME row-major layout (round 2 kept a transposed, key-permuted V^T copy that only a separate pass
+//                                     through LDS could write; now the QKV GEMM's epilogue appends k and v rows alike).  The V^T fragments of O^T = V^T P^T
+//                                     are taken from the row-major LDS tile with ds_read_b64_tr_b16 (cdna_hip_programming.md T10): per 16 lanes a block of
+//                                     4 keys x 16 channels comes back transposed, lane = channel, and the 4 key rows are free to choose, so the two reads
+//                                     of a fragment fetch exactly the keys {0..3, 8..11} + 4 lh of the k16 step - the order in which a lane's score
+//                                     registers hold their keys.
+// Mapping (wave64): workgroup = 4 waves = 128 queries of one (row, head); tiles of 32 keys x (NKP K planes + NKP V planes) are
+// DMA'd (global_load_lds, 16 B per lane) into a 3-stage ring (16 KB per stage at NKP = 2).  Swizzles (on the DMA source chunk and on the read address):
+// K rows chunk ^ ((row >> 1) & 7) (ds_read_b128 by 32 key rows); V rows chunk ^ (4 ((row >> 1) & 1)): the transposed read touches 4 consecutive rows x 64 B
+// per 32 lanes and rows r, r + 2 share their banks (128-byte rows), so rows 2, 3 of every 4 swap their 64-byte halves: conflict-free.
 // Algorithmic bytes per launch: R*H*64*4*(2*Ktot + 2*l) for NKP = 2 - now also the bytes the cache really holds.
 #include <stdlib.h>
 
@@ -50,6 +56,16 @@ __device__ __forceinline__ void split8h(const float* v, f16x8& h, f16x8& l) {
         const _Float16 hh = (_Float16)x;
         h[e] = hh; l[e] = (_Float16)(x - (float)hh);
     }
+}
+
+// One V^T fragment: 8 keys x this lane's channel = two ds_read_b64_tr_b16 (rows `off` .. + 3 and `off` + 8 rows .. + 3 of the addressed 4 x 16 blocks).
+// EXEC must be all ones (the gather crosses lanes): the callers keep whole waves active.  The wait is the compiler's (the builtin is counted in lgkmcnt).
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f16x8 lds_read_tr8(uint32_t addr, int off) {
+    typedef __attribute__((address_space(3))) s16x4* lp_t;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(uintptr_t)(addr + off));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(uintptr_t)(addr + off + 1024));
+    return __builtin_bit_cast(f16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
 // acc += A.B over the kept plane products, smallest terms first: a = planes of the cache operand (NKP of them), b = {h, l} of Q or P
@@ -100,17 +116,15 @@ __global__ __launch_bounds__(256, 2) void attention_f16x2_kernel(AttnHArgs a) {
         }
     }
 
-    // DMA, 6 instructions per wave per tile: K plane tile = 32 key rows of 128 B (wave w: rows 8w..8w+7, chunk swizzle
-    // (row >> 1) & 7); V^T plane tile = 64 channel rows of 64 B (wave w: rows 16w..16w+15, chunk swizzle (row >> 2) & 3).
-    // LDS ring of 3 stages (K planes then V^T planes, 24 KB each); tile t lives in stage t % 3 and is requested two
+    // DMA, 2 NKP instructions per wave per tile: a K / V plane tile = 32 key rows of 128 B (wave w: rows 8w..8w+7; K chunk swizzle (row >> 1) & 7, V chunk
+    // swizzle 4 ((row >> 1) & 1)).  LDS ring of 3 stages (K planes then V planes); tile t lives in stage t % 3 and is requested two
     // iterations before it is read: one 32-key iteration (~1 us) is shorter than the HBM/MALL latency.
     const size_t head = ((size_t)r * a.H + h) * NKP * (size_t)a.Lp * 64;
     const size_t kps = (size_t)a.Lp * 64;                    // plane stride, both operands
-    const int krow = 8 * wave + (lane >> 3), kchunk = (lane & 7) ^ ((krow >> 1) & 7);
-    const int vrow = 16 * wave + (lane >> 2), vchunk = (lane & 3) ^ ((vrow >> 2) & 3);
+    const int krow = 8 * wave + (lane >> 3), kchunk = (lane & 7) ^ ((krow >> 1) & 7), vchunk = (lane & 7) ^ (4 * ((krow >> 1) & 1));
     // loop-invariant 32-bit lane offsets + wave-uniform bases (common.h SDVAR_DMA16): no vector address arithmetic per tile
     const int swave = __builtin_amdgcn_readfirstlane(wave);
-    const uint32_t lk = (uint32_t)(krow * 64 + 8 * kchunk) * 2u, lv = (uint32_t)(vrow * a.Lp + 8 * vchunk) * 2u;
+    const uint32_t lk = (uint32_t)(krow * 64 + 8 * kchunk) * 2u, lv = (uint32_t)(krow * 64 + 8 * vchunk) * 2u;
     const char* const bk = reinterpret_cast<const char*>(a.kc + head);
     const char* const bv = reinterpret_cast<const char*>(a.vc + head);
     auto issue = [&](int t) {
@@ -118,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void attention_f16x2_kernel(AttnHArgs a) {
 #pragma unroll
         for (int p = 0; p < NKP; ++p) {
             SDVAR_DMA16(lk, bk + (p * kps + (size_t)t * AKT * 64) * 2, SDVAR_LDS_ADDR(st + p * APL));
-            SDVAR_DMA16(lv, bv + (p * kps + (size_t)t * AKT) * 2, SDVAR_LDS_ADDR(st + (NKP + p) * APL));
+            SDVAR_DMA16(lv, bv + (p * kps + (size_t)t * AKT * 64) * 2, SDVAR_LDS_ADDR(st + (NKP + p) * APL));
         }
     };
 
@@ -128,7 +142,11 @@ __global__ __launch_bounds__(256, 2) void attention_f16x2_kernel(AttnHArgs a) {
     // running maximum in log2 units (M = m log2 e, rounded once per tile so that p and the rescale factor use the same value)
     float M_run = -INFINITY, l_run = 0.f;
 
-    const int swk = (li >> 1) & 7, swv = (li >> 2) & 3;
+    const int swk = (li >> 1) & 7;
+    // transposed V reads: lane = (lh, channel block cb = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3) supplies the address of key row 4 lh + q (+ 16 j, + 8
+    // for the second half of the fragment), channels 32 db + 16 cb + 4 p .. + 3; with the row swizzle the 64-byte half of rows q >= 2 is flipped
+    const int vq = (lane >> 2) & 3, vp = lane & 3, vcb = (lane >> 4) & 1;
+    const uint32_t voff0 = (uint32_t)((4 * lh + vq) * 128 + (((vq >> 1) & 1) * 64) + vcb * 32 + vp * 8);       // db = 0; db = 1 is ^ 64
     const int ntiles = (kend + AKT - 1) / AKT;
     const float L2E = 1.4426950408889634f;
     issue(0);
@@ -142,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void attention_f16x2_kernel(AttnHArgs a) {
         if (!wave_active) continue;
         const int k0 = t * AKT;
         const uint16_t* sk = att_sm + (t % ANST) * ASTAGE + li * 64;              // this lane's K row (key li)
-        const uint16_t* sv = att_sm + (t % ANST) * ASTAGE + NKP * APL + li * 32;  // this lane's V^T rows (channels li and 32 + li)
+        const uint32_t sv0 = SDVAR_LDS_ADDR(att_sm + (t % ANST) * ASTAGE + NKP * APL) + voff0, sv1 = sv0 ^ 64u;     // V tile, channel halves db = 0 / 1
         f32x16 s;
 #pragma unroll
         for (int i = 0; i < 16; ++i) s[i] = 0.f;
@@ -153,14 +171,14 @@ __global__ __launch_bounds__(256, 2) void attention_f16x2_kernel(AttnHArgs a) {
             for (int p = 0; p < NKP; ++p) kf[p] = *reinterpret_cast<const f16x8*>(sk + p * APL + 8 * ((2 * c + lh) ^ swk));
             mfma_planes<NKP>(s, kf, qp[c]);
         }
-        // V^T fragments of the tile: issued now, consumed after the softmax arithmetic
+        // V^T fragments of the tile (two transposed 8-byte reads each: keys 16 j + 4 lh + {0..3} and + 8): issued now, consumed after the softmax arithmetic
         f16x8 vf[2][2][NKP];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int p = 0; p < NKP; ++p) {
-                vf[j][0][p] = *reinterpret_cast<const f16x8*>(sv + p * APL + 8 * ((2 * j + lh) ^ swv));
-                vf[j][1][p] = *reinterpret_cast<const f16x8*>(sv + p * APL + 1024 + 8 * ((2 * j + lh) ^ swv));
+                vf[j][0][p] = lds_read_tr8(sv0, j * 2048 + p * (APL * 2));
+                vf[j][1][p] = lds_read_tr8(sv1, j * 2048 + p * (APL * 2));
             }
         // ---- mask (only in tiles that reach past some query's visible keys; this lane holds keys k0 + (i&3) + 8*(i>>2) + 4*lh)
         if (__builtin_amdgcn_ballot_w64(k0 + AKT > vis_q) != 0) {

@@ -105,20 +105,46 @@ __device__ __forceinline__ void split2h(float x, uint16_t& h, uint16_t& l) {
     const _Float16 ll = (_Float16)(x - (float)hh);
     h = __builtin_bit_cast(uint16_t, hh); l = __builtin_bit_cast(uint16_t, ll);
 }
+// ---- the same split two / four values at a time, in packed instructions (v_cvt_pk_f16_f32, v_pk_add_f32): 2.5 vector instructions per value instead of ~11.
+// split2h_pk_raw does NO range handling: |x| <= 65504 or NaN only (a NaN flows through both conversions by itself; an inf would turn into inf - inf).
+typedef _Float16 f16x2p __attribute__((ext_vector_type(2)));
+typedef float f32x2p __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2h_pk_raw(float x0, float x1, uint32_t& h, uint32_t& l) {
+    const f32x2p v = {x0, x1};
+    const f16x2p hh = __builtin_convertvector(v, f16x2p);               // round to nearest even, as (_Float16)x
+    const f32x2p r = v - __builtin_convertvector(hh, f32x2p);
+    const f16x2p ll = __builtin_convertvector(r, f16x2p);
+    h = __builtin_bit_cast(uint32_t, hh); l = __builtin_bit_cast(uint32_t, ll);
+}
+// max(|a|, |b|, |c|) ignoring NaNs (v_max3_f32 with source modifiers: one instruction, no canonicalisation)
+__device__ __forceinline__ float absmax3(float a, float b, float c) {
+    float m;
+    asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(m) : "v"(a), "v"(b), "v"(c));
+    return m;
+}
+// Range handling for a whole wave at once: `m` = this lane's max |x| over the values it is about to split (NaNs ignored).  Almost always every lane is inside
+// the fp16 range and the clamp (4 instructions per value) is skipped by a wave-uniform branch; if ANY lane is outside, every lane clamps (finite values
+// saturate at +-65504, NaN stays NaN: clamp_f16_range).
+__device__ __forceinline__ bool wave_needs_clamp(float m) { return __builtin_amdgcn_ballot_w64(m > 65504.0f) != 0ull; }
+// four consecutive values -> the packed words of the two planes
+__device__ __forceinline__ void split4h_pk(const float* v, uint2& h, uint2& l) {
+    float c[4] = {v[0], v[1], v[2], v[3]};
+    if (wave_needs_clamp(fmaxf(absmax3(v[0], v[1], v[2]), fabsf(v[3])))) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) c[e] = clamp_f16_range(v[e]);
+    }
+    split2h_pk_raw(c[0], c[1], h.x, l.x); split2h_pk_raw(c[2], c[3], h.y, l.y);
+}
+
 // Output-plane format of the producers of GEMM operands (ln_modulate, attention, GELU epilogues): none, three bf16 planes, two fp16 planes
 enum { PLANES_NONE = 0, PLANES_F16X2 = 2, PLANES_BF16X3 = 3 };
 // four consecutive values of one row -> the packed 8-byte words of each plane, written at the K-blocked position
 __device__ __forceinline__ void store_planes4(uint16_t* outp, size_t ops, size_t o, const float* v, int fmt) {
     if (fmt == PLANES_F16X2) {
-        uint16_t q[2][4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) split2h(v[e], q[0][e], q[1][e]);
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            uint2 w;
-            w.x = (uint32_t)q[k][0] | ((uint32_t)q[k][1] << 16); w.y = (uint32_t)q[k][2] | ((uint32_t)q[k][3] << 16);
-            *reinterpret_cast<uint2*>(outp + k * ops + o) = w;
-        }
+        uint2 h, l;
+        split4h_pk(v, h, l);
+        *reinterpret_cast<uint2*>(outp + o) = h;
+        *reinterpret_cast<uint2*>(outp + ops + o) = l;
     } else {
         uint16_t q[3][4];
 #pragma unroll

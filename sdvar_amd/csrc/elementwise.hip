@@ -230,6 +230,83 @@ __global__ __launch_bounds__(256) void qk_norm_append_kernel(const float* __rest
     v_cache[c] = (KV)v;
 }
 
+// Formats 3 / 4 of the cache (attention_f16x2.hip: two fp16 planes per value, or ONE fp16 plane = the fp16 KV cache of BASELINE config P4): K planes AND V planes
+// [R][H][NP][Lp][64], one 128-byte row per position (the attention kernel takes its V^T fragments with ds_read_b64_tr_b16: no transposed copy, no LDS pass here).
+// Same arithmetic as qk_norm_append_kernel; format 3 holds the fp32 values to 2^-22, format 4 holds fp16(k), fp16(v) rounded to nearest even like torch's .half().
+// thread = (position, channel group of 8): the whole append is in flight at once with 16-byte loads (six per thread and slab); the q / k norms are an in-thread
+// sum of 8 squares + three shuffle steps inside the 8-lane group.  Used when the QKV launch was split along K (small M) - an unsplit launch finishes q, k, v in
+// its own epilogue (gemm_f16x2.hip HEPI_QKV) - and by the op-level tests.
+__global__ __launch_bounds__(256) void qk_norm_append_rows_kernel(const float* __restrict__ qkv, const float* __restrict__ scale_mul, float* __restrict__ q_out,
+                                                                  uint16_t* __restrict__ k_cache, uint16_t* __restrict__ v_cache, int R, int l, int H, int Lp, int pos0,
+                                                                  PendingSplitK pend, int fmt) {
+    const int NP = fmt == 3 ? 2 : 1;
+    const int tid = threadIdx.x, h = blockIdx.y, r = blockIdx.z;
+    const int t = blockIdx.x * 32 + (tid >> 3), cg = tid & 7;
+    const bool live = t < l;
+    const int C = H * 64;
+    const size_t ps = (size_t)Lp * 64;
+    const bool l2 = scale_mul != nullptr;            // attn_l2_norm=False: raw q (x 2^-5, the softmax scale) and raw k (basic_var.py:71-72)
+    const float sm = l2 ? expf(fminf(scale_mul[h], 4.605170249938965f)) : 0.03125f;
+    float q[8], k[8], v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) q[e] = k[e] = v[e] = 0.f;
+    auto add8 = [](float* d, const float* p) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { d[e] += a[e]; d[4 + e] += b[e]; }
+    };
+    if (live) {
+        const size_t o = ((size_t)r * l + t) * 3 * C + h * 64 + 8 * cg;
+        if (pend.ws) {             // qkv[row][col] = sum_s ws[s][row][col] + bias[col], slabs added in slice order, four slabs (24 16-byte loads) in flight at a time
+            const size_t slab = (size_t)R * l * 3 * C;
+            int s = 0;
+            for (; s + 3 < pend.split; s += 4) {
+                f32x4 tt[4][6];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int w = 0; w < 3; ++w) {
+                        const float* p = pend.ws + (size_t)(s + u) * slab + o + (size_t)w * C;
+                        tt[u][2 * w] = *reinterpret_cast<const f32x4*>(p); tt[u][2 * w + 1] = *reinterpret_cast<const f32x4*>(p + 4);
+                    }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        q[e] += tt[u][0][e]; q[4 + e] += tt[u][1][e]; k[e] += tt[u][2][e]; k[4 + e] += tt[u][3][e]; v[e] += tt[u][4][e]; v[4 + e] += tt[u][5][e];
+                    }
+            }
+            for (; s < pend.split; ++s) { const float* p = pend.ws + (size_t)s * slab + o; add8(q, p); add8(k, p + C); add8(v, p + 2 * C); }
+            add8(q, pend.bias + h * 64 + 8 * cg); add8(k, pend.bias + C + h * 64 + 8 * cg); add8(v, pend.bias + 2 * C + h * 64 + 8 * cg);
+        } else {
+            add8(q, qkv + o); add8(k, qkv + o + C); add8(v, qkv + o + 2 * C);
+        }
+    }
+    float sq = 0.f, sk = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sq += q[e] * q[e]; sk += k[e] * k[e]; }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) { sq += __shfl_xor(sq, o, 64); sk += __shfl_xor(sk, o, 64); }
+    if (!live) return;
+    const float qn = l2 ? fmaxf(sqrtf(sq), 1e-12f) : 1.0f, kn = l2 ? fmaxf(sqrtf(sk), 1e-12f) : 1.0f;
+    f32x4 q0, q1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { q0[e] = l2 ? (q[e] / qn) * sm : q[e] * sm; q1[e] = l2 ? (q[4 + e] / qn) * sm : q[4 + e] * sm; }
+    float* pq = q_out + (((size_t)r * H + h) * l + t) * 64 + 8 * cg;
+    *reinterpret_cast<f32x4*>(pq) = q0; *reinterpret_cast<f32x4*>(pq + 4) = q1;
+    const size_t row = ((size_t)r * H + h) * NP * ps + (size_t)(pos0 + t) * 64 + 8 * cg;
+    float kn8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) kn8[e] = l2 ? k[e] / kn : k[e];
+    uint2 h0, l0, h1, l1;
+    split4h_pk(kn8, h0, l0); split4h_pk(kn8 + 4, h1, l1);
+    *reinterpret_cast<u32x4*>(k_cache + row) = u32x4{h0.x, h0.y, h1.x, h1.y};
+    if (fmt == 3) *reinterpret_cast<u32x4*>(k_cache + row + ps) = u32x4{l0.x, l0.y, l1.x, l1.y};
+    split4h_pk(v, h0, l0); split4h_pk(v + 4, h1, l1);
+    *reinterpret_cast<u32x4*>(v_cache + row) = u32x4{h0.x, h0.y, h1.x, h1.y};
+    if (fmt == 3) *reinterpret_cast<u32x4*>(v_cache + row + ps) = u32x4{l0.x, l0.y, l1.x, l1.y};
+}
+
 // Formats 2 / 3 / 4 of the cache (attention_bf16x3.hip: three bf16 planes; attention_f16x2.hip: two fp16 planes, or ONE fp16 plane = the
 // fp16 KV cache of BASELINE config P4): K planes [R][H][NP][Lp][64] and V^T planes [R][H][NP][64][Lp] with bits 2 and 3 of the key
 // position swapped inside every block of 16 keys.  Same arithmetic as above; format 2 holds the fp32 values exactly, format 3 to
@@ -389,9 +466,10 @@ int qk_norm_append(const float* qkv, const float* scale_mul, float* q_out, void*
     SDVAR_CHECK_ARG(kv_f16 >= 0 && kv_f16 <= 4, "qk_norm_append: cache format %d (0 = fp32, 1 = fp16, 2 = bf16x3 planes, 3 = f16x2 planes, 4 = one fp16 plane)", kv_f16);
     if (kv_f16 >= 2) {
         SDVAR_CHECK_ARG(Lmax % 64 == 0, "qk_norm_append: the planes KV formats need Lmax %% 64 == 0 (got %d)", Lmax);
-        SDVAR_CHECK_ARG(!v_only || !pd.ws, "qk_norm_append: the v-only pass takes a finished qkv buffer");
-        hipLaunchKernelGGL(qk_norm_append_planes_kernel, dim3((unsigned)((pos0 + l + 31) / 32 - pos0 / 32), H, R), dim3(256), 0, stream, qkv, scale_mul, q_out, (uint16_t*)k_cache, (uint16_t*)v_cache, R, l, H, Lmax, pos0, pd, kv_f16, v_only);
-    } else if (v_only) { set_error("qk_norm_append: the v-only pass exists for the planes cache formats only"); return SDVAR_ERR_ARG;
+        SDVAR_CHECK_ARG(!v_only, "qk_norm_append: there is no v-only pass any more (an unsplit QKV launch finishes q, k and v in its epilogue)");
+        if (kv_f16 == 2) hipLaunchKernelGGL(qk_norm_append_planes_kernel, dim3((unsigned)((pos0 + l + 31) / 32 - pos0 / 32), H, R), dim3(256), 0, stream, qkv, scale_mul, q_out, (uint16_t*)k_cache, (uint16_t*)v_cache, R, l, H, Lmax, pos0, pd, kv_f16, 0);
+        else hipLaunchKernelGGL(qk_norm_append_rows_kernel, dim3((unsigned)((l + 31) / 32), H, R), dim3(256), 0, stream, qkv, scale_mul, q_out, (uint16_t*)k_cache, (uint16_t*)v_cache, R, l, H, Lmax, pos0, pd, kv_f16);
+    } else if (v_only) { set_error("qk_norm_append: there is no v-only pass"); return SDVAR_ERR_ARG;
     } else if (kv_f16) hipLaunchKernelGGL(qk_norm_append_kernel<__half>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, qkv, scale_mul, q_out, (__half*)k_cache, (__half*)v_cache, R, l, H, Lmax, pos0, pd);
     else hipLaunchKernelGGL(qk_norm_append_kernel<float>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, qkv, scale_mul, q_out, (float*)k_cache, (float*)v_cache, R, l, H, Lmax, pos0, pd);
     SDVAR_LAUNCH_CHECK();

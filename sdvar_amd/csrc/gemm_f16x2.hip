@@ -46,19 +46,20 @@ constexpr int HBN = 128;
 // relative on the result): libm's tanhf costs ~40 vector instructions per value and the epilogue of a 256 x 128 tile evaluates 64 of them per lane
 // with nothing to hide them under (12 us per round of workgroups at M = 4096, fc1)
 __device__ __forceinline__ float gelu_tanh_h(float x) {
-    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    const float u = k0 * (x + k1 * x * x * x);
-    const float e = __builtin_amdgcn_exp2f(u * -2.8853900817779268f);        // exp(-2u); +inf for very negative x: the quotient is then 0
+    // -2 u log2 e = x (C0 + C1 x^2), C0 = -2 log2(e) sqrt(2 / pi), C1 = 0.044715 C0: 7 vector instructions (mul, fma, mul, exp2, add, rcp, mul)
+    const float C0 = -2.3022081986f, C1 = -0.10294324f;
+    const float w = x * __builtin_fmaf(x * x, C1, C0);
+    const float e = __builtin_amdgcn_exp2f(w);                               // exp(-2u); +inf for very negative x: the quotient is then 0
     return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
 // HEPI_QKV (the unsplit QKV launch of a transformer block, N = 3 H 64): the q and k thirds leave the epilogue finished - bias, per-head L2 norm, q scale
-// (basic_var.py:101-109), q as fp32 (R, H, l, 64), k as planes of the KV cache at positions pos0 + t - and only v goes to `out` (fp32, bias added) for
-// qk_norm_append's v-only pass, which owns the transposed V^T layout.  Replaces the fp32 round trip of q and k through HBM and two thirds of
-// qk_norm_append's traffic (the launch is HBM bound from M = 1024).
+// (basic_var.py:101-109), q as fp32 (R, H, l, 64), k and v as planes of the KV cache at positions pos0 + t (both row-major [position][64]: the attention kernel
+// takes V^T fragments with ds_read_b64_tr_b16, so no transposed copy exists).  Nothing goes to `out`: the launch replaces qk_norm_append altogether
+// (round 2 still ran its v-only pass behind this epilogue for a transposed V^T cache layout).
 struct QkvEpi {
     const float* scale_mul;      // (H) or null: attn_l2_norm=False (q x 2^-5, raw k)
-    float* q_out; uint16_t* k_cache;
+    float* q_out; uint16_t* k_cache; uint16_t* v_cache;      // v_cache: planes [R][H][NP][Lp][64], row-major like K (attention_f16x2.hip reads V^T through ds_read_b64_tr_b16)
     int l, H, Lp, pos0, fmt;     // tokens per row of the CFG batch, heads, cache rows, first position, cache format (3: two fp16 planes, 4: one)
 };
 
@@ -124,20 +125,20 @@ __device__ __forceinline__ void qk_store_row(const GemmHArgs& a, const f32x16* v
                 for (int x = 0; x < 4; ++x) o[x] = l2 ? (v[j][4 * g + x] / nrm) * sm : v[j][4 * g + x] * sm;
                 *reinterpret_cast<f32x4*>(pq + 32 * j + 8 * g) = o;
             }
-    } else {
+    } else {                   // k (which 1: normalised) or v (which 2: as it is): planes of the cache at position pos0 + t
         const int NP = e.fmt == 3 ? 2 : 1;
         const size_t ps = (size_t)e.Lp * 64;
-        uint16_t* pk = e.k_cache + ((size_t)r * e.H + h) * NP * ps + (size_t)(e.pos0 + t) * 64 + cbase + 4 * lh;
+        const bool nk = l2 && which == 1;
+        uint16_t* pk = (which == 1 ? e.k_cache : e.v_cache) + ((size_t)r * e.H + h) * NP * ps + (size_t)(e.pos0 + t) * 64 + cbase + 4 * lh;
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                uint16_t hh[4], ll[4];
+                float kv[4];
 #pragma unroll
-                for (int x = 0; x < 4; ++x) split2h(l2 ? v[j][4 * g + x] / nrm : v[j][4 * g + x], hh[x], ll[x]);
+                for (int x = 0; x < 4; ++x) kv[x] = nk ? v[j][4 * g + x] / nrm : v[j][4 * g + x];
                 uint2 wh, wl;
-                wh.x = (uint32_t)hh[0] | ((uint32_t)hh[1] << 16); wh.y = (uint32_t)hh[2] | ((uint32_t)hh[3] << 16);
-                wl.x = (uint32_t)ll[0] | ((uint32_t)ll[1] << 16); wl.y = (uint32_t)ll[2] | ((uint32_t)ll[3] << 16);
+                split4h_pk(kv, wh, wl);
                 *reinterpret_cast<uint2*>(pk + 32 * j + 8 * g) = wh;
                 if (e.fmt == 3) *reinterpret_cast<uint2*>(pk + ps + 32 * j + 8 * g) = wl;
             }
@@ -173,21 +174,21 @@ __device__ __forceinline__ void h_store_tile(const GemmHArgs& a, float* outp, co
             continue;
         }
         f32x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[4 * g + e] * wsi;
-        if (EPI != HEPI_PARTIAL && a.bias) {
+        if (EPI != HEPI_PARTIAL && a.bias) {          // acc * 2^-S + bias: the product with a power of two is exact, so the fused form rounds like mul + add
             const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + n);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] + bv[e];
+            for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(acc[4 * g + e], wsi, bv[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[4 * g + e] * wsi;
         }
         if (EPI == HEPI_BIAS_GELU_PLANES) {
-            uint16_t h[4], l[4];
+            float gv[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) split2h(gelu_tanh_h(v[e]), h[e], l[e]);
-            const size_t o = kb_index(m, n, a.M);
+            for (int e = 0; e < 4; ++e) gv[e] = gelu_tanh_h(v[e]);
             uint2 wh, wl;
-            wh.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16); wh.y = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
-            wl.x = (uint32_t)l[0] | ((uint32_t)l[1] << 16); wl.y = (uint32_t)l[2] | ((uint32_t)l[3] << 16);
+            split4h_pk(gv, wh, wl);
+            const size_t o = kb_index(m, n, a.M);
             *reinterpret_cast<uint2*>(a.outp + o) = wh; *reinterpret_cast<uint2*>(a.outp + a.ops + o) = wl;
         } else {
             if (EPI == HEPI_GATED_RES) {
@@ -198,6 +199,52 @@ __device__ __forceinline__ void h_store_tile(const GemmHArgs& a, float* outp, co
             }
             *reinterpret_cast<f32x4*>(outp + (size_t)m * a.ldo + n) = v;
         }
+    }
+}
+
+// The same tile when the host has checked a.vec and the kernel that every one of the tile's 32 columns is inside N (true for all model shapes: N is a multiple
+// of the column tile): no per-group range checks or element-wise fallback, ONE index computation per tile (inside a 32-column tile the K-blocked plane offset and
+// the row-major offsets advance by 8 elements per register group), bias / gate / residual through three pointers.  The generic h_store_tile spent more
+// instructions on its branches and 64-bit index arithmetic than on the epilogue's arithmetic (8030 instructions per wave in the 256 x 256 kernel's GELU epilogue).
+template <int EPI>
+__device__ __forceinline__ void h_store_tile_fast(const GemmHArgs& a, float* outp, const f32x16& acc, float wsi, int m, int nb) {
+    if (m >= a.M) return;
+    const float* pb = (EPI != HEPI_PARTIAL && a.bias) ? a.bias + nb : nullptr;
+    if (EPI == HEPI_BIAS_GELU_PLANES) {
+        uint16_t* p0 = a.outp + kb_index(m, nb, a.M);
+        uint16_t* p1 = p0 + a.ops;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float gv[4];
+            const f32x4 bv = pb ? *reinterpret_cast<const f32x4*>(pb + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gv[e] = gelu_tanh_h(__builtin_fmaf(acc[4 * g + e], wsi, bv[e]));
+            uint2 wh, wl;
+            split4h_pk(gv, wh, wl);
+            *reinterpret_cast<uint2*>(p0 + 8 * g) = wh; *reinterpret_cast<uint2*>(p1 + 8 * g) = wl;
+        }
+        return;
+    }
+    float* po = outp + (size_t)m * a.ldo + nb;
+    const float* pr = (EPI == HEPI_GATED_RES) ? a.res + (size_t)m * a.ldres + nb : nullptr;
+    const float* pg = (EPI == HEPI_GATED_RES) ? a.gate + (size_t)(m / a.rows_per_gate) * a.gate_stride + nb : nullptr;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        f32x4 v;
+        if (pb) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(pb + 8 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(acc[4 * g + e], wsi, bv[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[4 * g + e] * wsi;
+        }
+        if (EPI == HEPI_GATED_RES) {
+            const f32x4 rv = *reinterpret_cast<const f32x4*>(pr + 8 * g), gt = *reinterpret_cast<const f32x4*>(pg + 8 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = rv[e] + v[e] * gt[e];
+        }
+        *reinterpret_cast<f32x4*>(po + 8 * g) = v;
     }
 }
 
@@ -360,9 +407,13 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_v2_kernel(GemmHArgs a) {
         // the 128 columns of a tile lie inside one of the q / k / v thirds (H 64 is a multiple of 128 or the launcher does not pick this epilogue); a head
         // is the 64 columns of the wave pair (wn, wn ^ 1): the row norms are exchanged through LDS (free: the ring's last reads are behind the barrier)
         const int Cq = a.qk.H * 64, which = n0 / Cq, nh = n0 - which * Cq + (wn >> 1) * 64, h = nh >> 6;
-        if (which == 2) {
+        if (which == 2) {          // v: bias added, straight into the cache planes (32 of the head's 64 channels per wave; no norm, nothing to exchange)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) h_store_tile<HEPI_BIAS>(a, a.out, acc[i], wsi, m0 + wm * 64 + i * 32 + li, n0 + wn * 32 + 4 * lh);
+            for (int i = 0; i < 2; ++i) {
+                f32x16 vv;
+                (void)qk_bias_sq(a, acc[i], vv, wsi, n0 + wn * 32 + 4 * lh);
+                qk_store_row<1>(a, &vv, 0.f, 2, h, m0 + wm * 64 + i * 32 + li, lh, (wn & 1) * 32);
+            }
         } else {
             float* ex = reinterpret_cast<float*>(hsm);           // [4 wn][128 rows]
             f32x16 v[2]; float sq[2];
@@ -382,8 +433,13 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_v2_kernel(GemmHArgs a) {
         }
     } else {
         float* outp = (EPI == HEPI_PARTIAL) ? a.out + (size_t)ks * a.M * a.ldo : a.out;
+        if (a.vec && n0 + HBN <= a.N) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) h_store_tile<EPI>(a, outp, acc[i], wsi, m0 + wm * 64 + i * 32 + li, n0 + wn * 32 + 4 * lh);
+            for (int i = 0; i < 2; ++i) h_store_tile_fast<EPI>(a, outp, acc[i], wsi, m0 + wm * 64 + i * 32 + li, n0 + wn * 32 + 4 * lh);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) h_store_tile<EPI>(a, outp, acc[i], wsi, m0 + wm * 64 + i * 32 + li, n0 + wn * 32 + 4 * lh);
+        }
     }
     if (a.stamps && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -489,7 +545,11 @@ __global__ __launch_bounds__(256) void gemm_f16x2_small_kernel(GemmHArgs a) {
         const int Cq = a.qk.H * 64, which = n0 / Cq, nh = n0 - which * Cq + (wave >> 1) * 64, h = nh >> 6;
         if (which == 2) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) h_store_tile<HEPI_BIAS>(a, a.out, acc[i], wsi, m0 + i * 32 + li, n0 + wave * 32 + 4 * lh);
+            for (int i = 0; i < TM; ++i) {
+                f32x16 vv;
+                (void)qk_bias_sq(a, acc[i], vv, wsi, n0 + wave * 32 + 4 * lh);
+                qk_store_row<1>(a, &vv, 0.f, 2, h, m0 + i * 32 + li, lh, (wave & 1) * 32);
+            }
         } else {
             float* ex = reinterpret_cast<float*>(hsm);           // [4 waves][BM rows]
             f32x16 v[TM]; float sq[TM];
@@ -509,8 +569,13 @@ __global__ __launch_bounds__(256) void gemm_f16x2_small_kernel(GemmHArgs a) {
         }
     } else {
         float* outp = (EPI == HEPI_PARTIAL) ? a.out + (size_t)ks * a.M * a.ldo : a.out;
+        if (a.vec && n0 + HBN <= a.N) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) h_store_tile<EPI>(a, outp, acc[i], wsi, m0 + i * 32 + li, n0 + wave * 32 + 4 * lh);
+            for (int i = 0; i < TM; ++i) h_store_tile_fast<EPI>(a, outp, acc[i], wsi, m0 + i * 32 + li, n0 + wave * 32 + 4 * lh);
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) h_store_tile<EPI>(a, outp, acc[i], wsi, m0 + i * 32 + li, n0 + wave * 32 + 4 * lh);
+        }
     }
     if (a.stamps && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -624,16 +689,11 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_v3_kernel(GemmHArgs a) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int m = m0 + wm * 64 + i * 32 + li;
-            if (which == 2) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) h_store_tile<HEPI_BIAS>(a, a.out, acc[i][j], wsi, m, n0 + wn * 64 + j * 32 + 4 * lh);
-            } else {
-                f32x16 v[2];
-                float sq = qk_bias_sq(a, acc[i][0], v[0], wsi, n0 + wn * 64 + 4 * lh);
-                sq += qk_bias_sq(a, acc[i][1], v[1], wsi, n0 + wn * 64 + 32 + 4 * lh);
-                sq += __shfl_xor(sq, 32, 64);
-                qk_store_row<2>(a, v, sq, which, h, m, lh, 0);
-            }
+            f32x16 v[2];
+            float sq = qk_bias_sq(a, acc[i][0], v[0], wsi, n0 + wn * 64 + 4 * lh);
+            sq += qk_bias_sq(a, acc[i][1], v[1], wsi, n0 + wn * 64 + 32 + 4 * lh);
+            if (which != 2) sq += __shfl_xor(sq, 32, 64);
+            qk_store_row<2>(a, v, sq, which, h, m, lh, 0);
         }
         return;
     }
@@ -653,9 +713,224 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_v3_kernel(GemmHArgs a) {
                 }
             continue;
         }
+        if (a.vec && n0 + HBN <= a.N) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) h_store_tile<EPI>(a, outp, acc[i][j], wsi, m0 + wm * 64 + i * 32 + li, n0 + wn * 64 + j * 32 + 4 * lh);
+            for (int i = 0; i < 2; ++i) h_store_tile_fast<EPI>(a, outp, acc[i][j], wsi, m0 + wm * 64 + i * 32 + li, n0 + wn * 64 + j * 32 + 4 * lh);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) h_store_tile<EPI>(a, outp, acc[i][j], wsi, m0 + wm * 64 + i * 32 + li, n0 + wn * 64 + j * 32 + 4 * lh);
+        }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 256 x 256 workgroup tile, 8 waves (2 x 4) of 128 (m) x 64 (n) outputs: the large-M kernel for the wide GEMMs (QKV, fc1, head).
+// Why: the 256 x 128 kernel pulls 48 KB per K-step through the CU for 24 MFMAs per wave (66 GB/s per CU at the rate it runs: the L2 -> LDS path of
+// every CU is busy), reads 0.67 fragments per MFMA, and both waves of a SIMD run the SAME program in phase - they stall on their fragment reads together
+// and then compete for the matrix pipe together.  Here a K-step moves 64 KB for 48 MFMAs per wave (a third less operand traffic per flop, 0.5 fragment reads
+// per MFMA) and the two waves of every SIMD alternate roles (MI355X_MICROARCH.md "Two waves per SIMD"; the structure of the guide's 256^2 template):
+//     slot:        0    1    2    3    4    5    6    7     (one K-step = 8 slots, an s_barrier between slots)
+//     waves 0-3:   L0   M0   L1   M1   L2   M2   L3   M3    (wm = 0: the upper 128 rows of the tile)
+//     waves 4-7:   M3'  L0   M0   L1   M1   L2   M2   L3    (wm = 1: one slot behind)
+//   Mp = 12 MFMAs on one quadrant (64 m x 32 n) of the wave's tile over the K-step's 32 k (3 plane products x 2 k16 x 2 row tiles);
+//   L0 = fragment reads X rows 0-63 (8 x b128) + W columns 0-31 (4), L1 = W columns 32-63 (4), L2 = X rows 64-127 (8) + the LDS-DMA of the W slab of
+//   K-step t+2 (4 instructions), L3 = the DMA of the X slab of K-step t+2 (4) + the counted vmcnt that retires K-step t+1.
+//   While one wave of a SIMD owns the matrix pipe the other one reads LDS / issues DMA, so neither waits for the other's kind of work.
+// LDS: 2 stages x 64 KB (X planes [2][256][32] then W planes [2][256][32], rows of 64 B, chunk swizzle of the other kernels).  A slab of stage t % 2 is
+// refilled (K-step t+2) as soon as its last reader is past its lgkmcnt(0) + barrier: W after slot 3, X after slot 5 - a whole K-step (64 KB per CU) is always in flight.
+constexpr int H4_STAGE = 2 * (256 + 256) * 32;          // fp16 elements per stage (64 KB)
+
+// VAR (DMA placement, A/B): 0 = 4 + 4 instructions in L2 / L3 (a whole K-step of lookahead); 1 = 2 per L segment (X of K-step t+1 in L0 / L1, W of t+2 in L2 / L3);
+// 2 = as 1 but issued inside the M segments, one instruction behind the 4th and the 8th MFMA
+template <int EPI, int VAR>
+__global__ __launch_bounds__(512, 2) void gemm_f16x2_v4_kernel(GemmHArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t hsm[];
+    constexpr int BM = 256, BN = 256;
+    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN, ntile = tiles_m * tiles_n;
+    const int ks = blockIdx.x / ntile;
+    const int lid = xcd_remap(blockIdx.x - ks * ntile, ntile);
+    const int G = 4, per_group = tiles_m * G;                   // an XCD's run of tile ids covers G column tiles x a run of row tiles
+    const int g = lid / per_group, rem = lid - g * per_group;
+    const int gw = min(G, tiles_n - g * G);
+    const int tm = rem / gw, tn = g * G + rem % gw;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int kt0 = ks * a.k_per_split;
+    const int nk = min(a.K / HBK - kt0, a.k_per_split);
+
+    // DMA: a slab (X or W of one K-step) = 2 planes x 16 row blocks of 16 rows (1 KB each) = 32 instructions, 4 per wave: wave w fills plane w / 4, rows 64 (w % 4) .. + 63
+    const int dpl = wave >> 2, drow0 = 64 * (wave & 3) + (lane >> 2);
+    const int dch = (lane & 3) ^ ((lane >> 4) & 3);             // chunk swizzle (row >> 2) & 3 of rows drow0 + 16 e: the same for every e
+    uint32_t vx[4], vw[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        vx[e] = (uint32_t)(min(m0 + drow0 + 16 * e, a.M - 1) * 32 + 8 * dch) * 2u;        // clamped: rows past the edge are never stored
+        vw[e] = (uint32_t)(min(n0 + drow0 + 16 * e, a.N - 1) * 32 + 8 * dch) * 2u;
+    }
+    const char* const bx = reinterpret_cast<const char*>(a.X + (size_t)kt0 * a.M * 32 + (size_t)dpl * a.xps);
+    const char* const bw = reinterpret_cast<const char*>(a.W + (size_t)kt0 * a.N * 32 + (size_t)dpl * a.wps);
+    const uint32_t lds0 = SDVAR_LDS_ADDR(hsm);
+    const uint32_t ldx = lds0 + (uint32_t)(dpl * 16384 + (64 * (wave & 3)) * 64), ldw = ldx + 32768u;      // byte address of this wave's first row block, stage 0
+    // instructions e0 .. e1-1 of this wave's share of the X / W slab of K-step t
+    auto issue_x = [&](int t, int e0, int e1) {
+        const char* src = bx + (size_t)t * a.M * 64;
+        const uint32_t dst = ldx + (uint32_t)(t & 1) * 65536u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (e >= e0 && e < e1) SDVAR_DMA16(vx[e], src, dst + 1024u * e);
+    };
+    auto issue_w = [&](int t, int e0, int e1) {
+        const char* src = bw + (size_t)t * a.N * 64;
+        const uint32_t dst = ldw + (uint32_t)(t & 1) * 65536u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (e >= e0 && e < e1) SDVAR_DMA16(vw[e], src, dst + 1024u * e);
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment read addresses (bytes, stage 0): row * 64 + 16 * ((2 s + lh) ^ ((li >> 2) & 3)); plane p at + 16384 p, 32-row tile i at + 2048 i
+    const int sw = (li >> 2) & 3;
+    const uint32_t ax0 = lds0 + (uint32_t)((wm * 128 + li) * 64 + 16 * ((0 + lh) ^ sw)), ax1 = lds0 + (uint32_t)((wm * 128 + li) * 64 + 16 * ((2 + lh) ^ sw));
+    const uint32_t aw0 = lds0 + 32768u + (uint32_t)((wn * 64 + li) * 64 + 16 * ((0 + lh) ^ sw)), aw1 = lds0 + 32768u + (uint32_t)((wn * 64 + li) * 64 + 16 * ((2 + lh) ^ sw));
+
+#ifdef SDVAR_V4_STAMPS
+    unsigned long long wsr[4] = {0, 0, 0, 0}, wsc[4] = {0, 0, 0, 0};        // s_memrealtime (100 MHz) / s_memtime (core clock) at entry, loop start, loop end, exit
+    wsr[0] = __builtin_amdgcn_s_memrealtime(); wsc[0] = __builtin_amdgcn_s_memtime();
+#endif
+    issue_w(0, 0, 4); issue_x(0, 0, 4);
+    if (VAR == 0) {
+        if (nk > 1) { issue_w(1, 0, 4); issue_x(1, 0, 4); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        if (nk > 1) { issue_w(1, 0, 4); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+#ifdef SDVAR_V4_STAMPS
+    wsr[1] = __builtin_amdgcn_s_memrealtime(); wsc[1] = __builtin_amdgcn_s_memtime();
+#endif
+    if (wm == 1) __builtin_amdgcn_s_barrier();                  // the lower half of the tile runs one slot behind (wave-uniform branch)
+
+    f16x8 fx[2][2][2], fw[2][2][2];                             // fx[row tile of the half][k16 step][plane], fw[column tile][k16 step][plane]
+#ifdef SDVAR_V4_STAMPS          // diagnostic build only: slot boundaries of K-step 8 of waves 0 and 4 of workgroup 0 -> a.stamps[16 (wave / 4) + k]
+    unsigned long long stm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define SDVAR_H4_STAMP(k) do { if (t == 8) stm[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SDVAR_H4_STAMP(k) do { } while (0)
+#endif
+#define SDVAR_H4_SLOT(k) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); SDVAR_H4_STAMP(k); __builtin_amdgcn_sched_barrier(0); } while (0)
+    // 12 MFMAs of one quadrant; DMA_A / DMA_B (VAR 2) are issued behind the 4th and the 8th
+#define SDVAR_H4_MFMA(I0, J, DMA_A, DMA_B)                                                                                          \
+    do {                                                                                                                            \
+        SDVAR_MFMA3(acc[(I0)][J], fx[0][0][0], fx[0][0][1], fw[J][0][0], fw[J][0][1]);                                              \
+        SDVAR_MFMA3(acc[(I0) + 1][J], fx[1][0][0], fx[1][0][1], fw[J][0][0], fw[J][0][1]);                                          \
+        __builtin_amdgcn_sched_barrier(0); if (VAR == 2) { DMA_A; } __builtin_amdgcn_sched_barrier(0);                               \
+        SDVAR_MFMA3(acc[(I0)][J], fx[0][1][0], fx[0][1][1], fw[J][1][0], fw[J][1][1]);                                              \
+        __builtin_amdgcn_sched_barrier(0); if (VAR == 2) { DMA_B; } __builtin_amdgcn_sched_barrier(0);                               \
+        SDVAR_MFMA3(acc[(I0) + 1][J], fx[1][1][0], fx[1][1][1], fw[J][1][0], fw[J][1][1]);                                          \
+    } while (0)
+#pragma unroll 1
+    for (int t = 0; t < nk; ++t) {
+        const uint32_t so = (uint32_t)(t & 1) * 65536u;
+        const uint32_t x0 = ax0 + so, x1 = ax1 + so, w0 = aw0 + so, w1 = aw1 + so;
+        const bool p1 = t + 1 < nk, p2 = t + 2 < nk;
+        SDVAR_H4_STAMP(0);
+        // ---- L0: X rows 0-63 of the wave's half, W columns 0-31
+        SDVAR_LDS_RDH(fx[0][0][0], x0, 0);     SDVAR_LDS_RDH(fx[0][0][1], x0, 16384); SDVAR_LDS_RDH(fw[0][0][0], w0, 0);     SDVAR_LDS_RDH(fw[0][0][1], w0, 16384);
+        SDVAR_LDS_RDH(fx[1][0][0], x0, 2048);  SDVAR_LDS_RDH(fx[1][0][1], x0, 18432); SDVAR_LDS_RDH(fx[0][1][0], x1, 0);     SDVAR_LDS_RDH(fx[0][1][1], x1, 16384);
+        SDVAR_LDS_RDH(fw[0][1][0], w1, 0);     SDVAR_LDS_RDH(fw[0][1][1], w1, 16384); SDVAR_LDS_RDH(fx[1][1][0], x1, 2048);  SDVAR_LDS_RDH(fx[1][1][1], x1, 18432);
+        if (VAR == 1 && p1) issue_x(t + 1, 0, 2);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SDVAR_H4_SLOT(1);
+        SDVAR_H4_MFMA(0, 0, if (p1) issue_x(t + 1, 0, 1), if (p1) issue_x(t + 1, 1, 2));                      // M0: rows 0-63 x columns 0-31
+        SDVAR_H4_SLOT(2);
+        // ---- L1: W columns 32-63
+        SDVAR_LDS_RDH(fw[1][0][0], w0, 2048);  SDVAR_LDS_RDH(fw[1][0][1], w0, 18432); SDVAR_LDS_RDH(fw[1][1][0], w1, 2048);  SDVAR_LDS_RDH(fw[1][1][1], w1, 18432);
+        if (VAR == 1 && p1) issue_x(t + 1, 2, 4);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SDVAR_H4_SLOT(3);
+        SDVAR_H4_MFMA(0, 1, if (p1) issue_x(t + 1, 2, 3), if (p1) issue_x(t + 1, 3, 4));                      // M1: rows 0-63 x columns 32-63
+        SDVAR_H4_SLOT(4);
+        // ---- L2: X rows 64-127; every wave is past its last read of this stage's W slab: refill it with K-step t + 2
+        SDVAR_LDS_RDH(fx[0][0][0], x0, 4096);  SDVAR_LDS_RDH(fx[0][0][1], x0, 20480); SDVAR_LDS_RDH(fx[1][0][0], x0, 6144);  SDVAR_LDS_RDH(fx[1][0][1], x0, 22528);
+        SDVAR_LDS_RDH(fx[0][1][0], x1, 4096);  SDVAR_LDS_RDH(fx[0][1][1], x1, 20480); SDVAR_LDS_RDH(fx[1][1][0], x1, 6144);  SDVAR_LDS_RDH(fx[1][1][1], x1, 22528);
+        if (VAR == 0 && p2) issue_w(t + 2, 0, 4);
+        if (VAR == 1 && p2) issue_w(t + 2, 0, 2);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SDVAR_H4_SLOT(5);
+        SDVAR_H4_MFMA(2, 1, if (p2) issue_w(t + 2, 0, 1), if (p2) issue_w(t + 2, 1, 2));                      // M2: rows 64-127 x columns 32-63
+        SDVAR_H4_SLOT(6);
+        // ---- L3: the X slab is free too (the other half's L2 was one slot ago); K-step t + 1 must have landed before anybody starts it
+        if (VAR == 0) {
+            if (p2) { issue_x(t + 2, 0, 4); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (VAR == 1) {
+            if (p2) { issue_w(t + 2, 2, 4); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {             // VAR 2: the last two W instructions of K-step t + 2 go out inside M3, behind this wait: in flight are W(t+2)[0..1] only
+            if (p2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        SDVAR_H4_SLOT(7);
+        SDVAR_H4_MFMA(2, 0, if (p2) issue_w(t + 2, 2, 3), if (p2) issue_w(t + 2, 3, 4));                      // M3: rows 64-127 x columns 0-31
+        SDVAR_H4_SLOT(8);
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();                  // matches the extra barrier of the late half
+#ifdef SDVAR_V4_STAMPS
+    wsr[2] = __builtin_amdgcn_s_memrealtime(); wsc[2] = __builtin_amdgcn_s_memtime();
+    if (a.stamps && blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4)) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) a.stamps[16 * (wave >> 2) + k] = stm[k];
+    }
+#endif
+#undef SDVAR_H4_MFMA
+#undef SDVAR_H4_SLOT
+#undef SDVAR_H4_STAMP
+
+    const float wsi = a.wsi ? *a.wsi : 1.0f;
+    if (EPI == HEPI_QKV) {             // a wave's 64 columns are one head of q, k or v (the thirds are multiples of 64 columns: decided per wave)
+        const int Cq = a.qk.H * 64, nw = n0 + wn * 64, which = nw / Cq, h = (nw - which * Cq) >> 6;
+        if (nw >= a.N) return;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wm * 128 + i * 32 + li;
+            f32x16 v[2];
+            float sq = qk_bias_sq(a, acc[i][0], v[0], wsi, nw + 4 * lh);
+            sq += qk_bias_sq(a, acc[i][1], v[1], wsi, nw + 32 + 4 * lh);
+            if (which != 2) sq += __shfl_xor(sq, 32, 64);
+            qk_store_row<2>(a, v, sq, which, h, m, lh, 0);
+        }
+        return;
+    }
+    float* outp = (EPI == HEPI_PARTIAL) ? a.out + (size_t)ks * a.M * a.ldo : a.out;
+    if (a.vec && n0 + BN <= a.N) {            // every model shape: aligned operands, N a multiple of the column tile
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) h_store_tile_fast<EPI>(a, outp, acc[i][j], wsi, m0 + wm * 128 + i * 32 + li, n0 + wn * 64 + j * 32 + 4 * lh);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) h_store_tile<EPI>(a, outp, acc[i][j], wsi, m0 + wm * 128 + i * 32 + li, n0 + wn * 64 + j * 32 + 4 * lh);
+    }
+#ifdef SDVAR_V4_STAMPS
+    if (a.stamps && lane == 0 && wave == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wsr[3] = __builtin_amdgcn_s_memrealtime(); wsc[3] = __builtin_amdgcn_s_memtime();
+        unsigned long long* o = a.stamps + 32 + (blockIdx.x == 0 ? 0 : 8);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { o[k] = wsr[k]; o[4 + k] = wsc[k]; }
+    }
+#endif
 }
 
 // out = epi( sum_s slab[s] + bias ) for the split-K path; the GELU variant writes planes
@@ -823,6 +1098,8 @@ float* splitk_workspace(size_t* floats);     // gemm.hip: the shared slab worksp
 #define CM_RED0 4000.0
 #define CM_REDBW 5000.0
 #define CM_DEFBW 2000.0     // bytes per cycle at which a deferring consumer (ln_modulate, qk_norm_append) reads the slabs: not fitted
+#define CM_K4 3120.0        // 256 x 256 kernel: cycles per K-step (48 MFMAs x 32 cycles x 2 waves per SIMD, + 1.5 %)
+#define CM_FIX4 50000.0     // ... and its prologue + epilogue + launch, in the units of the other tiles' costs (calibrated on M = 2704 / 4096 / 6800, profiles/r03_gemm_tile_ab.log)
 
 static int g_force_bm_h = 0, g_force_split_h = 0;
 void debug_set_gemm_cfg_h(int bm, int split) { g_force_bm_h = bm; g_force_split_h = split; }
@@ -876,6 +1153,14 @@ static void choose_cfg_h(int M, int N, int K, size_t ws_floats, int* bm_out, int
             }
         }
     }
+    // the 256 x 256 ping-pong kernel (bm code 512): its K loop runs at the matrix pipe's issue rate (3072 cycles per K-step for twice the tile, in-kernel stamps:
+    // tools/micro/gemm_v4_stamps.py) but it needs one workgroup per CU and whole rounds of 256 tiles; unsplit only
+    static const bool no_v4 = getenv("SDVAR_GEMM_NO_V4") != nullptr;       // A/B runs only
+    if (!no_v4 && N >= 256 && M > 512) {
+        const long tiles4 = (long)((M + 255) / 256) * ((N + 255) / 256), rounds = (tiles4 + 255) / 256;
+        const double cyc = rounds * (nkt * CM_K4 + CM_FIX4);
+        if (cyc < best) { best = cyc; bbm = 512; bs = 1; btail = 0; }
+    }
     *bm_out = bbm; *split_out = bs; *tail_out = btail;
 }
 
@@ -927,6 +1212,21 @@ static int launch_h3_kernel(const GemmHArgs& a, int grid, hipStream_t stream) {
     return SDVAR_OK;
 }
 
+static int g_h4_var = -1;          // DMA placement of the 256 x 256 kernel (SDVAR_GEMM_H4_VAR, A/B runs)
+template <int EPI>
+static int launch_h4_kernel(const GemmHArgs& a, int grid, hipStream_t stream) {
+    const size_t lds = 2 * (size_t)H4_STAGE * sizeof(uint16_t);      // 128 KB
+    if (g_h4_var < 0) { const char* e = getenv("SDVAR_GEMM_H4_VAR"); g_h4_var = e ? atoi(e) : 0; if (g_h4_var < 0 || g_h4_var > 2) g_h4_var = 0; }
+    static LdsOptIn opt_in;
+    SDVAR_LDS_OPT_IN(opt_in, lds, (const void*)gemm_f16x2_v4_kernel<EPI, 0>, (const void*)gemm_f16x2_v4_kernel<EPI, 1>, (const void*)gemm_f16x2_v4_kernel<EPI, 2>);
+    if (g_h4_var == 1) hipLaunchKernelGGL((gemm_f16x2_v4_kernel<EPI, 1>), dim3(grid), dim3(512), lds, stream, a);
+    else if (g_h4_var == 2) hipLaunchKernelGGL((gemm_f16x2_v4_kernel<EPI, 2>), dim3(grid), dim3(512), lds, stream, a);
+    else hipLaunchKernelGGL((gemm_f16x2_v4_kernel<EPI, 0>), dim3(grid), dim3(512), lds, stream, a);
+    SDVAR_LAUNCH_CHECK();
+    return SDVAR_OK;
+}
+void debug_set_h4_var(int v) { g_h4_var = v; }
+
 static int launch_reduce_h(const GemmHArgs& a, const float* ws, int split, int epi, hipStream_t stream) {
     const size_t total = (size_t)a.M * (a.N / 4);
     const int rgrid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
@@ -959,6 +1259,28 @@ static int launch_h3(GemmHArgs a, int epi, int split, hipStream_t stream) {
         case HEPI_BIAS: return launch_h3_kernel<HEPI_BIAS>(a, tiles, stream);
         case HEPI_BIAS_GELU_PLANES: return launch_h3_kernel<HEPI_BIAS_GELU_PLANES>(a, tiles, stream);
         default: return launch_h3_kernel<HEPI_GATED_RES>(a, tiles, stream);
+    }
+}
+
+static int launch_h4(GemmHArgs a, int epi, int split, hipStream_t stream) {
+    const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
+    const int nkt = a.K / HBK;
+    if (split > 1) {
+        size_t wsf = 0;
+        float* ws = splitk_workspace(&wsf);
+        if (!ws) return SDVAR_ERR_HIP;
+        GemmHArgs p = a;
+        p.out = ws; p.ldo = a.N; p.split = split; p.k_per_split = (nkt + split - 1) / split;
+        int rc = launch_h4_kernel<HEPI_PARTIAL>(p, tiles * split, stream);
+        if (rc) return rc;
+        if (g_defer_h) { *g_defer_h = split; return SDVAR_OK; }
+        return launch_reduce_h(a, ws, split, epi, stream);
+    }
+    a.split = 1; a.k_per_split = nkt;
+    switch (epi) {
+        case HEPI_BIAS: return launch_h4_kernel<HEPI_BIAS>(a, tiles, stream);
+        case HEPI_BIAS_GELU_PLANES: return launch_h4_kernel<HEPI_BIAS_GELU_PLANES>(a, tiles, stream);
+        default: return launch_h4_kernel<HEPI_GATED_RES>(a, tiles, stream);
     }
 }
 
@@ -1043,16 +1365,16 @@ static thread_local const QkvEpi* g_qkv_epi = nullptr;      // set by gemm_f16x2
 static thread_local int* g_qkv_fused = nullptr;
 
 // The QKV launch of a transformer block: as gemm_f16x2_nt(epi 0, out = the (M, 3 H 64) fp32 qkv buffer, defer), but when the launch comes out UNSPLIT the
-// q and k thirds are finished in the epilogue (QkvEpi) and *fused = 1: the caller then runs qk_norm_append's v-only pass.  Otherwise *fused = 0 and the
+// q, k and v are finished in the epilogue (QkvEpi) and *fused = 1: the caller runs no qk_norm_append at all.  Otherwise *fused = 0 and the
 // result is in `out` (or in the slabs, *defer > 0) as before.
 int gemm_f16x2_qkv(const uint16_t* X, size_t xps, const uint16_t* W, size_t wps, const float* wsi, const float* bias, float* out, int ldo, int M, int N, int K,
-                   const float* scale_mul, float* q_out, void* k_cache, int l, int H, int Lp, int pos0, int kv_fmt, int* defer, int* fused, hipStream_t stream) {
-    SDVAR_CHECK_ARG(fused && defer && q_out && k_cache && l > 0 && H > 0 && N == 3 * H * 64 && M % l == 0, "gemm_f16x2_qkv: bad arguments (M=%d N=%d l=%d H=%d)", M, N, l, H);
+                   const float* scale_mul, float* q_out, void* k_cache, void* v_cache, int l, int H, int Lp, int pos0, int kv_fmt, int* defer, int* fused, hipStream_t stream) {
+    SDVAR_CHECK_ARG(fused && defer && q_out && k_cache && v_cache && l > 0 && H > 0 && N == 3 * H * 64 && M % l == 0, "gemm_f16x2_qkv: bad arguments (M=%d N=%d l=%d H=%d)", M, N, l, H);
     *fused = 0;
     static const bool env_off = getenv("SDVAR_NO_QKV_FUSE") != nullptr;      // A/B runs
     const bool off = env_off || g_qkv_fuse_off;
-    const QkvEpi e{scale_mul, q_out, (uint16_t*)k_cache, l, H, Lp, pos0, kv_fmt};
-    const bool ok = !off && (kv_fmt == 3 || kv_fmt == 4) && (H * 64) % 128 == 0 && ((uintptr_t)q_out % 16) == 0 && ((uintptr_t)k_cache % 16) == 0 && Lp % 8 == 0;
+    const QkvEpi e{scale_mul, q_out, (uint16_t*)k_cache, (uint16_t*)v_cache, l, H, Lp, pos0, kv_fmt};
+    const bool ok = !off && (kv_fmt == 3 || kv_fmt == 4) && (H * 64) % 128 == 0 && ((uintptr_t)q_out % 16) == 0 && ((uintptr_t)k_cache % 16) == 0 && ((uintptr_t)v_cache % 16) == 0 && Lp % 8 == 0;
     g_qkv_epi = ok ? &e : nullptr; g_qkv_fused = fused;
     const int rc = gemm_f16x2_nt(X, xps, W, wps, wsi, bias, out, ldo, nullptr, 0, M, N, K, HEPI_BIAS, nullptr, 0, nullptr, 1, 0, defer, stream);
     g_qkv_epi = nullptr; g_qkv_fused = nullptr;
@@ -1077,7 +1399,7 @@ int gemm_f16x2_nt(const uint16_t* X, size_t xps, const uint16_t* W, size_t wps, 
 #else
     const int dbg = 0;
 #endif
-    GemmHArgs a{X, W, xps, wps, wsi, bias, out, outp, ops, res, gate, M, N, K, ldo, ldres, rows_per_gate > 0 ? rows_per_gate : 1, gate_stride, 1, K / HBK, 0, dbg, debug_get_gemm_stamps(), QkvEpi{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0}, 0, 0};
+    GemmHArgs a{X, W, xps, wps, wsi, bias, out, outp, ops, res, gate, M, N, K, ldo, ldres, rows_per_gate > 0 ? rows_per_gate : 1, gate_stride, 1, K / HBK, 0, dbg, debug_get_gemm_stamps(), QkvEpi{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0}, 0, 0};
     auto al16 = [](const void* q) { return ((uintptr_t)q % 16) == 0; };
     a.vec = N % 4 == 0 && al16(bias) && al16(out) && al16(outp) && al16(res) && al16(gate) && ldo % 4 == 0 && ops % 4 == 0 &&
             (epi != HEPI_GATED_RES || (ldres % 4 == 0 && gate_stride % 4 == 0));
@@ -1089,9 +1411,16 @@ int gemm_f16x2_nt(const uint16_t* X, size_t xps, const uint16_t* W, size_t wps, 
     const bool qkv = g_qkv_epi != nullptr && a.vec;
     choose_cfg_h(M, N, K, wsf, &bm, &split, &tail, !no_hybrid && !qkv, defer != nullptr);
     if (g_force_bm_h) { bm = g_force_bm_h; tail = 0; }
+    if (g_force_bm_h == 256 && g_force_split_h < 0) {        // test aid: force the hybrid tail split -split ways (where the shape has a partial last round)
+        const int tiles = ((M + 255) / 256) * ((N + HBN - 1) / HBN), remt = tiles % 256, nkt = K / HBK;
+        int ts = -g_force_split_h;
+        if (ts > nkt / 2) ts = nkt / 2;
+        const int kps = ts > 0 ? (nkt + ts - 1) / ts : nkt;
+        if (tiles > 256 && remt && !qkv && N % 4 == 0 && ts >= 2 && (nkt + kps - 1) / kps == ts && (size_t)ts * remt * (256 * 128) <= wsf) { tail = ts; split = 1; }
+    }
     static const bool trace = getenv("SDVAR_GEMM_TRACE") != nullptr;
     if (trace) fprintf(stderr, "[gemm_f16x2] M=%d N=%d K=%d epi=%d -> bm=%d split=%d tail=%d\n", M, N, K, epi, bm, split, tail);
-    if (g_force_split_h) {
+    if (g_force_split_h > 0) {
         split = g_force_split_h;
         const int nkt = K / HBK;
         if (split > nkt) split = nkt;
@@ -1103,11 +1432,13 @@ int gemm_f16x2_nt(const uint16_t* X, size_t xps, const uint16_t* W, size_t wps, 
     if (qkv && split == 1 && tail == 0) {
         a.qk = *g_qkv_epi; a.split = 1; a.k_per_split = K / HBK;
         *g_qkv_fused = 1;
+        if (bm == 512) return launch_h4_kernel<HEPI_QKV>(a, ((M + 255) / 256) * ((N + 255) / 256), stream);
         if (bm == 256) return launch_h3_kernel<HEPI_QKV>(a, ((M + 255) / 256) * ((N + HBN - 1) / HBN), stream);
         if (bm == 128) return launch_h2_kernel<HEPI_QKV>(a, ((M + 127) / 128) * ((N + HBN - 1) / HBN), stream);
         if (bm == 64) return launch_small_any<64, HEPI_QKV>(a, ((M + 63) / 64) * ((N + HBN - 1) / HBN), stream);
         return launch_small_any<32, HEPI_QKV>(a, ((M + 31) / 32) * ((N + HBN - 1) / HBN), stream);
     }
+    if (bm == 512) return launch_h4(a, epi, split, stream);
     if (bm == 256 && tail > 0) return launch_h3_hybrid(a, epi, tail, stream);
     if (bm == 256) return launch_h3(a, epi, split, stream);
     if (bm == 32) return launch_h<32>(a, epi, split, stream);
