@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SDVAR_ABI_VERSION 2
+#define SDVAR_ABI_VERSION 3      /* 3 (round 3): the f16-plane KV-cache formats 3 / 4 store V row-major like K; new debug entry points (guard, gemm cfg getter) */
 #define SDVAR_MAX_STAGES 16
 
 typedef struct sdvar_model sdvar_model_t;   /* one VAR transformer: weights (borrowed), KV cache, workspaces */
@@ -190,9 +190,15 @@ int sdvar_op_split_planes_f16(const float* x, uint16_t* planes, int32_t rows, in
 int sdvar_op_gemm_f16x2(const uint16_t* Xp, uint64_t x_plane_stride, const uint16_t* Wp, uint64_t w_plane_stride, const float* w_scale, const float* bias, float* out,
                         int32_t ldo, uint16_t* out_planes, uint64_t out_plane_stride, int32_t M, int32_t N, int32_t K, int32_t epilogue,
                         const float* res, int32_t ldres, const float* gate, int32_t rows_per_gate, int32_t gate_stride, void* stream);
+/* Single-operator entry points of the attention path (models/basic_var.py:101-117).  kv_f16 = cache format:
+ *   0  fp32   K, V (R, H, Lmax, 64)                    1  fp16, same shape (the reference's half-precision cache)
+ *   2  bf16x3 planes: K (R, H, 3, Lmax, 64), V^T (R, H, 3, 64, Lmax) with bits 2 and 3 of the key position swapped inside every 16 keys (attention_bf16x3.hip)
+ *   3  f16x2 planes:  K AND V (R, H, 2, Lmax, 64) fp16, high plane then low plane, one 128-byte row per position (gemm mode f16x2, the default)
+ *   4  one fp16 plane: K and V (R, H, 1, Lmax, 64) = the fp16 KV cache of BASELINE config P4 in the layout of format 3
+ * Formats 2-4 need Lmax % 64 == 0 and a zero-initialised cache (whole 32-key tiles are streamed; rows past the valid keys must be finite). */
 int sdvar_op_qk_norm_append(const float* qkv, const float* scale_mul, float* q_out, void* k_cache, void* v_cache, int32_t kv_f16, int32_t R,
                             int32_t l, int32_t H, int32_t Lmax, int32_t pos0, void* stream);
-/* q (R,H,l,64), caches (R,H,Lmax,64) fp32 or fp16 (kv_f16) with Ktot valid keys, out (R,l,H*64); queries >= qbeg[j] see keys < vis[j] */
+/* q (R,H,l,64), caches in format kv_f16 (above) with Ktot valid keys, out (R,l,H*64) fp32 or out_planes (K-blocked operand planes); queries >= qbeg[j] see keys < vis[j] */
 int sdvar_op_attention(const float* q, const void* k_cache, const void* v_cache, int32_t kv_f16, float* out, uint16_t* out_planes, uint64_t plane_stride,
                        int32_t plane_format, int32_t R, int32_t H, int32_t l, int32_t Lmax, int32_t Ktot, int32_t n_stages, const int32_t* qbeg /*host*/,
                        const int32_t* vis /*host*/, void* stream);

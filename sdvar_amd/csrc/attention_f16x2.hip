@@ -28,6 +28,8 @@
 
 namespace sdvar {
 
+unsigned long long* debug_get_gemm_stamps();      // gemm_bf16x3.hip: the diagnostic stamp buffer (SDVAR_ATT_STAMPS builds of the 8-wave kernel write slot times to it)
+
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
 typedef uint16_t u16x8 __attribute__((ext_vector_type(8)));
@@ -46,6 +48,7 @@ struct AttnHArgs {
     int n_chunk;
     int qbeg[ATTH_MAX_CHUNK + 1];
     int vis[ATTH_MAX_CHUNK];
+    unsigned long long* stamps;            // diagnostic builds only (-DSDVAR_ATT_STAMPS)
 };
 
 // eight consecutive values -> the two packed fp16x8 words (h = fp16(x), l = fp16(x - h)); values saturate at the fp16 range
@@ -78,6 +81,72 @@ __device__ __forceinline__ void mfma_planes(f32x16& acc, const f16x8* a, const f
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+// 16-byte LDS read through the compiler (counted in lgkmcnt by hipcc): addr = LDS byte address
+#define SDVAR_LDS_RDP(dst, addr) (dst) = *reinterpret_cast<const __attribute__((address_space(3))) f16x8*>((uintptr_t)(addr))
+
+// The vector-ALU part of one 32-key tile (both kernels): mask, online softmax with a DEFERRED running maximum, two-plane split of P.
+//   s      S^T accumulator of the tile: register i = key k0 + (i & 3) + 8 (i >> 2) + 4 lh of this lane's query
+//   M_run  reference maximum in log2 units; it follows a tile's maximum only when some query of the wave sees a score more than 2^ATT_DEFER above it
+//          (cdna_hip_programming.md T13): P <= 2^ATT_DEFER stays far inside the fp16 range of its high plane, and the O / l rescale (33 multiplies) leaves
+//          almost every tile.  Exact in exact arithmetic: O and l carry the same reference.
+//   pp     P^T operand planes of the two k16 steps
+constexpr float ATT_DEFER = 6.0f;
+__device__ __forceinline__ void softmax_tile(f32x16& s, int k0, int vis_q, int lh, float& M_run, float& l_run, f32x16& o0, f32x16& o1, f16x8 (&pp)[2][2]) {
+    const float L2E = 1.4426950408889634f;
+    if (__builtin_amdgcn_ballot_w64(k0 + AKT > vis_q) != 0) {            // only the tiles that reach past some query's visible keys: a real (wave-uniform) branch
+        asm volatile("" ::: "memory");                                   // ... the 32 compare / select instructions are not to be if-converted into every tile
+        const int d = vis_q - k0 - 4 * lh;                               // register i holds key k0 + (i & 3) + 8 (i >> 2) + 4 lh: masked from d on
+#pragma unroll
+        for (int i = 0; i < 16; ++i) if ((i & 3) + 8 * (i >> 2) >= d) s[i] = -INFINITY;
+    }
+    // The first maximum is the COMPILER's instruction: s comes straight out of the S^T MFMAs, and hipcc pads the matrix-pipe -> vector-ALU read hazard only for
+    // instructions it can see (cdna_hip_programming.md 5.7).  With the asm chain directly behind the MFMAs (the mask arithmetic that used to sit in between is a
+    // skipped branch now) some lanes read a not yet written accumulator for the maximum - harmless for the quotient (any reference works) but different from
+    // launch to launch by ~1e-7, and an overflow risk.  Every later read of s is ordered behind this one (same MFMA results).
+    float mloc = fmaxf(s[0], s[1]);
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mloc) : "v"(mloc), "v"(s[2]), "v"(s[3]));
+#pragma unroll
+    for (int i = 4; i < 16; i += 2) asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mloc) : "v"(mloc), "v"(s[i]), "v"(s[i + 1]));
+    {
+        const auto sw2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mloc), __float_as_uint(mloc), false, false);
+        mloc = fmaxf(__uint_as_float(sw2[0]), __uint_as_float(sw2[1]));
+    }
+    // deferred running maximum: moved (and O, l rescaled) only when some query of the wave sees a score more than 2^ATT_DEFER above its reference
+    const float mt = mloc * L2E;
+    if (__builtin_amdgcn_ballot_w64(mt > M_run + ATT_DEFER) != 0) {       // wave-uniform; always taken in tile 0 (M_run = -inf)
+        const float M_new = fmaxf(M_run, mt);
+        const float alpha = __builtin_amdgcn_exp2f(M_run - M_new);
+        M_run = M_new;
+        l_run *= alpha;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+    }
+    const f32x2 l2e2 = {L2E, L2E}, nM2 = {-M_run, -M_run};
+    f32x2 pr[8], ls2 = {0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const f32x2 x = __builtin_elementwise_fma(f32x2{s[2 * e], s[2 * e + 1]}, l2e2, nM2);
+        pr[e] = f32x2{__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+        ls2 += pr[e];
+    }
+    float lsum = ls2[0] + ls2[1];
+    {
+        const auto sw2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(lsum), __float_as_uint(lsum), false, false);
+        lsum = __uint_as_float(sw2[0]) + __uint_as_float(sw2[1]);
+    }
+    l_run += lsum;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        u32x4 ph, pl;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {                                    // p in [0, 2^ATT_DEFER]: inside the fp16 range, no clamp
+            uint32_t hw, lw;
+            split2h_pk_raw(pr[4 * j + e][0], pr[4 * j + e][1], hw, lw);
+            ph[e] = hw; pl[e] = lw;
+        }
+        pp[j][0] = __builtin_bit_cast(f16x8, ph); pp[j][1] = __builtin_bit_cast(f16x8, pl);
+    }
+}
 
 // The softmax / split arithmetic is written for instruction count (vector-ALU work does not hide under MFMAs on gfx950: see
 // attention_bf16x3.hip): packed fp32 ops on register pairs, v_max3, masking only in the tiles that straddle a visibility boundary.
@@ -148,7 +217,6 @@ __global__ __launch_bounds__(256, 2) void attention_f16x2_kernel(AttnHArgs a) {
     const int vq = (lane >> 2) & 3, vp = lane & 3, vcb = (lane >> 4) & 1;
     const uint32_t voff0 = (uint32_t)((4 * lh + vq) * 128 + (((vq >> 1) & 1) * 64) + vcb * 32 + vp * 8);       // db = 0; db = 1 is ^ 64
     const int ntiles = (kend + AKT - 1) / AKT;
-    const float L2E = 1.4426950408889634f;
     issue(0);
     if (ntiles > 1) issue(1);
     for (int t = 0; t < ntiles; ++t) {
@@ -180,54 +248,9 @@ __global__ __launch_bounds__(256, 2) void attention_f16x2_kernel(AttnHArgs a) {
                 vf[j][0][p] = lds_read_tr8(sv0, j * 2048 + p * (APL * 2));
                 vf[j][1][p] = lds_read_tr8(sv1, j * 2048 + p * (APL * 2));
             }
-        // ---- mask (only in tiles that reach past some query's visible keys; this lane holds keys k0 + (i&3) + 8*(i>>2) + 4*lh)
-        if (__builtin_amdgcn_ballot_w64(k0 + AKT > vis_q) != 0) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) if (k0 + (i & 3) + 8 * (i >> 2) + 4 * lh >= vis_q) s[i] = -INFINITY;
-        }
-        // ---- online softmax in log2 units: p = 2^(s log2e - M)
-        float mloc = s[0];                                      // scores are never NaN: plain v_max3_f32, no canonicalisation
-        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mloc) : "v"(s[0]), "v"(s[1]), "v"(s[2]));
-#pragma unroll
-        for (int i = 3; i < 15; i += 2) asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mloc) : "v"(mloc), "v"(s[i]), "v"(s[i + 1]));
-        asm("v_max_f32 %0, %1, %2" : "=v"(mloc) : "v"(mloc), "v"(s[15]));
-        {
-            const auto sw2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mloc), __float_as_uint(mloc), false, false);
-            mloc = fmaxf(__uint_as_float(sw2[0]), __uint_as_float(sw2[1]));                  // the other half of the query's keys
-        }
-        const float M_new = fmaxf(M_run, mloc * L2E);          // finite from the first tile on (key 0 is always visible)
-        const float alpha = __builtin_amdgcn_exp2f(M_run - M_new);
-        M_run = M_new;
-        const f32x2 l2e2 = {L2E, L2E}, nM2 = {-M_new, -M_new};
-        f32x2 pr[8], ls2 = {0.f, 0.f};
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const f32x2 x = __builtin_elementwise_fma(f32x2{s[2 * e], s[2 * e + 1]}, l2e2, nM2);      // v_pk_fma_f32
-            pr[e] = f32x2{__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
-            ls2 += pr[e];
-        }
-        float lsum = ls2[0] + ls2[1];
-        {
-            const auto sw2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(lsum), __float_as_uint(lsum), false, false);
-            lsum = __uint_as_float(sw2[0]) + __uint_as_float(sw2[1]);
-        }
-        l_run = l_run * alpha + lsum;
-        // ---- two-plane split of the probabilities, two at a time; pair e of step j = registers 8j + 2e, 8j + 2e + 1, which
-        // are k-slots 8lh + 2e, +1 of the MFMA, i.e. keys 16j + {0..3, 8..11} + 4lh - the permuted key order of the V^T rows
+        // ---- mask, online softmax (deferred running maximum), two-plane split of P
         f16x8 pp[2][2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const f32x2 x = pr[4 * j + e];                                   // p in [0, 1]: no saturation needed
-                const f16x2v hh = __builtin_convertvector(x, f16x2v);
-                const f32x2 rr = x - __builtin_convertvector(hh, f32x2);
-                const f16x2v ll = __builtin_convertvector(rr, f16x2v);
-                pp[j][0][2 * e] = hh[0]; pp[j][0][2 * e + 1] = hh[1];
-                pp[j][1][2 * e] = ll[0]; pp[j][1][2 * e + 1] = ll[1];
-            }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+        softmax_tile(s, k0, vis_q, lh, M_run, l_run, o0, o1, pp);
         // ---- O^T += V^T P^T
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -257,6 +280,206 @@ __global__ __launch_bounds__(256, 2) void attention_f16x2_kernel(AttnHArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same attention for MORE than 128 queries per (row, head) (stages 8 - 9 of the 256^2 ladder, every large verify chunk): ONE workgroup of 8 waves = 256
+// queries streams the (row, head) cache once (the 4-wave kernel above ran two workgroups over the same keys: 1.6x the algorithmic HBM traffic, measured), and
+// the two waves of every SIMD alternate between the matrix pipe and the vector ALU - the schedule of gemm_f16x2_v4_kernel (MI355X_MICROARCH.md "Two waves per
+// SIMD"): a 32-key tile costs a wave 12 + 12 MFMAs (768 matrix-pipe cycles) AND ~450 vector-ALU cycles of softmax / two-plane split, which one in-order wave
+// cannot overlap with its own MFMAs.
+//     slot (s_barrier between slots):   4t      4t+1    4t+2    4t+3
+//     waves 0-3:                        S(t)    V1(t)   PV(t)   V2(t)
+//     waves 4-7 (one slot behind):      V2(t-1) S(t)    V1(t)   PV(t)
+//   S(t)  = 12 MFMAs  S^T = K Q^T of tile t (K fragments already in registers)
+//   V1(t) = mask, online softmax (running maximum moved only when a score exceeds it by more than 2^6: cdna_hip_programming.md T13), two-plane split of P, O rescale
+//   PV(t) = 12 MFMAs  O^T += V^T P^T (V^T fragments already in registers)
+//   V2(t) = fragment reads of tile t+1 (K: 8 x b128, V^T: 16 x b64 transposed) + the LDS-DMA of tile t+3 into the stage tile t has just left
+// so in every slot one wave of a SIMD feeds the matrix pipe and the other one the vector ALU / LDS.  A tile is completely in registers after V2(t-1): the ring
+// (3 stages of 16 KB) holds three tiles in flight.  Tile t+1 must have landed before ANY wave reads it in slot 4t+3: every wave waits for its own share
+// (counted vmcnt) at the end of the slot before - PV(t) for the early half, V1(t) for the late half; the waits stand in both segments of both halves.
+constexpr int PP_NST = 3;
+
+template <int NKP>
+__global__ __launch_bounds__(512, 2) void attention_f16x2_pp_kernel(AttnHArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t att_sm[];
+    constexpr int ASTAGE = 2 * NKP * APL;         // one K tile + one V tile, NKP planes each
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int qt = blockIdx.x, h = blockIdx.y, r = blockIdx.z;
+    const int q0 = qt * 256;
+    const int late = wave >> 2;                                 // waves 4-7 run one slot behind
+
+    const int qi_raw = q0 + wave * 32 + li;
+    const int qi = min(qi_raw, a.l - 1);
+    int vis_q = a.vis[0];
+#pragma unroll 1
+    for (int j = 1; j < a.n_chunk; ++j) if (qi >= a.qbeg[j]) vis_q = a.vis[j];
+    const int q_last = min(q0 + 255, a.l - 1);
+    int kend = a.vis[0];
+#pragma unroll 1
+    for (int j = 1; j < a.n_chunk; ++j) if (q_last >= a.qbeg[j]) kend = a.vis[j];
+    const bool wave_active = (q0 + wave * 32) < a.l;            // wave-uniform: an inactive wave keeps every barrier and its share of the DMA, nothing else
+
+    f16x8 qp[4][2];
+    {
+        const float* pq = a.q + (((size_t)r * a.H + h) * a.l + qi) * 64 + 8 * lh;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float v[8];
+            const f32x4 u0 = *reinterpret_cast<const f32x4*>(pq + 16 * c), u1 = *reinterpret_cast<const f32x4*>(pq + 16 * c + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = u0[e]; v[4 + e] = u1[e]; }
+            split8h(v, qp[c][0], qp[c][1]);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { asm volatile("" : "+v"(qp[c][0]), "+v"(qp[c][1])); }      // finished HERE: hipcc would sink the split (and its vmcnt waits, which
+    }                                                                                            // drain the DMA queue too) to the first MFMA, behind the tile requests
+
+    // DMA: a tile = NKP K plane tiles + NKP V plane tiles of 32 rows x 128 B (4 instructions each); waves 0-3 bring K rows 8 w .. 8 w + 7 of every plane,
+    // waves 4-7 the V rows: NKP instructions per wave and tile
+    const size_t head = ((size_t)r * a.H + h) * NKP * (size_t)a.Lp * 64;
+    const size_t kps = (size_t)a.Lp * 64;
+    const int drow = 8 * (wave & 3) + (lane >> 3);
+    const int dchunk = (lane & 7) ^ (late ? 4 * ((drow >> 1) & 1) : ((drow >> 1) & 7));
+    const uint32_t ld = (uint32_t)(drow * 64 + 8 * dchunk) * 2u;
+    const char* const bsrc = reinterpret_cast<const char*>((late ? a.vc : a.kc) + head);
+    const uint32_t lds0 = SDVAR_LDS_ADDR(att_sm);
+    auto issue = [&](int t) {
+        const uint32_t st = lds0 + (uint32_t)((t % PP_NST) * ASTAGE + (late ? NKP * APL : 0) + (wave & 3) * 512) * 2u;
+#pragma unroll
+        for (int p = 0; p < NKP; ++p) SDVAR_DMA16(ld, bsrc + (p * kps + (size_t)t * AKT * 64) * 2, st + (uint32_t)(p * APL) * 2u);
+    };
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
+    float M_run = -INFINITY, l_run = 0.f;
+
+    const int swk = (li >> 1) & 7;
+    const int vq = (lane >> 2) & 3, vp = lane & 3, vcb = (lane >> 4) & 1;
+    const uint32_t koff = (uint32_t)(li * 128), voff0 = (uint32_t)(NKP * APL * 2 + (4 * lh + vq) * 128 + (((vq >> 1) & 1) * 64) + vcb * 32 + vp * 8);
+    const int ntiles = (kend + AKT - 1) / AKT;
+
+    f16x8 kf[4][NKP], vf[2][2][NKP];
+    auto read_tile = [&](int t) {               // K and V^T fragments of tile t -> registers
+        const uint32_t sb = lds0 + (uint32_t)((t % PP_NST) * ASTAGE) * 2u;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int p = 0; p < NKP; ++p) SDVAR_LDS_RDP(kf[c][p], sb + koff + (uint32_t)(p * APL * 2 + 16 * ((2 * c + lh) ^ swk)));
+        const uint32_t sv0 = sb + voff0, sv1 = sv0 ^ 64u;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int p = 0; p < NKP; ++p) {
+                vf[j][0][p] = lds_read_tr8(sv0, j * 2048 + p * (APL * 2));
+                vf[j][1][p] = lds_read_tr8(sv1, j * 2048 + p * (APL * 2));
+            }
+    };
+#define SDVAR_PP_SLOT() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#ifdef SDVAR_ATT_STAMPS          // slot boundaries of tile 10 (waves 0 and 4 of workgroup (0, 0, 0)) -> stamps[16 (wave / 4) + k]; kernel phases -> stamps[32 ..]
+    unsigned long long stm[5] = {0, 0, 0, 0, 0}, wsr[4] = {0, 0, 0, 0}, wsc[4] = {0, 0, 0, 0};
+    wsr[0] = __builtin_amdgcn_s_memrealtime(); wsc[0] = __builtin_amdgcn_s_memtime();
+#define SDVAR_PP_STAMP(k) do { if (t == 10) stm[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SDVAR_PP_STAMP(k) do { } while (0)
+#endif
+
+    const int npre = min(PP_NST, ntiles);
+    for (int t = 0; t < npre; ++t) issue(t);
+    // tile 0 landed: at most the other npre - 1 tiles (NKP instructions each) in flight
+    if (npre >= 3) { if (NKP == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+    else if (npre == 2) { if (NKP == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SDVAR_PP_SLOT();
+    if (late) SDVAR_PP_SLOT();                                  // wave-uniform
+    // V2(-1): fragments of tile 0
+    read_tile(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    SDVAR_PP_SLOT();
+
+#ifdef SDVAR_ATT_STAMPS
+    wsr[1] = __builtin_amdgcn_s_memrealtime(); wsc[1] = __builtin_amdgcn_s_memtime();
+#endif
+#pragma unroll 1
+    for (int t = 0; t < ntiles; ++t) {
+        const int k0 = t * AKT;
+        SDVAR_PP_STAMP(0);
+        // ---------------- S(t)
+        f32x16 s;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] = 0.f;
+        if (wave_active) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) mfma_planes<NKP>(s, kf[c], qp[c]);
+        }
+        SDVAR_PP_SLOT(); SDVAR_PP_STAMP(1);
+        // ---------------- V1(t)
+        f16x8 pp[2][2];
+        if (wave_active) {
+            softmax_tile(s, k0, vis_q, lh, M_run, l_run, o0, o1, pp);
+        }
+        if (t + 2 < ntiles) { if (NKP == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SDVAR_PP_SLOT(); SDVAR_PP_STAMP(2);
+        // ---------------- PV(t)
+        if (wave_active) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                mfma_planes<NKP>(o0, vf[j][0], pp[j]);
+                mfma_planes<NKP>(o1, vf[j][1], pp[j]);
+            }
+        }
+        if (t + 2 < ntiles) { if (NKP == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SDVAR_PP_SLOT(); SDVAR_PP_STAMP(3);
+        // ---------------- V2(t): tile t+1 into registers, tile t+3 into the stage tile t left one slot ago (both halves are past their reads of it)
+        if (t + 1 < ntiles) read_tile(t + 1);
+        if (t + PP_NST < ntiles) issue(t + PP_NST);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SDVAR_PP_SLOT(); SDVAR_PP_STAMP(4);
+    }
+    if (!late) SDVAR_PP_SLOT();                                 // matches the late half's extra slot
+#ifdef SDVAR_ATT_STAMPS
+    wsr[2] = __builtin_amdgcn_s_memrealtime(); wsc[2] = __builtin_amdgcn_s_memtime();
+#endif
+#undef SDVAR_PP_SLOT
+#undef SDVAR_PP_STAMP
+
+    if (wave_active && qi_raw < a.l) {
+        const float inv = 1.0f / l_run;
+        const size_t obase = ((size_t)r * a.l + qi_raw) * (a.H * 64) + h * 64 + 4 * lh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v0, v1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v0[e] = o0[4 * g + e] * inv; v1[e] = o1[4 * g + e] * inv; }
+            if (a.outp) {
+                const float u0[4] = {v0[0], v0[1], v0[2], v0[3]}, u1[4] = {v1[0], v1[1], v1[2], v1[3]};
+                const int orow = r * a.l + qi_raw, ocol = h * 64 + 4 * lh + 8 * g;
+                store_planes4(a.outp, a.ops, kb_index(orow, ocol, a.R * a.l), u0, a.pfmt);
+                store_planes4(a.outp, a.ops, kb_index(orow, ocol + 32, a.R * a.l), u1, a.pfmt);
+            } else {
+                *reinterpret_cast<f32x4*>(a.out + obase + 8 * g) = v0;
+                *reinterpret_cast<f32x4*>(a.out + obase + 32 + 8 * g) = v1;
+            }
+        }
+    }
+#ifdef SDVAR_ATT_STAMPS
+    if (a.stamps && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0 && (wave == 0 || wave == 4)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wsr[3] = __builtin_amdgcn_s_memrealtime(); wsc[3] = __builtin_amdgcn_s_memtime();
+#pragma unroll
+        for (int k = 0; k < 5; ++k) a.stamps[16 * (wave >> 2) + k] = stm[k];
+        if (wave == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { a.stamps[32 + k] = wsr[k]; a.stamps[36 + k] = wsc[k]; }
+        }
+    }
+#endif
+}
+
 // nkp: 2 = cache format 3 (two fp16 planes per value), 1 = cache format 4 (one fp16 plane: the fp16 KV cache)
 int attention_f16x2(const float* q, const void* kc, const void* vc, int nkp, float* out, uint16_t* outp, size_t ops, int pfmt, int R, int H, int l, int Lp,
                     int Ktot, int n_chunk, const int* qbeg, const int* vis, hipStream_t stream) {
@@ -273,7 +496,16 @@ int attention_f16x2(const float* q, const void* kc, const void* vc, int nkp, flo
         SDVAR_CHECK_ARG(vis[j] >= 1 && vis[j] <= Ktot && (j == 0 ? qbeg[0] == 0 : (qbeg[j] > qbeg[j - 1] && vis[j] >= vis[j - 1])), "attention: bad stage table at %d", j);
     }
     a.qbeg[n_chunk] = l;
+    a.stamps = debug_get_gemm_stamps();
     const size_t lds = ANST * (size_t)(2 * nkp * APL) * sizeof(uint16_t);       // 48 KB / 24 KB: under the 64 KB default limit
+    static const int pp_min = getenv("SDVAR_ATTN_PP_MIN") ? atoi(getenv("SDVAR_ATTN_PP_MIN")) : 129;      // A/B runs: queries per (row, head) from which the 8-wave kernel runs
+    if (l >= pp_min) {
+        const size_t ldp = PP_NST * (size_t)(2 * nkp * APL) * sizeof(uint16_t);
+        if (nkp == 2) hipLaunchKernelGGL(attention_f16x2_pp_kernel<2>, dim3((l + 255) / 256, H, R), dim3(512), ldp, stream, a);
+        else hipLaunchKernelGGL(attention_f16x2_pp_kernel<1>, dim3((l + 255) / 256, H, R), dim3(512), ldp, stream, a);
+        SDVAR_LAUNCH_CHECK();
+        return SDVAR_OK;
+    }
     if (nkp == 2) hipLaunchKernelGGL(attention_f16x2_kernel<2>, dim3((l + 127) / 128, H, R), dim3(256), lds, stream, a);
     else hipLaunchKernelGGL(attention_f16x2_kernel<1>, dim3((l + 127) / 128, H, R), dim3(256), lds, stream, a);
     SDVAR_LAUNCH_CHECK();

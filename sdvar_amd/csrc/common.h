@@ -111,10 +111,14 @@ typedef _Float16 f16x2p __attribute__((ext_vector_type(2)));
 typedef float f32x2p __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split2h_pk_raw(float x0, float x1, uint32_t& h, uint32_t& l) {
     const f32x2p v = {x0, x1};
-    const f16x2p hh = __builtin_convertvector(v, f16x2p);               // round to nearest even, as (_Float16)x
+    const f16x2p hh = __builtin_convertvector(v, f16x2p);               // v_cvt_pk_f16_f32: round to nearest even, as (_Float16)x
     const f32x2p r = v - __builtin_convertvector(hh, f32x2p);
     const f16x2p ll = __builtin_convertvector(r, f16x2p);
     h = __builtin_bit_cast(uint32_t, hh); l = __builtin_bit_cast(uint32_t, ll);
+    // (Tried in round 3: l by v_fma_mixlo_f16 / v_fma_mixhi_f16 in inline asm - h as an fp16 source, x as an fp32 source, one rounding: 3 instead of 5 instructions
+    //  per pair, bit-identical on 1 M random pairs incl. subnormal low planes, tools/micro/fma_mix_probe.hip.  Not used: hipcc pads no hazards around an asm
+    //  statement (cdna_hip_programming.md 5.7) and gfx950 has a transcendental-result and a partial-register-write forwarding hazard, both of which these two
+    //  instructions can meet wherever the scheduler puts them; the saving is ~2 issue slots per pair.)
 }
 // max(|a|, |b|, |c|) ignoring NaNs (v_max3_f32 with source modifiers: one instruction, no canonicalisation)
 __device__ __forceinline__ float absmax3(float a, float b, float c) {

@@ -251,7 +251,13 @@ __global__ __launch_bounds__(512, 2) void conv_bf16x3_kernel(ConvArgs a) {
 // work per K-step (30 MFMAs per wave), so the ring has three stages and keeps two K-steps of LDS-DMA in flight.
 //   stage = X planes [2][256][32] then W planes [2][160][32]; per K-step wave w issues X rows [32w, 32w+32) of both planes (4 instructions)
 //   and W rows [16w, 16w+16) (2), waves 0 and 1 also W rows [128 + 16w, ...) (2 more): the counted vmcnt wait is per wave.
-template <int EPI>
+// PP = 1 (default): the two waves of every SIMD alternate between the matrix pipe and LDS / DMA (the schedule of gemm_f16x2_v4_kernel): a K-step is
+//     slot:       4t     4t+1    4t+2    4t+3
+//     waves 0-3:  L0(t)  M0(t)   L1(t)   M1(t)        Ls = the 12 fragment reads of k16 step s + 4 of the 8 DMA slots of K-step t + 2
+//     waves 4-7:  M1(t-1) L0(t)  M0(t)   L1(t)        Ms = its 15 MFMAs (5 column tiles x 3 plane products)
+// with an s_barrier between slots.  K-step t + 1 is read from slot 4t + 4 on: every wave waits for its own share (counted vmcnt) at the end of slot 4t + 3.
+// PP = 0: the round-2 loop (one barrier per K-step, every wave reads, then multiplies).
+template <int EPI, int PP>
 __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint16_t csm[];
     const int tiles_m = (a.M + CBM - 1) / CBM, tiles_n = (a.N + CBN - 1) / CBN, ntile = tiles_m * tiles_n;
@@ -322,6 +328,64 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(ConvArgs a) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) issue_one(csm + CSTAGE_H, q);
     }
+    if (PP) {
+        const int late = __builtin_amdgcn_readfirstlane(wave >> 2);
+        auto wait_next = [&](int t) {          // K-step t + 1 landed: K-step t + 2 (8 instructions for waves 0-1, 6 for the others), if requested, may stay in flight
+            if (t + 2 < nk) { if (two_w) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+#define SDVAR_C_SLOT() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define SDVAR_LDS_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr) : "memory")
+#define SDVAR_RD_B(ab, p, pb) SDVAR_LDS_RD(fb[p][0], ab, pb); SDVAR_LDS_RD(fb[p][1], ab, pb + 2048); SDVAR_LDS_RD(fb[p][2], ab, pb + 4096); \
+                              SDVAR_LDS_RD(fb[p][3], ab, pb + 6144); SDVAR_LDS_RD(fb[p][4], ab, pb + 8192)
+#define SDVAR_C_MFMA()                                                                                  \
+        _Pragma("unroll") for (int j = 0; j < 5; ++j) {                                                 \
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[1], fb[0][j], acc[j], 0, 0, 0);          \
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0], fb[1][j], acc[j], 0, 0, 0);          \
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0], fb[0][j], acc[j], 0, 0, 0);          \
+        }
+        wait_next(-1);
+        SDVAR_C_SLOT();
+        if (late) SDVAR_C_SLOT();
+        f16x8 fa[2], fb[2][5];                  // [plane], [plane][column tile] of the current k16 step
+#pragma unroll 1
+        for (int t = 0; t < nk; ++t) {
+            const bool pf = t + 2 < nk;
+            uint16_t* nst = csm + ((t + 2) % 3) * CSTAGE_H;
+            const uint32_t sb = (uint32_t)(uintptr_t)(lds_ptr_t)(csm + (t % 3) * CSTAGE_H);
+            const uint32_t aa0 = sb + 2 * (offa + ch0), aa1 = sb + 2 * (offa + ch1), ab0 = sb + 2 * (offb + ch0), ab1 = sb + 2 * (offb + ch1);
+            // ---- L0(t)
+            SDVAR_LDS_RD(fa[0], aa0, 0); SDVAR_LDS_RD(fa[1], aa0, 16384);
+            SDVAR_RD_B(ab0, 0, 0); SDVAR_RD_B(ab0, 1, 10240);
+            if (pf) {
+                set_next();
+#pragma unroll
+                for (int q = 0; q < 4; ++q) issue_one(nst, q);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            SDVAR_C_SLOT();
+            SDVAR_C_MFMA();                      // M0(t)
+            SDVAR_C_SLOT();
+            // ---- L1(t)
+            SDVAR_LDS_RD(fa[0], aa1, 0); SDVAR_LDS_RD(fa[1], aa1, 16384);
+            SDVAR_RD_B(ab1, 0, 0); SDVAR_RD_B(ab1, 1, 10240);
+            if (pf) {
+#pragma unroll
+                for (int q = 4; q < 8; ++q) issue_one(nst, q);
+            }
+            if (late) wait_next(t);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            SDVAR_C_SLOT();
+            SDVAR_C_MFMA();                      // M1(t)
+            if (!late) wait_next(t);
+            SDVAR_C_SLOT();
+        }
+        if (!late) SDVAR_C_SLOT();
+#undef SDVAR_C_MFMA
+#undef SDVAR_RD_B
+#undef SDVAR_LDS_RD
+#undef SDVAR_C_SLOT
+    } else
     for (int t = 0; t < nk; ++t) {
         // K-step t has landed when only the newest K-step's instructions (8 for waves 0-1, 6 for the others) are still in flight
         if (t + 1 < nk) { if (two_w) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
@@ -493,13 +557,16 @@ int conv_planes(const uint16_t* X, size_t xps, size_t x_rows, int x_row0, const 
         a.k_per_split = kps; a.split = split;
     }
     const size_t lds = F16 ? 3 * (size_t)CSTAGE_H * sizeof(uint16_t) : 2 * (size_t)CSTAGE * sizeof(uint16_t);      // 156 KB either way
+    static const bool pp = !(getenv("SDVAR_CONV_PP") && atoi(getenv("SDVAR_CONV_PP")) == 0);          // A/B runs: SDVAR_CONV_PP=0 selects the round-2 loop
     static LdsOptIn opt_in, opt_in_h;
-    if (F16) SDVAR_LDS_OPT_IN(opt_in_h, lds, (const void*)conv_f16x2_kernel<CEPI_BIAS>, (const void*)conv_f16x2_kernel<CEPI_BIAS_RES>, (const void*)conv_f16x2_kernel<CEPI_PARTIAL>);
+    if (F16) SDVAR_LDS_OPT_IN(opt_in_h, lds, (const void*)conv_f16x2_kernel<CEPI_BIAS, 0>, (const void*)conv_f16x2_kernel<CEPI_BIAS_RES, 0>, (const void*)conv_f16x2_kernel<CEPI_PARTIAL, 0>,
+                              (const void*)conv_f16x2_kernel<CEPI_BIAS, 1>, (const void*)conv_f16x2_kernel<CEPI_BIAS_RES, 1>, (const void*)conv_f16x2_kernel<CEPI_PARTIAL, 1>);
     else SDVAR_LDS_OPT_IN(opt_in, lds, (const void*)conv_bf16x3_kernel<CEPI_BIAS>, (const void*)conv_bf16x3_kernel<CEPI_BIAS_RES>, (const void*)conv_bf16x3_kernel<CEPI_PARTIAL>);
     if (split > 1) {
         ConvArgs p = a;
         p.out = ws;
-        if (F16) hipLaunchKernelGGL((conv_f16x2_kernel<CEPI_PARTIAL>), dim3(tiles * split), dim3(512), lds, stream, p);
+        if (F16 && pp) hipLaunchKernelGGL((conv_f16x2_kernel<CEPI_PARTIAL, 1>), dim3(tiles * split), dim3(512), lds, stream, p);
+        else if (F16) hipLaunchKernelGGL((conv_f16x2_kernel<CEPI_PARTIAL, 0>), dim3(tiles * split), dim3(512), lds, stream, p);
         else hipLaunchKernelGGL((conv_bf16x3_kernel<CEPI_PARTIAL>), dim3(tiles * split), dim3(512), lds, stream, p);
         SDVAR_LAUNCH_CHECK();
         const size_t total = (size_t)M * (N / 4);
@@ -510,8 +577,10 @@ int conv_planes(const uint16_t* X, size_t xps, size_t x_rows, int x_row0, const 
     }
     if (gn_part && N % 32 == 0 && CBN % (N / 32) == 0 && (H * Wd) % CBM == 0) { a.gn_part = gn_part; a.cpg = N / 32; if (gn_done) *gn_done = 1; }
     if (F16) {
-        if (res) hipLaunchKernelGGL((conv_f16x2_kernel<CEPI_BIAS_RES>), dim3(tiles), dim3(512), lds, stream, a);
-        else hipLaunchKernelGGL((conv_f16x2_kernel<CEPI_BIAS>), dim3(tiles, up_phase >= 0 ? 4 : 1), dim3(512), lds, stream, a);
+        if (res && pp) hipLaunchKernelGGL((conv_f16x2_kernel<CEPI_BIAS_RES, 1>), dim3(tiles), dim3(512), lds, stream, a);
+        else if (res) hipLaunchKernelGGL((conv_f16x2_kernel<CEPI_BIAS_RES, 0>), dim3(tiles), dim3(512), lds, stream, a);
+        else if (pp) hipLaunchKernelGGL((conv_f16x2_kernel<CEPI_BIAS, 1>), dim3(tiles, up_phase >= 0 ? 4 : 1), dim3(512), lds, stream, a);
+        else hipLaunchKernelGGL((conv_f16x2_kernel<CEPI_BIAS, 0>), dim3(tiles, up_phase >= 0 ? 4 : 1), dim3(512), lds, stream, a);
     } else if (res) hipLaunchKernelGGL((conv_bf16x3_kernel<CEPI_BIAS_RES>), dim3(tiles), dim3(512), lds, stream, a);
     else hipLaunchKernelGGL((conv_bf16x3_kernel<CEPI_BIAS>), dim3(tiles, up_phase >= 0 ? 4 : 1), dim3(512), lds, stream, a);
     SDVAR_LAUNCH_CHECK();

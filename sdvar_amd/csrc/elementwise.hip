@@ -8,6 +8,7 @@
 //   build_lvl_pos      lvl_embed[lvl(t)] + pos_1LC[t]                               var.py:164
 //   embed_next         word_embed(next) + lvl_pos, written to both CFG rows of a (R, ltot, C) chunk input   var.py:186-188
 #include <hip/hip_fp16.h>
+#include <stdlib.h>
 
 #include "common.h"
 

@@ -359,6 +359,58 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_v2_kernel(GemmHArgs a) {
             if (more) read_half(t + 1, 1);
             __builtin_amdgcn_sched_barrier(0);
         }
+    } else if (NS == 6) {
+        // Ping-pong variant (template value 6 = "4 stages, the two waves of a SIMD alternate"): the schedule of gemm_f16x2_v4_kernel on this tile.  A K-step is one
+        // L segment (12 fragment reads + the 4 DMA instructions of K-step t + 3) and one M segment (12 MFMAs), an s_barrier between segments; waves 4-7 (wm = 1)
+        // run one segment behind, so in every slot one wave of a SIMD feeds the matrix pipe while the other reads LDS / issues DMA:
+        //     slot:       2t     2t+1    2t+2
+        //     waves 0-3:  L(t)   M(t)    L(t+1)
+        //     waves 4-7:  M(t-1) L(t)    M(t)
+        // Stage (t + 3) % 4 = (t - 1) % 4 is refilled in L(t): its last reader (the late half's L(t-1), slot 2t - 1) is past its lgkmcnt(0) + barrier.
+        // K-step t + 1 is read from slot 2t + 2 on: every wave waits for its own share (counted vmcnt: K-steps t + 2, t + 3 stay in flight) at the END of slot
+        // 2t + 1 - in M(t) for the early half, in L(t) for the late half - i.e. 4 - 5 slots (~2000 cycles) after it was requested.
+        f16x8 fa[2][2][2], fb[2][2];
+        const int late = __builtin_amdgcn_readfirstlane(wm);
+        auto issue4 = [&](int t) {
+            uint16_t* st = hsm + (t & 3) * H2_STAGE + swave * 512;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                SDVAR_DMA16(lx, bx + ((size_t)t * a.M * 32 + p * a.xps) * 2, SDVAR_LDS_ADDR(st + p * 4096));
+                SDVAR_DMA16(lw, bw + ((size_t)t * a.N * 32 + p * a.wps) * 2, SDVAR_LDS_ADDR(st + (2 + p) * 4096));
+            }
+        };
+        auto wait_next = [&](int t) {          // K-step t + 1 landed: the K-steps requested after it (at most two) may stay in flight
+            const int after = nk - t - 2;
+            if (after >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (after == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+#define SDVAR_H2_SLOT() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+        for (int tt = 0; tt < 3 && tt < nk; ++tt) issue4(tt);
+        wait_next(-1);
+        SDVAR_H2_SLOT();
+        if (late) SDVAR_H2_SLOT();
+#pragma unroll 1
+        for (int t = 0; t < nk; ++t) {
+            const uint32_t sb = (uint32_t)(uintptr_t)(lds_ptr_t)(hsm + (t & 3) * H2_STAGE);
+            const uint32_t aa0 = sb + 2 * (offa0 + ch0), aa1 = sb + 2 * (offa0 + ch1), ab0 = sb + 2 * (offb + ch0), ab1 = sb + 2 * (offb + ch1);
+            SDVAR_LDS_RDH(fa[0][1][0], aa0, 8192);  SDVAR_LDS_RDH(fb[0][0], ab0, 16384); SDVAR_LDS_RDH(fa[0][0][0], aa0, 0);
+            SDVAR_LDS_RDH(fb[0][1], ab0, 24576);    SDVAR_LDS_RDH(fa[0][1][1], aa0, 10240); SDVAR_LDS_RDH(fa[0][0][1], aa0, 2048);
+            SDVAR_LDS_RDH(fa[1][1][0], aa1, 8192);  SDVAR_LDS_RDH(fb[1][0], ab1, 16384); SDVAR_LDS_RDH(fa[1][0][0], aa1, 0);
+            SDVAR_LDS_RDH(fb[1][1], ab1, 24576);    SDVAR_LDS_RDH(fa[1][1][1], aa1, 10240); SDVAR_LDS_RDH(fa[1][0][1], aa1, 2048);
+            if (t + 3 < nk) issue4(t + 3);
+            if (late) wait_next(t);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            SDVAR_H2_SLOT();
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) { SDVAR_MFMA3(acc[i], fa[s2][0][i], fa[s2][1][i], fb[s2][0], fb[s2][1]); }
+            if (!late) wait_next(t);
+            SDVAR_H2_SLOT();
+        }
+        if (!late) SDVAR_H2_SLOT();
+#undef SDVAR_H2_SLOT
     } else {
     for (int tt = 0; tt < NS - 1 && tt < nk; ++tt) issue(tt);
     for (int t = 0; t < nk; ++t) {
@@ -1166,17 +1218,26 @@ static void choose_cfg_h(int M, int N, int K, size_t ws_floats, int* bm_out, int
 
 static thread_local int* g_defer_h = nullptr;     // set per call by gemm_bf16x3_nt; thread-local: host threads may drive different model objects concurrently
 
-static int g_h2_stages = -1;      // variant of the 128 x 128 kernel: 4 (default) = 3-stage ring with software-pipelined fragment reads (3-10 % faster than 3 on the shapes
+static int g_h2_stages = -1;      // variant of the 128 x 128 kernel: 6 (default, round 3) = 4-stage ring, the two waves of a SIMD alternate (1 - 7 % faster than 4: profiles/r03_l_v2pp_ab.log);
+                                   // 4 (round-2 default) = 3-stage ring with software-pipelined fragment reads (3-10 % faster than 3 on the shapes
                                    // that use this tile); 3 = 3-stage ring, reads in front of the MFMAs; 2 = 2-stage ring, two workgroups per CU (SDVAR_GEMM_H2_STAGES for A/B runs)
 
 template <int EPI>
 static int launch_h2_kernel(const GemmHArgs& a, int grid, hipStream_t stream) {
-    if (g_h2_stages < 0) { const char* e = getenv("SDVAR_GEMM_H2_STAGES"); g_h2_stages = (e && atoi(e) == 2) ? 2 : (e && atoi(e) == 3) ? 3 : (e && atoi(e) == 5) ? 5 : 4; }
+    if (g_h2_stages < 0) { const char* e = getenv("SDVAR_GEMM_H2_STAGES"); g_h2_stages = (e && atoi(e) == 2) ? 2 : (e && atoi(e) == 3) ? 3 : (e && atoi(e) == 5) ? 5 : (e && atoi(e) == 4) ? 4 : 6; }
     if (g_h2_stages == 5) {        // 5-stage ring (160 KB): four K-steps in flight
         const size_t lds = 5 * (size_t)H2_STAGE * sizeof(uint16_t);
         static LdsOptIn opt_in5;
         SDVAR_LDS_OPT_IN(opt_in5, lds, (const void*)gemm_f16x2_v2_kernel<EPI, 5>);
         hipLaunchKernelGGL((gemm_f16x2_v2_kernel<EPI, 5>), dim3(grid), dim3(512), lds, stream, a);
+        SDVAR_LAUNCH_CHECK();
+        return SDVAR_OK;
+    }
+    if (g_h2_stages == 6) {        // 4 stages (128 KB), ping-pong halves
+        const size_t lds = 4 * (size_t)H2_STAGE * sizeof(uint16_t);
+        static LdsOptIn opt_in6;
+        SDVAR_LDS_OPT_IN(opt_in6, lds, (const void*)gemm_f16x2_v2_kernel<EPI, 6>);
+        hipLaunchKernelGGL((gemm_f16x2_v2_kernel<EPI, 6>), dim3(grid), dim3(512), lds, stream, a);
         SDVAR_LAUNCH_CHECK();
         return SDVAR_OK;
     }

@@ -104,29 +104,35 @@ __global__ __launch_bounds__(256) void prep_planes_kernel(const float* __restric
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[e] = a0[e]; v[4 + e] = a1[e]; }
                 if (mode & 1) {
+                    const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + 8 * c8), g1 = *reinterpret_cast<const f32x4*>(gamma + 8 * c8 + 4);
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + 8 * c8), b1 = *reinterpret_cast<const f32x4*>(beta + 8 * c8 + 4);
+                    const float* st = stats + (size_t)b * 64;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const int c = 8 * c8 + e, g = c / cpg;
-                        const float mean = stats[((size_t)b * 32 + g) * 2], rstd = stats[((size_t)b * 32 + g) * 2 + 1];
-                        v[e] = ((v[e] - mean) * rstd) * gamma[c] + beta[c];
+                        const int g = (8 * c8 + e) / cpg;
+                        const f32x2p mr = *reinterpret_cast<const f32x2p*>(st + 2 * g);                 // {mean, rstd} of the group
+                        v[e] = ((v[e] - mr[0]) * mr[1]) * (e < 4 ? g0[e & 3] : g1[e & 3]) + (e < 4 ? b0[e & 3] : b1[e & 3]);
                     }
                 }
-                if (mode & 2) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = v[e] / (1.0f + expf(-v[e]));
+                if (mode & 2) {          // SiLU = x sigmoid(x) = x / (1 + 2^(-x log2 e)) on v_exp_f32 / v_rcp_f32 (1 ulp each), as the GELU of gemm_f16x2.hip: libm's expf and the
+#pragma unroll                          // IEEE division cost ~30 vector instructions per value in a kernel that moves 8 bytes per value
+                    for (int e = 0; e < 8; ++e) v[e] = v[e] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v[e] * -1.4426950408889634f));
                 }
             }
         }
         u32x4 a = {0, 0, 0, 0}, bq = {0, 0, 0, 0}, cq = {0, 0, 0, 0};
         const size_t o = ((size_t)(c8 >> 2) * R + r) * 32 + 8 * (c8 & 3);
         if (pfmt == PLANES_F16X2) {          // two fp16 planes (gemm_f16x2.hip): h = fp16(v), l = fp16(v - h)
-            if (live) {
+            if (live) {                   // packed split (common.h): finite values saturate, NaN stays NaN; the clamp itself only where a lane of the wave needs it
+                float m = fmaxf(absmax3(v[0], v[1], v[2]), absmax3(v[3], v[4], v[5]));
+                m = fmaxf(m, fmaxf(fabsf(v[6]), fabsf(v[7])));
+                const bool clampw = __builtin_amdgcn_ballot_w64(m > 65504.0f) != 0ull;          // among the live lanes of the wave
+                if (clampw) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    uint16_t h0, l0, h1, l1;
-                    split2h(v[2 * e], h0, l0); split2h(v[2 * e + 1], h1, l1);
-                    a[e] = (uint32_t)h0 | ((uint32_t)h1 << 16); bq[e] = (uint32_t)l0 | ((uint32_t)l1 << 16);
+                    for (int e = 0; e < 8; ++e) v[e] = clamp_f16_range(v[e]);
                 }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { uint32_t hw, lw; split2h_pk_raw(v[2 * e], v[2 * e + 1], hw, lw); a[e] = hw; bq[e] = lw; }
             }
             *reinterpret_cast<u32x4*>(outp + o) = a; *reinterpret_cast<u32x4*>(outp + ops + o) = bq;
             continue;

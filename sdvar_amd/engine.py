@@ -25,7 +25,7 @@ from .noise import exponential_noise
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsdvar_hip.so")
 MAX_STAGES = 16
-ABI_VERSION = 2
+ABI_VERSION = 3
 # GEMM arithmetic of the transformer blocks: 'f32' = fp32-in/fp32-accumulate MFMA; 'bf16x3' = exact 3-way bf16 split of both
 # operands, 6 bf16 MFMA products, fp32 accumulate (fp32-accurate, 2.67x the matrix-pipe throughput).  See DESIGN.md section 4.
 #   'f16x2' = two fp16 planes per operand (x ~ xh + xl to 2^-22), 3 fp16 MFMA products, fp32 accumulate: half the matrix work of bf16x3 at the same

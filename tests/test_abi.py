@@ -21,7 +21,7 @@ def test_header_symbols_exported_and_bound():
         assert hasattr(lib, s), f"{s} declared in include/sdvar_hip.h but not exported by libsdvar_hip.so"
         assert s in E._SIGNATURES, f"{s} has no ctypes prototype in sdvar_amd/engine.py"
     assert set(E._SIGNATURES) == set(syms)
-    assert lib.sdvar_abi_version() == E.ABI_VERSION == 2
+    assert lib.sdvar_abi_version() == E.ABI_VERSION == 3
 
 
 def test_argument_errors_are_reported_without_gpu():
