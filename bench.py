@@ -359,25 +359,33 @@ def main():
     def roof(name):
         c = classes[name]
         sec = c["ms"] * 1e-3
-        if name == "gemm":
+        if name in ("gemm", "gemm_small"):
             ach = c["flops"] / sec / 1e12            # algorithmic 2*M*N*K per launch / measured duration
             if tc.gemm_mode == "bf16x3":
                 peak = PEAK_BF16_MFMA_TFLOPS / 6.0   # 6 bf16 MFMA products per algorithmic fp32 product
                 kname, note = "gemm_bf16x3_{v3,v2,}_kernel", "peak = dense bf16 MFMA peak / 6 (split-operand products per fp32 product)"
             elif tc.gemm_mode == "f16x2":
                 peak = PEAK_BF16_MFMA_TFLOPS / 3.0   # 3 fp16 MFMA products per algorithmic fp32 product (f16 MFMA = bf16 MFMA rate)
-                kname, note = "gemm_f16x2_{v3,v2,small}_kernel", "peak = dense f16 MFMA peak / 3 (split-operand products per fp32 product)"
+                kname, note = "gemm_f16x2_{v4,v3,v2,small}_kernel", "peak = dense f16 MFMA peak / 3 (split-operand products per fp32 product)"
             else:
                 peak, kname, note = PEAK_F32_MFMA_TFLOPS, "gemm_f32_nt_kernel", "peak = fp32-in MFMA"
-            return dict(kernel=kname, bound="mfma", achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak, note=note,
+            regime = "launches with M >= 1024 rows (stages 6-9, large verify chunks): matrix-pipe regime" if name == "gemm" else \
+                     "launches with M < 1024 rows (stages 0-5, adaLN hoist): weight-streaming / launch-latency regime, priced against the same MFMA peak"
+            return dict(kernel=kname, bound="mfma", achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak, note=note, regime=regime,
                         vs_fp32_mfma_peak=ach / PEAK_F32_MFMA_TFLOPS,
-                        traffic=pmc.get("gemm", {}).get("hbm_bytes_per_launch"), algorithmic_bytes=c["bytes"] / c["launches"],
-                        launches=c["launches"], avg_us=c["ms"] * 1e3 / c["launches"])
+                        traffic=pmc.get(name, {}).get("hbm_bytes_per_launch"), algorithmic_bytes=c["bytes"] / c["launches"],
+                        launches=c["launches"], avg_us=c["ms"] * 1e3 / c["launches"],
+                        weight_stream_gbs=(c["bytes"] / (c["ms"] * 1e-3) / 1e9))
         ach = c["bytes"] / sec / 1e9
         return dict(kernel=name, bound="hbm", achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS,
                     traffic=pmc.get(name, {}).get("hbm_bytes_per_launch"), algorithmic_bytes=c["bytes"] / c["launches"],
                     launches=c["launches"], avg_us=c["ms"] * 1e3 / c["launches"], tflops=c["flops"] / sec / 1e12)
     roofline = roof(dom)
+    roofline_gemm_small = roof("gemm_small") if "gemm_small" in classes and dom != "gemm_small" else None
+    if "gemm" in classes and "gemm_small" in classes:          # the whole GEMM class as round 2 reported it (one average over every launch of the step)
+        ca, cb = classes["gemm"], classes["gemm_small"]
+        all_tf = (ca["flops"] + cb["flops"]) / ((ca["ms"] + cb["ms"]) * 1e-3) / 1e12
+        roofline["all_gemm_launches"] = dict(achieved=all_tf, frac=all_tf / roofline["peak"], launches=ca["launches"] + cb["launches"], ms=ca["ms"] + cb["ms"])
     # verify-attention by regime: launches with more than 36 queries per (row, head) are matrix/vector-pipe bound (fp32-accurate arithmetic:
     # 6 bf16 MFMA products per fp32 product), the short stages stream the cache once and are HBM / latency bound
     roofline_attn = None
@@ -419,7 +427,7 @@ def main():
         "per_rank_counters": dict(keys=list(D.COUNTER_KEYS), rows=agg["per_rank"], note="all-gathered over the process group (RCCL on the GPU box): one row per rank"),
         "images_per_s_no_decode": B * world * nd_steps / dt_nd,
         "decode_ms_per_batch": dec_ms, "decoder_tflops_algorithmic": dec_tflops, "decoder": "pytorch-miopen" if args.torch_decode else "hip (csrc/conv.hip, csrc/vae.hip)",
-        "modes": extra, "roofline_note": "roofline / kernel_class_ms_per_step come from one step with every kernel alone on the GPU (no draft/verify or decode overlap)", "roofline": roofline, "roofline_verify_attention": roofline_attn, "roofline_verify_attention_short_stages": roofline_attn_small, "kernel_class_ms_per_step": class_ms,
+        "modes": extra, "roofline_note": "roofline / kernel_class_ms_per_step come from one step with every kernel alone on the GPU (no draft/verify or decode overlap)", "roofline": roofline, "roofline_gemm_small_m": roofline_gemm_small, "roofline_verify_attention": roofline_attn, "roofline_verify_attention_short_stages": roofline_attn_small, "kernel_class_ms_per_step": class_ms,
     }
 
     # ---- CPU baseline (rank 0, N=1): the oracle's plain AR of the TARGET model on the host cores

@@ -239,8 +239,9 @@ int sdvar_debug_get_f16x2_guard(uint64_t* out4, int32_t reset);
 int sdvar_debug_set_gemm_stamps(uint64_t* stamps);
 
 /* ---- per-kernel-class timing with HIP events on the launch stream (bench.py roofline leg) ----------------------------- */
-#define SDVAR_PROF_CLASSES 9   /* 0 gemm, 1 attention with more than 36 queries per (row, head) (matrix-pipe bound), 2 ln_modulate, 3 qk_norm_append,
-                                  4 sampler, 5 verify, 6 quant, 7 embed/misc, 8 attention with <= 36 queries (stages 0-5: HBM / latency bound) */
+#define SDVAR_PROF_CLASSES 10  /* 0 gemm with M >= 1024 rows (matrix-pipe regime), 1 attention with more than 36 queries per (row, head) (matrix-pipe bound),
+                                  2 ln_modulate, 3 qk_norm_append, 4 sampler, 5 verify, 6 quant, 7 embed/misc, 8 attention with <= 36 queries (stages 0-5: HBM /
+                                  latency bound), 9 gemm with M < 1024 rows (stages 0-5, adaLN hoist: weight-streaming / launch-latency regime) */
 int sdvar_prof_enable(int32_t on);
 /* synchronises the recorded events and accumulates: ms, launches, algorithmic flops, algorithmic bytes per class */
 int sdvar_prof_collect(double* ms /*host[SDVAR_PROF_CLASSES]*/, int64_t* launches, double* flops, double* bytes);

@@ -361,17 +361,17 @@ int sdvar_model_begin(sdvar_model_t* m, int32_t B, const int64_t* labels, void* 
     }
     // adaLN parameters of every block: stage-invariant, computed once per call instead of once per stage
     if (m->shared_w) {          // shared_aln: one Linear for all blocks (var.py:192), each block adds its ada_gss (basic_var.py:153-154)
-        ProfScope ps(0, 2.0 * R * 6.0 * C * C, 4.0 * (6.0 * C * C + R * 7.0 * C), s);
+        ProfScope ps(9, 2.0 * R * 6.0 * C * C, 4.0 * (6.0 * C * C + R * 7.0 * C), s);
         SDVAR_TRY(gemm_f32_nt(m->cond_silu, C, m->shared_w, m->shared_b, m->gss_lin, 6 * C, R, 6 * C, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, s));
     }
     for (int i = 0; i < m->d.depth; ++i) {
-        ProfScope ps(0, 2.0 * R * 6.0 * C * C, 4.0 * (6.0 * C * C + R * 7.0 * C), s);
+        ProfScope ps(9, 2.0 * R * 6.0 * C * C, 4.0 * (6.0 * C * C + R * 7.0 * C), s);
         float* dst = m->ada + (size_t)i * m->Rmax * 6 * C;
         if (!m->blk[i].ada_w) SDVAR_TRY(add_row_vector(m->gss_lin, m->blk[i].ada_b, dst, R, 6 * C, s));
         else SDVAR_TRY(gemm_f32_nt(m->cond_silu, C, m->blk[i].ada_w, m->blk[i].ada_b, dst, 6 * C, R, 6 * C, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, s));
     }
     {
-        ProfScope ps(0, 2.0 * R * 2.0 * C * C, 4.0 * (2.0 * C * C + R * 3.0 * C), s);
+        ProfScope ps(9, 2.0 * R * 2.0 * C * C, 4.0 * (2.0 * C * C + R * 3.0 * C), s);
         SDVAR_TRY(gemm_f32_nt(m->cond_silu, C, m->nm_w, m->nm_b, m->ada_head, 2 * C, R, 2 * C, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, s));
     }
     m->begun = true;
@@ -441,6 +441,7 @@ static int stage_forward_impl(sdvar_model_t* m, float* x, int32_t s0, int32_t n,
     for (int j = 0; j < n; ++j) { qbeg[j] = lsum; lsum += m->lens[s0 + j]; vis[j] = m->cum[s0 + j] - m->kv_origin; lk += (double)m->lens[s0 + j] * vis[j]; }
     const int M = R * lsum, Ktot = m->kv_len + lsum;
     const double dM = M, dC = C;
+    const int GC = M >= 1024 ? 0 : 9;                                 // profiling class of this call's GEMMs: matrix-pipe regime / weight-streaming + latency regime
     const bool P = m->d.gemm_mode >= 1;                               // split-operand GEMMs: inputs travel as planes
     const int PF = m->d.gemm_mode == 2 ? PLANES_F16X2 : PLANES_BF16X3;
     const size_t ps = (size_t)M * C;                                  // plane stride of this call's (M, C) activations
@@ -469,7 +470,7 @@ static int stage_forward_impl(sdvar_model_t* m, float* x, int32_t s0, int32_t n,
         if (G2) SDVAR_TRY(guard_planes(m->xn_p, ps, s));
         PendingSplitK pq{nullptr, nullptr, nullptr, 0, 1, 0};
         int qk_fused = 0;        // the QKV launch came out unsplit and finished q, k and v in its epilogue (f16x2 planes cache): no qk_norm_append
-        if (!(skip & 16)) { ProfScope pp(0, 2 * dM * 3 * dC * dC, 4 * (dM * dC + 3 * dC * dC + 3 * dM * dC), s);
+        if (!(skip & 16)) { ProfScope pp(GC, 2 * dM * 3 * dC * dC, 4 * (dM * dC + 3 * dC * dC + 3 * dM * dC), s);
           if (P && m->d.gemm_mode == 2 && (m->kv_fmt == 3 || m->kv_fmt == 4)) {
                    SDVAR_TRY(gemm_f16x2_qkv(m->xn_p, ps, b.qkv_wp, (size_t)3 * C * C, b.wsc + 1, b.qkv_bias, m->qkv, 3 * C, M, 3 * C, C, b.scale_mul, m->qbuf, b.kc, b.vc, lsum, H, m->Lkv,
                                             m->kv_len, m->kv_fmt, dp, &qk_fused, s));
@@ -483,18 +484,18 @@ static int stage_forward_impl(sdvar_model_t* m, float* x, int32_t s0, int32_t n,
           if (bias) SDVAR_TRY(attention_masked(m->qbuf, b.kc, b.vc, m->kv_fmt, bias, m->att, P ? m->att_p : nullptr, ps, PF, R, H, lsum, m->Lkv, Ktot, s));
           else SDVAR_TRY(attention_f32(m->qbuf, b.kc, b.vc, m->kv_fmt, m->att, P ? m->att_p : nullptr, ps, PF, R, H, lsum, m->Lkv, Ktot, n, qbeg, vis, s)); }
         if (G2) SDVAR_TRY(guard_planes(m->att_p, ps, s));
-        if (!(skip & 32)) { ProfScope pp(0, 2 * dM * dC * dC, 4 * (3 * dM * dC + dC * dC), s);
+        if (!(skip & 32)) { ProfScope pp(GC, 2 * dM * dC * dC, 4 * (3 * dM * dC + dC * dC), s);
           if (P) { SDVAR_TRY(plane_gemm(m, m->att_p, ps, b.proj_wp, (size_t)C * C, b.wsc + 4, b.proj_b, x, C, nullptr, 0, M, C, C, EPI_GATED_RES, x, C, ada, lsum, 6 * C, dp, s));
                    if (defer) pend = PendingSplitK{ws, b.proj_b, ada, defer, lsum, 6 * C}; }
           else SDVAR_TRY(gemm_f32_nt(m->att, C, b.proj_w, b.proj_b, x, C, M, C, C, EPI_GATED_RES, x, C, ada, lsum, 6 * C, s)); }
         if (!(skip & 1)) { ProfScope pp(2, 8 * dM * dC, (P ? 10 : 8) * dM * dC, s);
           SDVAR_TRY(ln_modulate(x, ada + 3 * C, ada + 5 * C, m->xn, P ? m->xn_p : nullptr, ps, M, C, lsum, 6 * C, &pend, PF, s)); pend.ws = nullptr; }
         if (G2) SDVAR_TRY(guard_planes(m->xn_p, ps, s));
-        if (!(skip & 8)) { ProfScope pp(0, 2 * dM * 4 * dC * dC, 4 * (dM * dC + 4 * dC * dC + 4 * dM * dC), s);
+        if (!(skip & 8)) { ProfScope pp(GC, 2 * dM * 4 * dC * dC, 4 * (dM * dC + 4 * dC * dC + 4 * dM * dC), s);
           if (P) SDVAR_TRY(plane_gemm(m, m->xn_p, ps, b.fc1_wp, (size_t)4 * C * C, b.wsc + 8, b.fc1_b, nullptr, 0, m->hid_p, 4 * ps, M, 4 * C, C, EPI_BIAS_GELU, nullptr, 0, nullptr, 0, 0, nullptr, s));
           else SDVAR_TRY(gemm_f32_nt(m->xn, C, b.fc1_w, b.fc1_b, m->hid, 4 * C, M, 4 * C, C, EPI_BIAS_GELU, nullptr, 0, nullptr, 0, 0, s)); }
         if (G2) SDVAR_TRY(guard_planes(m->hid_p, 4 * ps, s));
-        if (!(skip & 64)) { ProfScope pp(0, 2 * dM * 4 * dC * dC, 4 * (4 * dM * dC + 4 * dC * dC + 2 * dM * dC), s);
+        if (!(skip & 64)) { ProfScope pp(GC, 2 * dM * 4 * dC * dC, 4 * (4 * dM * dC + 4 * dC * dC + 2 * dM * dC), s);
           if (P) { SDVAR_TRY(plane_gemm(m, m->hid_p, 4 * ps, b.fc2_wp, (size_t)4 * C * C, b.wsc + 12, b.fc2_b, x, C, nullptr, 0, M, C, 4 * C, EPI_GATED_RES, x, C, ada + C, lsum, 6 * C, dp, s));
                    if (defer) pend = PendingSplitK{ws, b.fc2_b, ada + C, defer, lsum, 6 * C}; }
           else SDVAR_TRY(gemm_f32_nt(m->hid, 4 * C, b.fc2_w, b.fc2_b, x, C, M, C, 4 * C, EPI_GATED_RES, x, C, ada + C, lsum, 6 * C, s)); }
@@ -502,7 +503,7 @@ static int stage_forward_impl(sdvar_model_t* m, float* x, int32_t s0, int32_t n,
     { ProfScope pp(2, 8 * dM * dC, (P ? 10 : 8) * dM * dC, s);      // also finishes the last block's fc2 residual when it was left split
       SDVAR_TRY(ln_modulate(x, m->ada_head, m->ada_head + C, m->xn, P ? m->xn_p : nullptr, ps, M, C, lsum, 2 * C, &pend, PF, s)); pend.ws = nullptr; }
     if (G2) SDVAR_TRY(guard_planes(m->xn_p, ps, s));
-    { ProfScope pp(0, 2 * dM * dC * V, 4 * (dM * dC + dC * V + dM * V), s);
+    { ProfScope pp(GC, 2 * dM * dC * V, 4 * (dM * dC + dC * V + dM * V), s);
       if (P) SDVAR_TRY(plane_gemm(m, m->xn_p, ps, m->head_wp, (size_t)V * C, m->head_wsc, m->head_b, logits, V, nullptr, 0, M, V, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, nullptr, s));
       else SDVAR_TRY(gemm_f32_nt(m->xn, C, m->head_w, m->head_b, logits, V, M, V, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, s)); }
     m->kv_len = Ktot;
@@ -516,12 +517,13 @@ int sdvar_head_forward(sdvar_model_t* m, const float* x, int32_t l, float* logit
     WsScope wsg(m->ws_own);
     const int C = m->C, R = 2 * m->B, V = m->d.vocab, M = R * l;
     const double dM = M, dC = C;
+    const int GC = M >= 1024 ? 0 : 9;
     const bool P = m->d.gemm_mode >= 1;
     const int PF = m->d.gemm_mode == 2 ? PLANES_F16X2 : PLANES_BF16X3;
     const size_t ps = (size_t)M * C;
     { ProfScope pp(2, 8 * dM * dC, (P ? 10 : 8) * dM * dC, s);
       SDVAR_TRY(ln_modulate(const_cast<float*>(x), m->ada_head, m->ada_head + C, m->xn, P ? m->xn_p : nullptr, ps, M, C, l, 2 * C, nullptr, PF, s)); }
-    { ProfScope pp(0, 2 * dM * dC * V, 4 * (dM * dC + dC * V + dM * V), s);
+    { ProfScope pp(GC, 2 * dM * dC * V, 4 * (dM * dC + dC * V + dM * V), s);
       if (P) SDVAR_TRY(plane_gemm(m, m->xn_p, ps, m->head_wp, (size_t)V * C, m->head_wsc, m->head_b, logits, V, nullptr, 0, M, V, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, nullptr, s));
       else SDVAR_TRY(gemm_f32_nt(m->xn, C, m->head_w, m->head_b, logits, V, M, V, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, s)); }
     return SDVAR_OK;
@@ -671,7 +673,7 @@ int sdvar_verify_accept(const float* logits, int32_t B, int32_t lsum, int32_t V,
 // ---------------------------------------------------------------------------------------------------- single ops
 int sdvar_op_gemm(const float* X, int32_t ldx, const float* W, const float* bias, float* out, int32_t ldo, int32_t M, int32_t N, int32_t K, int32_t epi,
                   const float* res, int32_t ldres, const float* gate, int32_t rows_per_gate, int32_t gate_stride, void* stream) {
-    ProfScope ps(0, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), (hipStream_t)stream);
+    ProfScope ps(M >= 1024 ? 0 : 9, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), (hipStream_t)stream);
     return gemm_f32_nt(X, ldx, W, bias, out, ldo, M, N, K, epi, res, ldres, gate, rows_per_gate, gate_stride, (hipStream_t)stream);
 }
 int sdvar_op_ln_modulate(const float* x, const float* scale, const float* shift, float* out, uint16_t* out_planes, uint64_t plane_stride, int32_t plane_format,
@@ -686,7 +688,7 @@ int sdvar_op_split_planes_f16(const float* x, uint16_t* planes, int32_t rows, in
 int sdvar_op_gemm_f16x2(const uint16_t* Xp, uint64_t x_plane_stride, const uint16_t* Wp, uint64_t w_plane_stride, const float* w_scale, const float* bias, float* out,
                         int32_t ldo, uint16_t* out_planes, uint64_t out_plane_stride, int32_t M, int32_t N, int32_t K, int32_t epi, const float* res, int32_t ldres,
                         const float* gate, int32_t rows_per_gate, int32_t gate_stride, void* stream) {
-    ProfScope ps(0, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), (hipStream_t)stream);
+    ProfScope ps(M >= 1024 ? 0 : 9, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), (hipStream_t)stream);
     return gemm_f16x2_nt(Xp, (size_t)x_plane_stride, Wp, (size_t)w_plane_stride, w_scale ? w_scale + 1 : nullptr, bias, out, ldo, out_planes, (size_t)out_plane_stride, M, N, K,
                          epi, res, ldres, gate, rows_per_gate, gate_stride, nullptr, (hipStream_t)stream);
 }
@@ -696,7 +698,7 @@ int sdvar_op_split_planes(const float* x, uint16_t* planes, int32_t rows, int32_
 int sdvar_op_gemm_bf16x3(const uint16_t* Xp, uint64_t x_plane_stride, const uint16_t* Wp, uint64_t w_plane_stride, const float* bias, float* out, int32_t ldo,
                          uint16_t* out_planes, uint64_t out_plane_stride, int32_t M, int32_t N, int32_t K, int32_t epi, const float* res, int32_t ldres,
                          const float* gate, int32_t rows_per_gate, int32_t gate_stride, void* stream) {
-    ProfScope ps(0, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), (hipStream_t)stream);
+    ProfScope ps(M >= 1024 ? 0 : 9, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), (hipStream_t)stream);
     return gemm_bf16x3_nt(Xp, (size_t)x_plane_stride, Wp, (size_t)w_plane_stride, bias, out, ldo, out_planes, (size_t)out_plane_stride, M, N, K, epi, res, ldres,
                           gate, rows_per_gate, gate_stride, nullptr, (hipStream_t)stream);
 }

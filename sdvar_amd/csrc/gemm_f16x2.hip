@@ -985,6 +985,385 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_v4_kernel(GemmHArgs a) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The 256 x 256 ping-pong kernel on v_mfma_f32_16x16x32_f16.  The K loop of gemm_f16x2_v4_kernel runs at the matrix pipe's issue rate and at the clock the chip
+// holds under that load (1.44 GHz with all 256 CUs busy: profiles/r03_d_gemm_v4_kernel_stamps.log), so the MFMA SHAPE is the in-loop lever left
+// (MI355X_MICROARCH.md "DVFS give-back" item 7): the same FLOPs issued as 16x16x32 run 14 % faster on random fp16 operands re-read from LDS
+// (tools/micro/mfma_shape_f16.hip, profiles/r03_o_mfma_shape_f16.log: 1704 against 1496 TFLOP/s, 2 waves per SIMD, every CU).
+// Same tile, waves, LDS image, DMA schedule and slot structure as v4 (VAR 0); what changes:
+//   fragments   one ds_read_b128 = 16 rows x 32 k (lane l: row l & 15, 16-byte chunk l >> 4 of the row's 64 bytes; the chunk swizzle permutes inside the row, a
+//               read covers 16 whole rows = 1 KB: conflict-free); X 8 row tiles, W 4 column tiles per wave; no k16 sub-steps
+//   products    acc[mt][nt] (f32x4) += Wh Xl + Wl Xh + Wh Xh with W as the A operand: D[n = 4 (l >> 4) + r][m = l & 15] - a lane holds four CONSECUTIVE columns
+//               of one row per tile, so every epilogue access is 16 bytes (fp32) / 8 bytes (a plane) as before
+//   slots       L0 = X tiles 0-3 (8 reads) + W tiles 0-1 (4); L1 = W tiles 2-3 (4); L2 = X tiles 4-7 (8) + DMA; L3 = DMA + vmcnt; Mq = 4 x 2 tiles x 3 = 24 MFMAs (384 cycles)
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+#define SDVAR_MFMA3_16(acc, xh, xl, wh, wl)                                            \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, acc, 0, 0, 0);                \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, acc, 0, 0, 0);                \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, acc, 0, 0, 0)
+
+// four consecutive columns n .. n + 3 of row m (16x16x32 accumulator group): every epilogue; a.vec and n + 3 < N checked by the caller for the 16-byte path
+template <int EPI>
+__device__ __forceinline__ void h_store4(const GemmHArgs& a, float* outp, const f32x4v& acc, float wsi, int m, int n, bool fast) {
+    if (m >= a.M || n >= a.N) return;
+    if (!fast) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (n + e < a.N) h_store<EPI>(a, outp, acc[e], wsi, (EPI != HEPI_PARTIAL && a.bias) ? a.bias[n + e] : 0.f, m, n + e);
+        return;
+    }
+    f32x4 v;
+    if (EPI != HEPI_PARTIAL && a.bias) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(acc[e], wsi, bv[e]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[e] * wsi;
+    }
+    if (EPI == HEPI_BIAS_GELU_PLANES) {
+        float gv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gv[e] = gelu_tanh_h(v[e]);
+        uint2 wh, wl;
+        split4h_pk(gv, wh, wl);
+        uint16_t* p0 = a.outp + kb_index(m, n, a.M);
+        *reinterpret_cast<uint2*>(p0) = wh; *reinterpret_cast<uint2*>(p0 + a.ops) = wl;
+        return;
+    }
+    if (EPI == HEPI_GATED_RES) {
+        const f32x4 rv = *reinterpret_cast<const f32x4*>(a.res + (size_t)m * a.ldres + n);
+        const f32x4 gt = *reinterpret_cast<const f32x4*>(a.gate + (size_t)(m / a.rows_per_gate) * a.gate_stride + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = rv[e] + v[e] * gt[e];
+    }
+    *reinterpret_cast<f32x4*>(outp + (size_t)m * a.ldo + n) = v;
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_f16x2_v5_kernel(GemmHArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t hsm[];
+    constexpr int BM = 256, BN = 256;
+    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN, ntile = tiles_m * tiles_n;
+    const int ks = blockIdx.x / ntile;
+    const int lid = xcd_remap(blockIdx.x - ks * ntile, ntile);
+    const int G = 4, per_group = tiles_m * G;
+    const int g = lid / per_group, rem = lid - g * per_group;
+    const int gw = min(G, tiles_n - g * G);
+    const int tm = rem / gw, tn = g * G + rem % gw;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int kt0 = ks * a.k_per_split;
+    const int nk = min(a.K / HBK - kt0, a.k_per_split);
+
+    // DMA: exactly as gemm_f16x2_v4_kernel
+    const int dpl = wave >> 2, drow0 = 64 * (wave & 3) + (lane >> 2);
+    const int dch = (lane & 3) ^ ((lane >> 4) & 3);
+    uint32_t vx[4], vw[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        vx[e] = (uint32_t)(min(m0 + drow0 + 16 * e, a.M - 1) * 32 + 8 * dch) * 2u;
+        vw[e] = (uint32_t)(min(n0 + drow0 + 16 * e, a.N - 1) * 32 + 8 * dch) * 2u;
+    }
+    const char* const bx = reinterpret_cast<const char*>(a.X + (size_t)kt0 * a.M * 32 + (size_t)dpl * a.xps);
+    const char* const bw = reinterpret_cast<const char*>(a.W + (size_t)kt0 * a.N * 32 + (size_t)dpl * a.wps);
+    const uint32_t lds0 = SDVAR_LDS_ADDR(hsm);
+    const uint32_t ldx = lds0 + (uint32_t)(dpl * 16384 + (64 * (wave & 3)) * 64), ldw = ldx + 32768u;
+    auto issue_x = [&](int t) {
+        const char* src = bx + (size_t)t * a.M * 64;
+        const uint32_t dst = ldx + (uint32_t)(t & 1) * 65536u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) SDVAR_DMA16(vx[e], src, dst + 1024u * e);
+    };
+    auto issue_w = [&](int t) {
+        const char* src = bw + (size_t)t * a.N * 64;
+        const uint32_t dst = ldw + (uint32_t)(t & 1) * 65536u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) SDVAR_DMA16(vw[e], src, dst + 1024u * e);
+    };
+
+    f32x4v acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+    // fragment read addresses (bytes, stage 0): row l15 of the 16-row tile, chunk lq swizzled by (row >> 2) & 3 = (l15 >> 2) & 3; plane p at + 16384 p, tile i at + 1024 i
+    const uint32_t fro = (uint32_t)(l15 * 64 + 16 * (lq ^ ((l15 >> 2) & 3)));
+    const uint32_t ax = lds0 + (uint32_t)(wm * 128 * 64) + fro, aw = lds0 + 32768u + (uint32_t)(wn * 64 * 64) + fro;
+
+    issue_w(0); issue_x(0);
+    if (nk > 1) { issue_w(1); issue_x(1); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();
+
+    f16x8 fx[4][2], fw[4][2];                                   // fx[row tile of the half][plane], fw[column tile][plane]
+#define SDVAR_H5_SLOT() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define SDVAR_H5_MFMA(I0, J0)                                                                                              \
+    do {                                                                                                                   \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                                   \
+            _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) { SDVAR_MFMA3_16(acc[(I0) + i_][(J0) + j_], fx[i_][0], fx[i_][1], fw[(J0) + j_][0], fw[(J0) + j_][1]); } \
+    } while (0)
+#pragma unroll 1
+    for (int t = 0; t < nk; ++t) {
+        const uint32_t so = (uint32_t)(t & 1) * 65536u;
+        const uint32_t x0 = ax + so, w0 = aw + so;
+        const bool p2 = t + 2 < nk;
+        // ---- L0: X row tiles 0-3 of the wave's half, W column tiles 0-1
+        SDVAR_LDS_RDH(fx[0][0], x0, 0);     SDVAR_LDS_RDH(fx[0][1], x0, 16384); SDVAR_LDS_RDH(fw[0][0], w0, 0);     SDVAR_LDS_RDH(fw[0][1], w0, 16384);
+        SDVAR_LDS_RDH(fx[1][0], x0, 1024);  SDVAR_LDS_RDH(fx[1][1], x0, 17408); SDVAR_LDS_RDH(fw[1][0], w0, 1024);  SDVAR_LDS_RDH(fw[1][1], w0, 17408);
+        SDVAR_LDS_RDH(fx[2][0], x0, 2048);  SDVAR_LDS_RDH(fx[2][1], x0, 18432); SDVAR_LDS_RDH(fx[3][0], x0, 3072);  SDVAR_LDS_RDH(fx[3][1], x0, 19456);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SDVAR_H5_SLOT();
+        SDVAR_H5_MFMA(0, 0);                                                                                  // M0: rows 0-63 x columns 0-31
+        SDVAR_H5_SLOT();
+        // ---- L1: W column tiles 2-3
+        SDVAR_LDS_RDH(fw[2][0], w0, 2048);  SDVAR_LDS_RDH(fw[2][1], w0, 18432); SDVAR_LDS_RDH(fw[3][0], w0, 3072);  SDVAR_LDS_RDH(fw[3][1], w0, 19456);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SDVAR_H5_SLOT();
+        SDVAR_H5_MFMA(0, 2);                                                                                  // M1: rows 0-63 x columns 32-63
+        SDVAR_H5_SLOT();
+        // ---- L2: X row tiles 4-7; the W slab of this stage is free: refill it with K-step t + 2
+        SDVAR_LDS_RDH(fx[0][0], x0, 4096);  SDVAR_LDS_RDH(fx[0][1], x0, 20480); SDVAR_LDS_RDH(fx[1][0], x0, 5120);  SDVAR_LDS_RDH(fx[1][1], x0, 21504);
+        SDVAR_LDS_RDH(fx[2][0], x0, 6144);  SDVAR_LDS_RDH(fx[2][1], x0, 22528); SDVAR_LDS_RDH(fx[3][0], x0, 7168);  SDVAR_LDS_RDH(fx[3][1], x0, 23552);
+        if (p2) issue_w(t + 2);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SDVAR_H5_SLOT();
+        SDVAR_H5_MFMA(4, 2);                                                                                  // M2: rows 64-127 x columns 32-63
+        SDVAR_H5_SLOT();
+        // ---- L3: the X slab is free too; K-step t + 1 must have landed before anybody starts it
+        if (p2) { issue_x(t + 2); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SDVAR_H5_SLOT();
+        SDVAR_H5_MFMA(4, 0);                                                                                  // M3: rows 64-127 x columns 0-31
+        SDVAR_H5_SLOT();
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();
+#undef SDVAR_H5_MFMA
+#undef SDVAR_H5_SLOT
+
+    const float wsi = a.wsi ? *a.wsi : 1.0f;
+    const int mrow = m0 + wm * 128 + l15, ncol = n0 + wn * 64 + 4 * lq;             // + 16 i (row tile), + 16 j (column tile)
+    if (EPI == HEPI_QKV) {             // a wave's 64 columns are one head of q, k or v; lane: row mrow + 16 i, columns 16 j + 4 lq + {0..3} of the head
+        const QkvEpi& e = a.qk;
+        const int Cq = e.H * 64, nw = n0 + wn * 64, which = nw / Cq, h = (nw - which * Cq) >> 6;
+        if (nw >= a.N) return;
+        const bool l2 = e.scale_mul != nullptr;
+        const float sm = (which == 0) ? (l2 ? expf(fminf(e.scale_mul[h], 4.605170249938965f)) : 0.03125f) : 1.0f;
+        const int NP = e.fmt == 3 ? 2 : 1;
+        const size_t ps = (size_t)e.Lp * 64;
+        f32x4 bv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[j] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + ncol + 16 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = mrow + 16 * i;
+            float v[4][4], sq = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int x = 0; x < 4; ++x) { v[j][x] = acc[i][j][x] * wsi + bv[j][x]; sq += v[j][x] * v[j][x]; }
+            if (which != 2 && l2) { sq += __shfl_xor(sq, 16, 64); sq += __shfl_xor(sq, 32, 64); }        // the head's 64 columns: 4 lane quarters x 16
+            if (m >= a.M) continue;
+            const float nrm = l2 ? fmaxf(sqrtf(sq), 1e-12f) : 1.0f;
+            const int r = m / e.l, tt = m - r * e.l;
+            if (which == 0) {
+                float* pq = e.q_out + (((size_t)r * e.H + h) * e.l + tt) * 64 + 4 * lq;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 o;
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) o[x] = l2 ? (v[j][x] / nrm) * sm : v[j][x] * sm;
+                    *reinterpret_cast<f32x4*>(pq + 16 * j) = o;
+                }
+            } else {
+                const bool nkk = l2 && which == 1;
+                uint16_t* pk = (which == 1 ? e.k_cache : e.v_cache) + ((size_t)r * e.H + h) * NP * ps + (size_t)(e.pos0 + tt) * 64 + 4 * lq;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float kv[4];
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) kv[x] = nkk ? v[j][x] / nrm : v[j][x];
+                    uint2 wh, wl;
+                    split4h_pk(kv, wh, wl);
+                    *reinterpret_cast<uint2*>(pk + 16 * j) = wh;
+                    if (e.fmt == 3) *reinterpret_cast<uint2*>(pk + ps + 16 * j) = wl;
+                }
+            }
+        }
+        return;
+    }
+    float* outp = (EPI == HEPI_PARTIAL) ? a.out + (size_t)ks * a.M * a.ldo : a.out;
+    const bool fast = a.vec && n0 + BN <= a.N;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) h_store4<EPI>(a, outp, acc[i][j], wsi, mrow + 16 * i, ncol + 16 * j, fast);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The 128 x 128 ping-pong kernel (gemm_f16x2_v2_kernel<EPI, 6>) on v_mfma_f32_16x16x32_f16: same tile, waves (2 x 4 of 64 x 32 outputs), 4-stage LDS image, DMA and
+// slot schedule; fragments, accumulators and epilogue addressing as gemm_f16x2_v5_kernel (a lane holds row l & 15 of every 16-row tile, columns 4 (l >> 4) .. + 3 of
+// every 16-column tile).  Per K-step a wave reads 4 X + 2 W tiles x 2 planes (12 x b128) and issues 4 x 2 x 3 = 24 MFMAs (384 matrix-pipe cycles).
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_f16x2_v6_kernel(GemmHArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t hsm[];
+    constexpr int BM = 128;
+    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + HBN - 1) / HBN, ntile = tiles_m * tiles_n;
+    const int ks = blockIdx.x / ntile;
+    const int lid = xcd_remap(blockIdx.x - ks * ntile, ntile);
+    const int G = 8, per_group = tiles_m * G;
+    const int g = lid / per_group, rem = lid - g * per_group;
+    const int gw = min(G, tiles_n - g * G);
+    const int tm = rem / gw, tn = g * G + rem % gw;
+    const int m0 = tm * BM, n0 = tn * HBN;
+
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
+    const int swave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = swave >> 2, wn = swave & 3;
+    const int drow = 16 * swave + (lane >> 2);
+    const int dchunk = (lane & 3) ^ ((drow >> 2) & 3);
+    const int xrow = min(m0 + drow, a.M - 1), wrow = min(n0 + drow, a.N - 1);
+    const int kt0 = ks * a.k_per_split;
+    const int nk = min(a.K / HBK - kt0, a.k_per_split);
+    const uint32_t lx = (uint32_t)(xrow * 32 + 8 * dchunk) * 2u, lw = (uint32_t)(wrow * 32 + 8 * dchunk) * 2u;
+    const char* const bx = reinterpret_cast<const char*>(a.X + (size_t)kt0 * a.M * 32);
+    const char* const bw = reinterpret_cast<const char*>(a.W + (size_t)kt0 * a.N * 32);
+    auto issue4 = [&](int t) {
+        uint16_t* st = hsm + (t & 3) * H2_STAGE + swave * 512;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            SDVAR_DMA16(lx, bx + ((size_t)t * a.M * 32 + p * a.xps) * 2, SDVAR_LDS_ADDR(st + p * 4096));
+            SDVAR_DMA16(lw, bw + ((size_t)t * a.N * 32 + p * a.wps) * 2, SDVAR_LDS_ADDR(st + (2 + p) * 4096));
+        }
+    };
+    auto wait_next = [&](int t) {
+        const int after = nk - t - 2;
+        if (after >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (after == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+
+    f32x4v acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+    // stage = X planes h, l [128][64 B] at 0 / 8192, W planes at 16384 / 24576 (bytes); fragment = row l15 of a 16-row tile, chunk lq swizzled by (l15 >> 2) & 3
+    const uint32_t fro = (uint32_t)(l15 * 64 + 16 * (lq ^ ((l15 >> 2) & 3)));
+    const uint32_t lds0 = SDVAR_LDS_ADDR(hsm);
+    const uint32_t ax = lds0 + (uint32_t)(wm * 64 * 64) + fro, aw = lds0 + 16384u + (uint32_t)(wn * 32 * 64) + fro;
+    const int late = wm;
+#define SDVAR_H6_SLOT() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+    for (int tt = 0; tt < 3 && tt < nk; ++tt) issue4(tt);
+    wait_next(-1);
+    SDVAR_H6_SLOT();
+    if (late) SDVAR_H6_SLOT();
+    f16x8 fx[4][2], fw[2][2];
+#pragma unroll 1
+    for (int t = 0; t < nk; ++t) {
+        const uint32_t so = (uint32_t)(t & 3) * (uint32_t)(H2_STAGE * 2);
+        const uint32_t x0 = ax + so, w0 = aw + so;
+        SDVAR_LDS_RDH(fx[0][0], x0, 0);     SDVAR_LDS_RDH(fx[0][1], x0, 8192);  SDVAR_LDS_RDH(fw[0][0], w0, 0);     SDVAR_LDS_RDH(fw[0][1], w0, 8192);
+        SDVAR_LDS_RDH(fx[1][0], x0, 1024);  SDVAR_LDS_RDH(fx[1][1], x0, 9216);  SDVAR_LDS_RDH(fw[1][0], w0, 1024);  SDVAR_LDS_RDH(fw[1][1], w0, 9216);
+        SDVAR_LDS_RDH(fx[2][0], x0, 2048);  SDVAR_LDS_RDH(fx[2][1], x0, 10240); SDVAR_LDS_RDH(fx[3][0], x0, 3072);  SDVAR_LDS_RDH(fx[3][1], x0, 11264);
+        if (t + 3 < nk) issue4(t + 3);
+        if (late) wait_next(t);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SDVAR_H6_SLOT();
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { SDVAR_MFMA3_16(acc[i][j], fx[i][0], fx[i][1], fw[j][0], fw[j][1]); }
+        if (!late) wait_next(t);
+        SDVAR_H6_SLOT();
+    }
+    if (!late) SDVAR_H6_SLOT();
+
+    const float wsi = a.wsi ? *a.wsi : 1.0f;
+    const int mrow = m0 + wm * 64 + l15, ncol = n0 + wn * 32 + 4 * lq;              // + 16 i, + 16 j
+    if (EPI == HEPI_QKV) {             // the wave's 32 columns are half a head: the row norms of the wave pair (wn, wn ^ 1) are exchanged through LDS
+        const QkvEpi& e = a.qk;
+        const int Cq = e.H * 64, which = n0 / Cq, nh = n0 - which * Cq + (wn >> 1) * 64, h = nh >> 6, cbase = (wn & 1) * 32;
+        const bool l2 = e.scale_mul != nullptr;
+        const int NP = e.fmt == 3 ? 2 : 1;
+        const size_t ps = (size_t)e.Lp * 64;
+        f32x4 bv[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bv[j] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + ncol + 16 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+        float v[4][2][4], sq[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            sq[i] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int x = 0; x < 4; ++x) { v[i][j][x] = acc[i][j][x] * wsi + bv[j][x]; sq[i] += v[i][j][x] * v[i][j][x]; }
+        }
+        if (which != 2 && l2) {
+            float* ex = reinterpret_cast<float*>(hsm);           // [4 wn][128 rows]; the ring's last reads are behind the final barrier of the loop
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sq[i] += __shfl_xor(sq[i], 16, 64); sq[i] += __shfl_xor(sq[i], 32, 64);
+                if (lq == 0) ex[wn * 128 + wm * 64 + 16 * i + l15] = sq[i];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float other = ex[(wn ^ 1) * 128 + wm * 64 + 16 * i + l15];
+                sq[i] = (wn & 1) ? other + sq[i] : sq[i] + other;               // lower half of the head first in both waves
+            }
+        }
+        const float sm = (which == 0) ? (l2 ? expf(fminf(e.scale_mul[h], 4.605170249938965f)) : 0.03125f) : 1.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = mrow + 16 * i;
+            if (m >= a.M) continue;
+            const float nrm = l2 ? fmaxf(sqrtf(sq[i]), 1e-12f) : 1.0f;
+            const int r = m / e.l, tt = m - r * e.l;
+            if (which == 0) {
+                float* pq = e.q_out + (((size_t)r * e.H + h) * e.l + tt) * 64 + cbase + 4 * lq;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    f32x4 o;
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) o[x] = l2 ? (v[i][j][x] / nrm) * sm : v[i][j][x] * sm;
+                    *reinterpret_cast<f32x4*>(pq + 16 * j) = o;
+                }
+            } else {
+                const bool nkk = l2 && which == 1;
+                uint16_t* pk = (which == 1 ? e.k_cache : e.v_cache) + ((size_t)r * e.H + h) * NP * ps + (size_t)(e.pos0 + tt) * 64 + cbase + 4 * lq;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float kv[4];
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) kv[x] = nkk ? v[i][j][x] / nrm : v[i][j][x];
+                    uint2 wh, wl;
+                    split4h_pk(kv, wh, wl);
+                    *reinterpret_cast<uint2*>(pk + 16 * j) = wh;
+                    if (e.fmt == 3) *reinterpret_cast<uint2*>(pk + ps + 16 * j) = wl;
+                }
+            }
+        }
+        return;
+    }
+    float* outp = (EPI == HEPI_PARTIAL) ? a.out + (size_t)ks * a.M * a.ldo : a.out;
+    const bool fast = a.vec && n0 + HBN <= a.N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) h_store4<EPI>(a, outp, acc[i][j], wsi, mrow + 16 * i, ncol + 16 * j, fast);
+#undef SDVAR_H6_SLOT
+}
+
 // out = epi( sum_s slab[s] + bias ) for the split-K path; the GELU variant writes planes
 template <int EPI>
 __global__ __launch_bounds__(256) void splitk_reduce_h_kernel(const float* __restrict__ ws, int split, const float* __restrict__ bias, float* out,
@@ -1150,7 +1529,7 @@ float* splitk_workspace(size_t* floats);     // gemm.hip: the shared slab worksp
 #define CM_RED0 4000.0
 #define CM_REDBW 5000.0
 #define CM_DEFBW 2000.0     // bytes per cycle at which a deferring consumer (ln_modulate, qk_norm_append) reads the slabs: not fitted
-#define CM_K4 3120.0        // 256 x 256 kernel: cycles per K-step (48 MFMAs x 32 cycles x 2 waves per SIMD, + 1.5 %)
+#define CM_K4 2850.0        // 256 x 256 kernel: cost per K-step in the units of the other tiles (3072 matrix-pipe cycles per K-step, at the higher clock the 16x16x32 shape holds)
 #define CM_FIX4 50000.0     // ... and its prologue + epilogue + launch, in the units of the other tiles' costs (calibrated on M = 2704 / 4096 / 6800, profiles/r03_gemm_tile_ab.log)
 
 static int g_force_bm_h = 0, g_force_split_h = 0;
@@ -1224,12 +1603,20 @@ static int g_h2_stages = -1;      // variant of the 128 x 128 kernel: 6 (default
 
 template <int EPI>
 static int launch_h2_kernel(const GemmHArgs& a, int grid, hipStream_t stream) {
-    if (g_h2_stages < 0) { const char* e = getenv("SDVAR_GEMM_H2_STAGES"); g_h2_stages = (e && atoi(e) == 2) ? 2 : (e && atoi(e) == 3) ? 3 : (e && atoi(e) == 5) ? 5 : (e && atoi(e) == 4) ? 4 : 6; }
+    if (g_h2_stages < 0) { const char* e = getenv("SDVAR_GEMM_H2_STAGES"); g_h2_stages = (e && atoi(e) == 2) ? 2 : (e && atoi(e) == 3) ? 3 : (e && atoi(e) == 5) ? 5 : (e && atoi(e) == 4) ? 4 : (e && atoi(e) == 7) ? 7 : 6; }
     if (g_h2_stages == 5) {        // 5-stage ring (160 KB): four K-steps in flight
         const size_t lds = 5 * (size_t)H2_STAGE * sizeof(uint16_t);
         static LdsOptIn opt_in5;
         SDVAR_LDS_OPT_IN(opt_in5, lds, (const void*)gemm_f16x2_v2_kernel<EPI, 5>);
         hipLaunchKernelGGL((gemm_f16x2_v2_kernel<EPI, 5>), dim3(grid), dim3(512), lds, stream, a);
+        SDVAR_LAUNCH_CHECK();
+        return SDVAR_OK;
+    }
+    if (g_h2_stages == 7) {        // 4 stages (128 KB), ping-pong halves, 16x16x32 MFMAs
+        const size_t lds = 4 * (size_t)H2_STAGE * sizeof(uint16_t);
+        static LdsOptIn opt_in7;
+        SDVAR_LDS_OPT_IN(opt_in7, lds, (const void*)gemm_f16x2_v6_kernel<EPI>);
+        hipLaunchKernelGGL((gemm_f16x2_v6_kernel<EPI>), dim3(grid), dim3(512), lds, stream, a);
         SDVAR_LAUNCH_CHECK();
         return SDVAR_OK;
     }
@@ -1273,14 +1660,16 @@ static int launch_h3_kernel(const GemmHArgs& a, int grid, hipStream_t stream) {
     return SDVAR_OK;
 }
 
-static int g_h4_var = -1;          // DMA placement of the 256 x 256 kernel (SDVAR_GEMM_H4_VAR, A/B runs)
+static int g_h4_var = -1;          // which 256 x 256 kernel (SDVAR_GEMM_H4_VAR, A/B runs)
 template <int EPI>
 static int launch_h4_kernel(const GemmHArgs& a, int grid, hipStream_t stream) {
     const size_t lds = 2 * (size_t)H4_STAGE * sizeof(uint16_t);      // 128 KB
-    if (g_h4_var < 0) { const char* e = getenv("SDVAR_GEMM_H4_VAR"); g_h4_var = e ? atoi(e) : 0; if (g_h4_var < 0 || g_h4_var > 2) g_h4_var = 0; }
+    if (g_h4_var < 0) { const char* e = getenv("SDVAR_GEMM_H4_VAR"); g_h4_var = e ? atoi(e) : 3; if (g_h4_var < 0 || g_h4_var > 3) g_h4_var = 3; }        // 3 (default) = the 16x16x32 kernel (gemm_f16x2_v5_kernel): 8 - 10 % faster than 0 on
+                                                                                                                             // qkv / fc1 at M >= 2704 (profiles/r03_p_v5_ab.log); 0 - 2 = the 32x32x16 kernel and its DMA placements
     static LdsOptIn opt_in;
-    SDVAR_LDS_OPT_IN(opt_in, lds, (const void*)gemm_f16x2_v4_kernel<EPI, 0>, (const void*)gemm_f16x2_v4_kernel<EPI, 1>, (const void*)gemm_f16x2_v4_kernel<EPI, 2>);
-    if (g_h4_var == 1) hipLaunchKernelGGL((gemm_f16x2_v4_kernel<EPI, 1>), dim3(grid), dim3(512), lds, stream, a);
+    SDVAR_LDS_OPT_IN(opt_in, lds, (const void*)gemm_f16x2_v4_kernel<EPI, 0>, (const void*)gemm_f16x2_v4_kernel<EPI, 1>, (const void*)gemm_f16x2_v4_kernel<EPI, 2>, (const void*)gemm_f16x2_v5_kernel<EPI>);
+    if (g_h4_var == 3) hipLaunchKernelGGL((gemm_f16x2_v5_kernel<EPI>), dim3(grid), dim3(512), lds, stream, a);
+    else if (g_h4_var == 1) hipLaunchKernelGGL((gemm_f16x2_v4_kernel<EPI, 1>), dim3(grid), dim3(512), lds, stream, a);
     else if (g_h4_var == 2) hipLaunchKernelGGL((gemm_f16x2_v4_kernel<EPI, 2>), dim3(grid), dim3(512), lds, stream, a);
     else hipLaunchKernelGGL((gemm_f16x2_v4_kernel<EPI, 0>), dim3(grid), dim3(512), lds, stream, a);
     SDVAR_LAUNCH_CHECK();

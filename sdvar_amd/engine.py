@@ -32,7 +32,7 @@ ABI_VERSION = 3
 #             measured accuracy while activations stay inside the fp16 range (csrc/gemm_f16x2.hip).
 GEMM_MODES = ("f32", "bf16x3", "f16x2")
 DEFAULT_GEMM_MODE = "f16x2"
-PROF_CLASSES = ("gemm", "attention", "ln_modulate", "qk_norm_append", "sampler", "verify", "quant", "embed_misc", "attention_small")
+PROF_CLASSES = ("gemm", "attention", "ln_modulate", "qk_norm_append", "sampler", "verify", "quant", "embed_misc", "attention_small", "gemm_small")
 
 
 class SdvarError(RuntimeError):

@@ -27,5 +27,5 @@ print(f"d{a.depth} B={B} mode={ctx.gemm_mode}: stage, tokens, wall ms (unprofile
 tot = 0
 for s in range(lad.S):
     c = prof[s][1]; tot += wall[s][0]
-    print(f"  s{s} l={lad.lens[s]:3d} M={2*B*lad.lens[s]:5d}  wall {wall[s][0]:6.3f}  gemm {c['gemm']['ms']:6.3f} ({c['gemm']['launches']} launches) attn {c['attention']['ms'] + c['attention_small']['ms']:5.3f} ln {c['ln_modulate']['ms']:5.3f} qk {c['qk_norm_append']['ms']:5.3f}")
+    print(f"  s{s} l={lad.lens[s]:3d} M={2*B*lad.lens[s]:5d}  wall {wall[s][0]:6.3f}  gemm {c['gemm']['ms'] + c['gemm_small']['ms']:6.3f} ({c['gemm']['launches'] + c['gemm_small']['launches']} launches) attn {c['attention']['ms'] + c['attention_small']['ms']:5.3f} ln {c['ln_modulate']['ms']:5.3f} qk {c['qk_norm_append']['ms']:5.3f}")
 print(f"  total {tot:.2f} ms")
