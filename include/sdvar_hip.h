@@ -71,6 +71,9 @@ int sdvar_model_bind_head(sdvar_model_t* m, const float* nm_w, const float* nm_b
  * of every block and of the head hoisted out of the stage loop (basic_var.py:156, :173 - cond never changes), KV
  * length cursor reset (basic_var.py:87).  labels: (B) int64. */
 int sdvar_model_begin(sdvar_model_t* m, int32_t B, const int64_t* labels, void* stream);
+/* The same prologue from the conditioning rows themselves: cond (2B, C) device = `sos` / `cond_BD` as SDVAR.init_param returned it
+ * (var.py:580-601) and VAR.autoregressive_infer_cfg_sd_helper1 receives it (var.py:319-345) - no label lookup. */
+int sdvar_model_begin_cond(sdvar_model_t* m, int32_t B, const float* cond, void* stream);
 /* the tensors SDVAR.init_param returns (var.py:580-601), copied out of the model object: cond (2B,C), lvl_pos (L,C),
  * first-token map (2B,C); any pointer may be NULL */
 int sdvar_model_export_prologue(sdvar_model_t* m, float* cond, float* lvl_pos, float* first, void* stream);
@@ -85,6 +88,10 @@ int sdvar_kv_set_origin(sdvar_model_t* m, int32_t stage);
 /* next-stage input embedding + CFG duplication (var.py:186-188): nxt (B, l', cvae) -> x rows b and B+b,
  * x[(r*ltot + tok_off + t)*C + :] = word_embed(nxt[b][t]) + lvl_pos[begin(s_next) + t]. */
 int sdvar_embed_next(sdvar_model_t* m, const float* nxt, int32_t s_next, float* x, int32_t ltot, int32_t tok_off, void* stream);
+/* The same with the lvl_pos rows pos_begin .. pos_begin + l' - 1 instead of the stage's own.  VAR.autoregressive_infer_cfg_sd_helper1 counts
+ * `cur_L` from the stage it is resumed at (var.py:352, 369-371, 385, 389: the skipped stages never advance it), so a call resumed at stage c
+ * embeds stage s with the rows begin(s) - begin(c); the mirror of that entry point reproduces it through this call. */
+int sdvar_embed_next_at(sdvar_model_t* m, const float* nxt, int32_t s_next, int32_t pos_begin, float* x, int32_t ltot, int32_t tok_off, void* stream);
 /* All blocks + head over the stages s0 .. s0+n_stages-1 in ONE pass (var.py:195-197; verify chunk var.py:1051-1055
  * with the mask rows of var.py:108-113 derived from the stage table).  x (R, lsum, C) is the input and is CLOBBERED
  * (it is the residual stream); logits (R, lsum, V).  Requires kv_len == begin(s0); appends lsum keys. */
@@ -103,8 +110,10 @@ int sdvar_head_forward(sdvar_model_t* m, const float* x, int32_t l, float* logit
 int sdvar_quant_create(int32_t n_stages, const int32_t* patch_nums /*host*/, int32_t cvae, int32_t vocab, int32_t max_batch,
                        int32_t n_phi, sdvar_quant_t** out /*host*/);
 int sdvar_quant_destroy(sdvar_quant_t* q);
-/* quantize.embedding.weight (V,cvae); quantize.quant_resi.qresi_ls.k.{weight (cvae,cvae,3,3), bias} as host arrays of
- * n_phi device pointers (quant.py:39, 199-229). */
+/* quantize.embedding.weight (V,cvae); the Phi convolutions {weight (cvae,cvae,3,3), bias} as host arrays of n_phi device pointers
+ * (quant.py:39, 199-243).  n_phi follows the layout the checkpoint was built with (quant.py:27-32): share_quant_resi >= 2 ->
+ * quant_resi.qresi_ls.<k> (PhiPartiallyShared, n_phi = share_quant_resi), 1 -> quant_resi.qresi (PhiShared, n_phi = 1),
+ * 0 -> quant_resi.<k> (PhiNonShared, n_phi = n_stages); stage s uses the Phi whose tick is nearest to s / (n_stages - 1). */
 int sdvar_quant_bind(sdvar_quant_t* q, const float* codebook, const float* const* phi_w /*host*/, const float* const* phi_b /*host*/);
 /* quant.py:187-196 for stage si: f_hat (B,cvae,HW,HW) += Phi(up(codebook[ids])) in place; nxt (B, pn_{si+1}^2, cvae)
  * = area_down(f_hat) (not written for the last stage; may be NULL there).  ids[b*ids_stride + p]. */

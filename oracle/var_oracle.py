@@ -138,11 +138,11 @@ class OracleVAR:
         h = F.layer_norm(x, (C,), eps=1e-6).mul(sc.add(1)).add_(sh)
         return F.linear(h, sd["head.weight"], sd["head.bias"])
 
-    def embed_next(self, nxt: Tensor, lvl_pos: Tensor, s_next: int) -> Tensor:
-        """var.py:186-188: next (B,Cvae,pn,pn) -> (2B, pn^2, C)."""
+    def embed_next(self, nxt: Tensor, lvl_pos: Tensor, s_next: int, pos_begin: Optional[int] = None) -> Tensor:
+        """var.py:186-188: next (B,Cvae,pn,pn) -> (2B, pn^2, C).  pos_begin: first lvl_pos row if not the stage's own (var.py:385 in the resumed sampler)."""
         B = nxt.shape[0]
         t = nxt.view(B, self.Cvae, -1).transpose(1, 2)
-        bg = self.begin(s_next)
+        bg = self.begin(s_next) if pos_begin is None else pos_begin
         t = F.linear(t, self.sd["word_embed.weight"], self.sd["word_embed.bias"]) + lvl_pos[:, bg:bg + self.lens[s_next]]
         return t.repeat(2, 1, 1)
 
@@ -150,13 +150,23 @@ class OracleVAR:
 class OracleQuant:
     """VectorQuantizer2 inference side: codebook + shared Phi convs (quant.py:187-229)."""
 
-    def __init__(self, vae_sd: Dict[str, Tensor], patch_nums: Sequence[int], n_phi: int = 4):
+    def __init__(self, vae_sd: Dict[str, Tensor], patch_nums: Sequence[int], n_phi: int = None):
         self.patch_nums = tuple(patch_nums)
         self.S = len(patch_nums)
         self.codebook = vae_sd["quantize.embedding.weight"].to(torch.float32)
-        self.phi = [(vae_sd[f"quantize.quant_resi.qresi_ls.{k}.weight"].float(), vae_sd[f"quantize.quant_resi.qresi_ls.{k}.bias"].float())
-                    for k in range(n_phi)]
-        K = n_phi
+        # the three Phi layouts of quant.py:27-32: PhiShared keeps ONE conv ("qresi", quant.py:209-216: __getitem__ ignores its argument),
+        # PhiPartiallyShared ("qresi_ls.<k>", quant.py:219-229) and PhiNonShared (an nn.ModuleList, "<k>", quant.py:232-243) pick by the nearest tick
+        pre = "quantize.quant_resi."
+        if pre + "qresi.weight" in vae_sd:
+            names = [pre + "qresi"]
+        else:
+            stem = pre + "qresi_ls." if pre + "qresi_ls.0.weight" in vae_sd else pre
+            names, k = [], 0
+            while f"{stem}{k}.weight" in vae_sd:
+                names.append(f"{stem}{k}"); k += 1
+        assert names and (n_phi is None or n_phi == len(names)), (len(names), n_phi)
+        self.phi = [(vae_sd[n + ".weight"].float(), vae_sd[n + ".bias"].float()) for n in names]
+        K = len(names)
         self.ticks = np.linspace(1 / 3 / K, 1 - 1 / 3 / K, K) if K == 4 else np.linspace(1 / 2 / K, 1 - 1 / 2 / K, K)
 
     def phi_of(self, si: int) -> int:
@@ -317,6 +327,48 @@ def plain_ar(model: OracleVAR, quant: OracleQuant, label_B: Tensor, cfg: float, 
     model.kv_reset()
     tr.f_hat = f_hat
     return tr
+
+
+def resume_ar(model: OracleVAR, quant: OracleQuant, cond: Tensor, current_step: int, step: int, next_map: Optional[Tensor], f_hat: Tensor, cfg: float,
+              top_k: int, top_p: float, noise: NoiseFn, more_smooth: bool = False, margins: Optional[list] = None):
+    """VAR.autoregressive_infer_cfg_sd_helper1 (var.py:319-443): stages current_step .. current_step + step - 1 from a handed-in state.  The KV cache is
+    EMPTY at entry (var.py:368 -> basic_var.py:87) and the position rows are counted from the stage the call starts at (var.py:352: `cur_L = 0`, and the
+    skipped stages `continue` before var.py:389 advances it).  Histories as var.py:436-443; f_hat snapshots are CLONES here (the reference's list holds one aliased
+    tensor, quant.py:191) - compare the last entry; the logits history holds the CFG logits AFTER the in-place top-k / top-p masking, as the reference's
+    does.  Draw index of stage si = si."""
+    B, S = cond.shape[0] // 2, model.S
+    sd = model.sd
+    lvl_1L = torch.cat([torch.full((n,), i, dtype=torch.int64) for i, n in enumerate(model.lens)])
+    lvl_pos = sd["lvl_embed.weight"][lvl_1L].unsqueeze(0) + sd["pos_1LC"]
+    model.kv_reset()
+    model.kv_base = model.begin(current_step)
+    inputs, f_hist, logit_hist, id_hist = [], [], [], []
+    nxt = next_map
+    end = min(current_step + step, S)
+    for si in range(current_step, end):
+        pn = model.patch_nums[si]
+        if si == 0:
+            x = cond.unsqueeze(1).expand(2 * B, 1, -1) + sd["pos_start"].expand(2 * B, 1, -1) + lvl_pos[:, :1]          # var.py:374-378
+        else:
+            inputs.append(nxt.reshape(B, model.Cvae, -1).transpose(1, 2).clone())                                      # var.py:382-384
+            x = model.embed_next(nxt.reshape(B, model.Cvae, pn, pn), lvl_pos, si, model.begin(si) - model.begin(current_step))   # var.py:352, 385, 389: cur_L counts from current_step
+        f_hist.append(f_hat.clone())
+        logits = model.forward(x, cond, si, 1)
+        cl = cfg_combine(logits, B, cfg * (si / (S - 1)))
+        ids, masked = sample_topk_topp(cl, top_k, top_p, noise(si, B, pn * pn, model.V), margins)
+        logit_hist.append(masked)                      # var.py:408 appends the tensor helpers.py:10,15 then mask IN PLACE: the history holds -inf at the removed entries
+        id_hist.append(ids)
+        if not more_smooth:
+            h = quant.embed_ids(ids, pn)
+        else:
+            ratio = si / (S - 1)
+            h = gumbel_mix(masked, ratio, noise(si | GUMBEL_DRAW, B, pn * pn, model.V).view(B, pn * pn, model.V), quant.codebook)
+            h = h.transpose(1, 2).reshape(B, quant.codebook.shape[1], pn, pn)
+        f_hat, nxt = quant.next_input(si, f_hat, h)
+    f_hist.append(f_hat.clone())
+    inputs.append(nxt)                                                                                                 # var.py:430 (raw (B, Cvae, pn', pn'); f_hat after the last stage)
+    model.kv_reset()
+    return inputs, f_hist, logit_hist, id_hist
 
 
 # ------------------------------------------------------------------------------------------------ hand-off sampler

@@ -24,7 +24,7 @@ int gemm_f16x2_qkv(const uint16_t* X, size_t xps, const uint16_t* W, size_t wps,
                    const float* scale_mul, float* q_out, void* k_cache, void* v_cache, int l, int H, int Lp, int pos0, int kv_fmt, int* defer, int* fused, hipStream_t stream);
 int silu_rows(const float* x, float* y, int n, hipStream_t stream);
 int add_row_vector(const float* src, const float* vec, float* out, int rows, int cols, hipStream_t stream);
-int prologue(const long long* labels, const float* class_emb, const float* pos_start, const float* lvl_pos, float* cond, float* x0, int B, int C, int num_classes, hipStream_t stream);
+int prologue(const long long* labels, const float* cond_in, const float* class_emb, const float* pos_start, const float* lvl_pos, float* cond, float* x0, int B, int C, int num_classes, hipStream_t stream);
 int build_lvl_pos(const float* lvl_embed, const float* pos, const int* stage_of_tok, float* out, int L, int C, hipStream_t stream);
 int embed_next(const float* nxt, const float* Ww, const float* bw, const float* lvl_pos, float* x, int B, int l, int C, int t0, int ltot, int tok_off, hipStream_t stream);
 int attention_f32(const float* q, const void* kc, const void* vc, int kv_f16, float* out, uint16_t* outp, size_t ops, int pfmt, int R, int H, int l, int Lmax, int Ktot, int n_chunk, const int* qbeg, const int* vis, hipStream_t stream);
@@ -155,8 +155,8 @@ struct sdvar_quant {
     std::vector<std::vector<float>> hWup, hWdn;
     float* up_scratch;
     const float* codebook;
-    const float* phi_w[8];
-    const float* phi_b[8];
+    const float* phi_w[SDVAR_MAX_STAGES];
+    const float* phi_b[SDVAR_MAX_STAGES];
     bool bound;
 };
 
@@ -347,16 +347,25 @@ static int check_bound(const sdvar_model* m) {
     return SDVAR_OK;
 }
 
+static int model_begin_impl(sdvar_model_t* m, int32_t B, const int64_t* labels, const float* cond_in, void* stream);
 int sdvar_model_begin(sdvar_model_t* m, int32_t B, const int64_t* labels, void* stream) {
+    SDVAR_CHECK_ARG(labels, "model_begin: null labels");
+    return model_begin_impl(m, B, labels, nullptr, stream);
+}
+int sdvar_model_begin_cond(sdvar_model_t* m, int32_t B, const float* cond, void* stream) {
+    SDVAR_CHECK_ARG(cond, "model_begin_cond: null cond");
+    return model_begin_impl(m, B, nullptr, cond, stream);
+}
+static int model_begin_impl(sdvar_model_t* m, int32_t B, const int64_t* labels, const float* cond_in, void* stream) {
     SDVAR_TRY(check_bound(m));
-    SDVAR_CHECK_ARG(B >= 1 && B <= m->d.max_batch && labels, "model_begin: B=%d (max %d)", B, m->d.max_batch);
+    SDVAR_CHECK_ARG(B >= 1 && B <= m->d.max_batch, "model_begin: B=%d (max %d)", B, m->d.max_batch);
     hipStream_t s = (hipStream_t)stream;
     WsScope wsg(m->ws_own);
     const int C = m->C, R = 2 * B;
     m->B = B; m->kv_len = 0; m->kv_origin = 0;
     {
         ProfScope ps(7, 0, 0, s);
-        SDVAR_TRY(prologue((const long long*)labels, m->class_emb, m->pos_start, m->lvl_pos, m->cond, m->x0, B, C, m->d.num_classes, s));
+        SDVAR_TRY(prologue((const long long*)labels, cond_in, m->class_emb, m->pos_start, m->lvl_pos, m->cond, m->x0, B, C, m->d.num_classes, s));
         SDVAR_TRY(silu_rows(m->cond, m->cond_silu, R * C, s));
     }
     // adaLN parameters of every block: stage-invariant, computed once per call instead of once per stage
@@ -410,11 +419,17 @@ int sdvar_kv_set_origin(sdvar_model_t* m, int32_t stage) {
     return SDVAR_OK;
 }
 
-int sdvar_embed_next(sdvar_model_t* m, const float* nxt, int32_t s_next, float* x, int32_t ltot, int32_t tok_off, void* stream) {
+int sdvar_embed_next_at(sdvar_model_t* m, const float* nxt, int32_t s_next, int32_t pos_begin, float* x, int32_t ltot, int32_t tok_off, void* stream) {
     SDVAR_CHECK_ARG(m && m->begun && nxt && x, "embed_next: model not begun or null");
     SDVAR_CHECK_ARG(s_next >= 1 && s_next < m->S && tok_off >= 0 && tok_off + m->lens[s_next] <= ltot, "embed_next: stage %d off %d ltot %d", s_next, tok_off, ltot);
+    SDVAR_CHECK_ARG(pos_begin >= 0 && pos_begin + m->lens[s_next] <= m->L, "embed_next: position rows %d .. %d outside the table (%d)", pos_begin, pos_begin + m->lens[s_next], m->L);
     ProfScope ps(7, 2.0 * m->B * m->lens[s_next] * 32.0 * m->C, 4.0 * m->lens[s_next] * m->C * (2.0 * m->B + 1.0), (hipStream_t)stream);
-    return embed_next(nxt, m->word_w, m->word_b, m->lvl_pos, x, m->B, m->lens[s_next], m->C, begin_of(m, s_next), ltot, tok_off, (hipStream_t)stream);
+    return embed_next(nxt, m->word_w, m->word_b, m->lvl_pos, x, m->B, m->lens[s_next], m->C, pos_begin, ltot, tok_off, (hipStream_t)stream);
+}
+
+int sdvar_embed_next(sdvar_model_t* m, const float* nxt, int32_t s_next, float* x, int32_t ltot, int32_t tok_off, void* stream) {
+    SDVAR_CHECK_ARG(m && s_next >= 1 && s_next < m->S, "embed_next: stage %d", s_next);
+    return sdvar_embed_next_at(m, nxt, s_next, begin_of(m, s_next), x, ltot, tok_off, stream);
 }
 
 static int stage_forward_impl(sdvar_model_t* m, float* x, int32_t s0, int32_t n, const float* bias, float* logits, void* stream);
@@ -554,7 +569,7 @@ static void bicubic_row(int n_in, int n_out, int o, float* row) {   // one row o
 
 int sdvar_quant_create(int32_t S, const int32_t* patch_nums, int32_t cvae, int32_t vocab, int32_t max_batch, int32_t n_phi, sdvar_quant_t** out) {
     SDVAR_CHECK_ARG(out && patch_nums && S >= 1 && S <= SDVAR_MAX_STAGES && cvae >= 1 && vocab >= 1 && max_batch >= 1, "quant_create: bad argument");
-    SDVAR_CHECK_ARG(n_phi >= 1 && n_phi <= 8, "quant_create: n_phi %d", n_phi);
+    SDVAR_CHECK_ARG(n_phi >= 1 && n_phi <= SDVAR_MAX_STAGES, "quant_create: n_phi %d", n_phi);          // 1 = PhiShared, S = PhiNonShared (quant.py:27-32)
     sdvar_quant* q = new sdvar_quant();
     q->S = S; q->Cv = cvae; q->V = vocab; q->maxB = max_batch; q->n_phi = n_phi; q->bound = false; q->codebook = nullptr;
     for (int s = 0; s < S; ++s) q->pn[s] = patch_nums[s];
@@ -719,11 +734,11 @@ int sdvar_op_noise_fill(float* q, int32_t B, int32_t l, int32_t V, uint64_t seed
 }
 
 int sdvar_debug_set_gemm_cfg(int32_t bm, int32_t split) {
-    // f16x2 only: bm 512 = the 256 x 256 tile kernel; bm 256 with split -T = hybrid tail split T ways (the other GEMM modes take bm 256 / split 0 for those)
-    SDVAR_CHECK_ARG(bm == 0 || bm == 32 || bm == 64 || bm == 128 || bm == 256 || bm == 512, "debug_set_gemm_cfg: bm %d", bm);
+    // f16x2 only: bm 512 = the 256 x 256 tile kernel; bm 16 = the skinny kernel (M <= 80); bm 256 with split -T = hybrid tail split T ways (the other modes take their nearest tile)
+    SDVAR_CHECK_ARG(bm == 0 || bm == 16 || bm == 32 || bm == 64 || bm == 128 || bm == 256 || bm == 512, "debug_set_gemm_cfg: bm %d", bm);
     SDVAR_CHECK_ARG(split >= -64 && split <= 64 && (split >= 0 || bm == 256), "debug_set_gemm_cfg: split %d", split);
-    debug_set_gemm_cfg(bm == 512 ? 256 : bm, split < 0 ? 0 : split);
-    debug_set_gemm_cfg_p(bm == 512 ? 256 : bm, split < 0 ? 0 : split);
+    debug_set_gemm_cfg(bm == 512 ? 256 : bm == 16 ? 32 : bm, split < 0 ? 0 : split);
+    debug_set_gemm_cfg_p(bm == 512 ? 256 : bm == 16 ? 32 : bm, split < 0 ? 0 : split);
     debug_set_gemm_cfg_h(bm, split);
     return SDVAR_OK;
 }

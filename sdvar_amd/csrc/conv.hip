@@ -124,6 +124,81 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[5
     }
 }
 
+// The same epilogue for the accumulators of v_mfma_f32_16x16x32_f16 with W as the A operand (conv_f16x2_kernel<EPI, 2>): acc[mt][nt] (f32x4) holds row
+// m0 + 32 wave + 16 mt + (lane & 15), columns n0 + 16 nt + 4 (lane >> 4) .. + 3 - four CONSECUTIVE columns of one pixel row per register group, so bias, residual
+// and output move 16 bytes per access (the 32x32x16 layout above: 4 bytes, 80 store instructions per wave against 20) and a lane owns 2 pixel rows, not 16 (two
+// index divisions for the up-sampling scatter).  The GroupNorm column sums run over the 16 lanes of a DPP row (4 row_shr adds per value) before the LDS stage.
+typedef float cf32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float dpp_row_sum16(float v) {          // lane 15 of every 16-lane row ends up with the row's sum
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xF, 0xF, true));      // row_shr:1, out-of-row lanes read 0
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xF, 0xF, true));      // row_shr:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xF, 0xF, true));      // row_shr:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xF, 0xF, true));      // row_shr:8
+    return v;
+}
+template <int EPI>
+__device__ __forceinline__ void conv_epilogue16(const ConvArgs& a, cf32x4 (&acc)[2][10], float wsi, int m0, int n0, int tm, int ks, int phase, int wave, int l15, int lq,
+                                                int tid, uint16_t* csm) {
+    int mrow[2]; size_t orow[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int m = m0 + wave * 32 + 16 * mt + l15;
+        mrow[mt] = m; orow[mt] = (size_t)m;
+        if (EPI != CEPI_PARTIAL && a.up_phase >= 0 && m < a.M) {          // pixel (b, y, x) of the input grid -> (b, 2y + py, 2x + px) of the output grid
+            const int hw = a.ih * a.iw, b = m / hw, rem = m - b * hw, y = rem / a.iw, x = rem - y * a.iw;
+            orow[mt] = ((size_t)(b * 2 * a.ih + 2 * y + (phase >> 1)) * (2 * a.iw) + 2 * x + (phase & 1));
+        }
+    }
+    cf32x4 rv[2][10];
+    if (EPI == CEPI_BIAS_RES) {                      // the whole residual tile of the lane in flight first (20 independent 16-byte loads)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 10; ++nt) {
+                const int n = n0 + 16 * nt + 4 * lq;
+                rv[mt][nt] = (n < a.N && mrow[mt] < a.M) ? *reinterpret_cast<const cf32x4*>(a.res + (size_t)mrow[mt] * a.ldo + n) : cf32x4{0.f, 0.f, 0.f, 0.f};
+            }
+    }
+    float* outp = (EPI == CEPI_PARTIAL) ? a.out + (size_t)ks * a.M * a.ldo : a.out;
+#pragma unroll
+    for (int nt = 0; nt < 10; ++nt) {
+        const int n = n0 + 16 * nt + 4 * lq;
+        if (n >= a.N) continue;                      // N % 4 == 0 (host): a group of four columns is inside or outside as a whole
+        const cf32x4 bv = (EPI != CEPI_PARTIAL && a.bias) ? *reinterpret_cast<const cf32x4*>(a.bias + n) : cf32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            if (mrow[mt] >= a.M) continue;
+            cf32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = acc[mt][nt][e] * wsi + bv[e]; if (EPI == CEPI_BIAS_RES) v[e] += rv[mt][nt][e]; }
+            if (!SDVAR_CDBG(a, 4)) *reinterpret_cast<cf32x4*>(outp + orow[mt] * a.ldo + n) = v;
+            acc[mt][nt] = v;
+        }
+    }
+    if (EPI != CEPI_PARTIAL && a.gn_part && !SDVAR_CDBG(a, 2)) {          // GroupNorm statistics of the tile just written (M % 256 == 0 when enabled: every row is real)
+        float* red = reinterpret_cast<float*>(csm);          // [2][8][160]
+        __syncthreads();                                     // every wave is done with the operand stages
+#pragma unroll
+        for (int nt = 0; nt < 10; ++nt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool in = n0 + 16 * nt + 4 * lq < a.N;
+                const float x0 = in ? acc[0][nt][e] : 0.f, x1 = in ? acc[1][nt][e] : 0.f;
+                const float s1 = dpp_row_sum16(x0 + x1), s2 = dpp_row_sum16(x0 * x0 + x1 * x1);
+                if (l15 == 15) { red[wave * 160 + 16 * nt + 4 * lq + e] = s1; red[1280 + wave * 160 + 16 * nt + 4 * lq + e] = s2; }
+            }
+        __syncthreads();
+        const int gl = tid, col0 = gl * a.cpg;
+        if (col0 < CBN && n0 + col0 < a.N) {
+            double a1 = 0.0, a2 = 0.0;
+            for (int w = 0; w < 8; ++w)
+                for (int c = 0; c < a.cpg; ++c) { a1 += (double)red[w * 160 + col0 + c]; a2 += (double)red[1280 + w * 160 + col0 + c]; }
+            double* o = a.gn_part + ((size_t)(a.up_phase >= 0 ? 4 * tm + phase : tm) * 32 + (n0 + col0) / a.cpg) * 2;
+            o[0] = a1; o[1] = a2;
+        }
+    }
+}
+
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void conv_bf16x3_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint16_t csm[];
@@ -328,6 +403,82 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(ConvArgs a) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) issue_one(csm + CSTAGE_H, q);
     }
+    if constexpr (PP == 2) {
+        // the ping-pong schedule of PP = 1 on v_mfma_f32_16x16x32_f16 (the shape the chip holds the higher clock on: profiles/r03_o_mfma_shape_f16.log): a fragment is
+        // 16 rows x 32 k (one ds_read_b128: row lane & 15, chunk lane >> 4), so the K-step splits by COLUMN tiles: slot L0 = the 4 X fragments + W tiles 0-4 (14 reads)
+        // + DMA slots 0-3, M0 = 2 x 5 x 3 = 30 MFMAs (480 matrix-pipe cycles), L1 = W tiles 5-9 (10 reads) + DMA slots 4-7, M1 = 30 MFMAs.
+        const int late = __builtin_amdgcn_readfirstlane(wave >> 2);
+        const int l15 = lane & 15, lq = lane >> 4;
+        auto wait_next = [&](int t) {
+            if (t + 2 < nk) { if (two_w) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+#define SDVAR_C_SLOT() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define SDVAR_LDS_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr) : "memory")
+#define SDVAR_C_MFMA16(J0)                                                                                      \
+        _Pragma("unroll") for (int j = 0; j < 5; ++j)                                                           \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                     \
+                acc16[i][(J0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[j][0], fx[i][1], acc16[i][(J0) + j], 0, 0, 0);   \
+                acc16[i][(J0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[j][1], fx[i][0], acc16[i][(J0) + j], 0, 0, 0);   \
+                acc16[i][(J0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[j][0], fx[i][0], acc16[i][(J0) + j], 0, 0, 0);   \
+            }
+        cf32x4 acc16[2][10];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 10; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc16[i][j][r] = 0.f;
+        // fragment addresses inside a stage (bytes): X plane p at + 16384 p, row tile i at + 1024 i; W planes behind the X planes (+ 32768), plane p at + 10240 p, column tile j at + 1024 j
+        const uint32_t fro = (uint32_t)(l15 * 64 + 16 * (lq ^ ((l15 >> 2) & 3)));
+        const uint32_t fxo = (uint32_t)(wave * 32 * 64) + fro, fwo = 32768u + fro;
+        wait_next(-1);
+        SDVAR_C_SLOT();
+        if (late) SDVAR_C_SLOT();
+        f16x8 fx[2][2], fw[5][2];                // [row tile][plane], [column tile of the half][plane]
+#pragma unroll 1
+        for (int t = 0; t < nk; ++t) {
+            const bool pf = t + 2 < nk;
+            uint16_t* nst = csm + ((t + 2) % 3) * CSTAGE_H;
+            const uint32_t sb = (uint32_t)(uintptr_t)(lds_ptr_t)(csm + (t % 3) * CSTAGE_H);
+            const uint32_t xa = sb + fxo, wa = sb + fwo;
+            // ---- L0(t)
+            SDVAR_LDS_RD(fx[0][0], xa, 0); SDVAR_LDS_RD(fx[0][1], xa, 16384); SDVAR_LDS_RD(fx[1][0], xa, 1024); SDVAR_LDS_RD(fx[1][1], xa, 17408);
+            SDVAR_LDS_RD(fw[0][0], wa, 0);    SDVAR_LDS_RD(fw[0][1], wa, 10240); SDVAR_LDS_RD(fw[1][0], wa, 1024); SDVAR_LDS_RD(fw[1][1], wa, 11264);
+            SDVAR_LDS_RD(fw[2][0], wa, 2048); SDVAR_LDS_RD(fw[2][1], wa, 12288); SDVAR_LDS_RD(fw[3][0], wa, 3072); SDVAR_LDS_RD(fw[3][1], wa, 13312);
+            SDVAR_LDS_RD(fw[4][0], wa, 4096); SDVAR_LDS_RD(fw[4][1], wa, 14336);
+            if (pf) {
+                set_next();
+#pragma unroll
+                for (int q = 0; q < 4; ++q) issue_one(nst, q);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            SDVAR_C_SLOT();
+            SDVAR_C_MFMA16(0);                   // M0(t): column tiles 0-4
+            SDVAR_C_SLOT();
+            // ---- L1(t)
+            SDVAR_LDS_RD(fw[0][0], wa, 5120); SDVAR_LDS_RD(fw[0][1], wa, 15360); SDVAR_LDS_RD(fw[1][0], wa, 6144); SDVAR_LDS_RD(fw[1][1], wa, 16384);
+            SDVAR_LDS_RD(fw[2][0], wa, 7168); SDVAR_LDS_RD(fw[2][1], wa, 17408); SDVAR_LDS_RD(fw[3][0], wa, 8192); SDVAR_LDS_RD(fw[3][1], wa, 18432);
+            SDVAR_LDS_RD(fw[4][0], wa, 9216); SDVAR_LDS_RD(fw[4][1], wa, 19456);
+            if (pf) {
+#pragma unroll
+                for (int q = 4; q < 8; ++q) issue_one(nst, q);
+            }
+            if (late) wait_next(t);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            SDVAR_C_SLOT();
+            SDVAR_C_MFMA16(5);                   // M1(t): column tiles 5-9
+            if (!late) wait_next(t);
+            SDVAR_C_SLOT();
+        }
+        if (!late) SDVAR_C_SLOT();
+#undef SDVAR_C_MFMA16
+#undef SDVAR_LDS_RD
+#undef SDVAR_C_SLOT
+        if (SDVAR_CDBG(a, 1)) return;
+        conv_epilogue16<EPI>(a, acc16, a.wsi ? *a.wsi : 1.0f, m0, n0, tm, ks, phase, wave, l15, lq, tid, csm);
+        return;
+    } else
     if (PP) {
         const int late = __builtin_amdgcn_readfirstlane(wave >> 2);
         auto wait_next = [&](int t) {          // K-step t + 1 landed: K-step t + 2 (8 instructions for waves 0-1, 6 for the others), if requested, may stay in flight
@@ -557,15 +708,19 @@ int conv_planes(const uint16_t* X, size_t xps, size_t x_rows, int x_row0, const 
         a.k_per_split = kps; a.split = split;
     }
     const size_t lds = F16 ? 3 * (size_t)CSTAGE_H * sizeof(uint16_t) : 2 * (size_t)CSTAGE * sizeof(uint16_t);      // 156 KB either way
-    static const bool pp = !(getenv("SDVAR_CONV_PP") && atoi(getenv("SDVAR_CONV_PP")) == 0);          // A/B runs: SDVAR_CONV_PP=0 selects the round-2 loop
+    const char* pp_s = getenv("SDVAR_CONV_PP");          // read per call (tests switch it): 0 = the round-2 loop, 1 = ping-pong on 32x32x16, 2 (default) = ping-pong on 16x16x32
+    const int pp_env = pp_s ? atoi(pp_s) : 2;
+    const int pp = (pp_env == 2 && N % 4 != 0) ? 1 : pp_env;                                         // the 16-byte epilogue needs whole groups of four columns
     static LdsOptIn opt_in, opt_in_h;
     if (F16) SDVAR_LDS_OPT_IN(opt_in_h, lds, (const void*)conv_f16x2_kernel<CEPI_BIAS, 0>, (const void*)conv_f16x2_kernel<CEPI_BIAS_RES, 0>, (const void*)conv_f16x2_kernel<CEPI_PARTIAL, 0>,
-                              (const void*)conv_f16x2_kernel<CEPI_BIAS, 1>, (const void*)conv_f16x2_kernel<CEPI_BIAS_RES, 1>, (const void*)conv_f16x2_kernel<CEPI_PARTIAL, 1>);
+                              (const void*)conv_f16x2_kernel<CEPI_BIAS, 1>, (const void*)conv_f16x2_kernel<CEPI_BIAS_RES, 1>, (const void*)conv_f16x2_kernel<CEPI_PARTIAL, 1>,
+                              (const void*)conv_f16x2_kernel<CEPI_BIAS, 2>, (const void*)conv_f16x2_kernel<CEPI_BIAS_RES, 2>, (const void*)conv_f16x2_kernel<CEPI_PARTIAL, 2>);
     else SDVAR_LDS_OPT_IN(opt_in, lds, (const void*)conv_bf16x3_kernel<CEPI_BIAS>, (const void*)conv_bf16x3_kernel<CEPI_BIAS_RES>, (const void*)conv_bf16x3_kernel<CEPI_PARTIAL>);
     if (split > 1) {
         ConvArgs p = a;
         p.out = ws;
-        if (F16 && pp) hipLaunchKernelGGL((conv_f16x2_kernel<CEPI_PARTIAL, 1>), dim3(tiles * split), dim3(512), lds, stream, p);
+        if (F16 && pp == 2) hipLaunchKernelGGL((conv_f16x2_kernel<CEPI_PARTIAL, 2>), dim3(tiles * split), dim3(512), lds, stream, p);
+        else if (F16 && pp) hipLaunchKernelGGL((conv_f16x2_kernel<CEPI_PARTIAL, 1>), dim3(tiles * split), dim3(512), lds, stream, p);
         else if (F16) hipLaunchKernelGGL((conv_f16x2_kernel<CEPI_PARTIAL, 0>), dim3(tiles * split), dim3(512), lds, stream, p);
         else hipLaunchKernelGGL((conv_bf16x3_kernel<CEPI_PARTIAL>), dim3(tiles * split), dim3(512), lds, stream, p);
         SDVAR_LAUNCH_CHECK();
@@ -577,8 +732,10 @@ int conv_planes(const uint16_t* X, size_t xps, size_t x_rows, int x_row0, const 
     }
     if (gn_part && N % 32 == 0 && CBN % (N / 32) == 0 && (H * Wd) % CBM == 0) { a.gn_part = gn_part; a.cpg = N / 32; if (gn_done) *gn_done = 1; }
     if (F16) {
-        if (res && pp) hipLaunchKernelGGL((conv_f16x2_kernel<CEPI_BIAS_RES, 1>), dim3(tiles), dim3(512), lds, stream, a);
+        if (res && pp == 2) hipLaunchKernelGGL((conv_f16x2_kernel<CEPI_BIAS_RES, 2>), dim3(tiles), dim3(512), lds, stream, a);
+        else if (res && pp) hipLaunchKernelGGL((conv_f16x2_kernel<CEPI_BIAS_RES, 1>), dim3(tiles), dim3(512), lds, stream, a);
         else if (res) hipLaunchKernelGGL((conv_f16x2_kernel<CEPI_BIAS_RES, 0>), dim3(tiles), dim3(512), lds, stream, a);
+        else if (pp == 2) hipLaunchKernelGGL((conv_f16x2_kernel<CEPI_BIAS, 2>), dim3(tiles, up_phase >= 0 ? 4 : 1), dim3(512), lds, stream, a);
         else if (pp) hipLaunchKernelGGL((conv_f16x2_kernel<CEPI_BIAS, 1>), dim3(tiles, up_phase >= 0 ? 4 : 1), dim3(512), lds, stream, a);
         else hipLaunchKernelGGL((conv_f16x2_kernel<CEPI_BIAS, 0>), dim3(tiles, up_phase >= 0 ? 4 : 1), dim3(512), lds, stream, a);
     } else if (res) hipLaunchKernelGGL((conv_bf16x3_kernel<CEPI_BIAS_RES>), dim3(tiles), dim3(512), lds, stream, a);

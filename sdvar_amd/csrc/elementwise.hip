@@ -534,21 +534,26 @@ int add_row_vector(const float* src, const float* vec, float* out, int rows, int
     return SDVAR_OK;
 }
 
-// cond (2B, C) = class_emb[label_b] for rows < B, class_emb[num_classes] for rows >= B;  x0 (2B,1,C) = cond + pos_start + lvl_pos[0]
-__global__ void prologue_kernel(const long long* __restrict__ labels, const float* __restrict__ class_emb, const float* __restrict__ pos_start,
+// cond (2B, C) = class_emb[label_b] for rows < B, class_emb[num_classes] for rows >= B - or, with cond_in, the caller's rows (VAR.autoregressive_infer_cfg_sd_helper1
+// is handed `sos`, var.py:344-345);  x0 (2B,1,C) = cond + pos_start + lvl_pos[0]
+__global__ void prologue_kernel(const long long* __restrict__ labels, const float* __restrict__ cond_in, const float* __restrict__ class_emb, const float* __restrict__ pos_start,
                                 const float* __restrict__ lvl_pos, float* __restrict__ cond, float* __restrict__ x0, int B, int C, int num_classes) {
     const int r = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    long long lab = (r < B) ? labels[r] : (long long)num_classes;
-    if (lab < 0 || lab > num_classes) lab = num_classes;
-    const float e = class_emb[(size_t)lab * C + c];
+    float e;
+    if (cond_in) e = cond_in[(size_t)r * C + c];
+    else {
+        long long lab = (r < B) ? labels[r] : (long long)num_classes;
+        if (lab < 0 || lab > num_classes) lab = num_classes;
+        e = class_emb[(size_t)lab * C + c];
+    }
     cond[(size_t)r * C + c] = e;
     x0[(size_t)r * C + c] = (e + pos_start[c]) + lvl_pos[c];
 }
 
-int prologue(const long long* labels, const float* class_emb, const float* pos_start, const float* lvl_pos, float* cond, float* x0,
+int prologue(const long long* labels, const float* cond_in, const float* class_emb, const float* pos_start, const float* lvl_pos, float* cond, float* x0,
              int B, int C, int num_classes, hipStream_t stream) {
-    hipLaunchKernelGGL(prologue_kernel, dim3((C + 255) / 256, 2 * B), dim3(256), 0, stream, labels, class_emb, pos_start, lvl_pos, cond, x0, B, C, num_classes);
+    hipLaunchKernelGGL(prologue_kernel, dim3((C + 255) / 256, 2 * B), dim3(256), 0, stream, labels, cond_in, class_emb, pos_start, lvl_pos, cond, x0, B, C, num_classes);
     SDVAR_LAUNCH_CHECK();
     return SDVAR_OK;
 }

@@ -1208,160 +1208,84 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_v5_kernel(GemmHArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The 128 x 128 ping-pong kernel (gemm_f16x2_v2_kernel<EPI, 6>) on v_mfma_f32_16x16x32_f16: same tile, waves (2 x 4 of 64 x 32 outputs), 4-stage LDS image, DMA and
-// slot schedule; fragments, accumulators and epilogue addressing as gemm_f16x2_v5_kernel (a lane holds row l & 15 of every 16-row tile, columns 4 (l >> 4) .. + 3 of
-// every 16-column tile).  Per K-step a wave reads 4 X + 2 W tiles x 2 planes (12 x b128) and issues 4 x 2 x 3 = 24 MFMAs (384 matrix-pipe cycles).
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_f16x2_v6_kernel(GemmHArgs a) {
+// Skinny kernel for M <= 80 rows (stages 0 - 1 and the first verify chunk: 16 - 80 CFG rows): these launches are weight streams - 4 - 17 MB of planes read once for
+// 0.1 - 0.8 GFLOP - and the LDS-ring kernels above spend their time on everything else: split-K over 6 - 24 workgroups per column panel, slabs, a reduce launch
+// or a slab-summing consumer, a DMA ring that never fills (9 - 12 us per launch against a 2 - 3 us stream: profiles/r02_gemm_sweep_cold_full.jsonl).
+// Here (cdna_hip_programming.md "GEMV / M <= 16 decode weights": operand streamed once and not shared across waves -> straight to VGPRs, deep unroll, late wait):
+//   workgroup = 16 output columns x ALL rows x a K range of at most 8 NW K-steps; NW = 4 waves, wave w takes K-steps w, w + NW, ...
+//   every W fragment of a wave (16 columns x 32 k x 2 planes = 2 KB per K-step: one contiguous run of the K-blocked planes, which IS the 16x16x32 A operand) is
+//   requested up front - up to 16 loads of 1 KB in flight per wave, ONE HBM round trip per launch; X fragments (L2-resident) likewise, in two batches from MT = 3;
+//   acc[mt] += Wh Xl + Wl Xh + Wh Xh on v_mfma_f32_16x16x32_f16; the waves' partial sums meet in LDS (summed in wave order: deterministic) and wave mt finishes row
+//   tile mt with the epilogue of the other kernels (h_store4): no slabs and no second launch unless K > 8 NW K-steps (fc2 at NW = 4: split over workgroups).
+template <int MT, int NW, int EPI>
+__global__ __launch_bounds__(64 * NW) void gemm_f16x2_skinny_kernel(GemmHArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint16_t hsm[];
-    constexpr int BM = 128;
-    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + HBN - 1) / HBN, ntile = tiles_m * tiles_n;
-    const int ks = blockIdx.x / ntile;
-    const int lid = xcd_remap(blockIdx.x - ks * ntile, ntile);
-    const int G = 8, per_group = tiles_m * G;
-    const int g = lid / per_group, rem = lid - g * per_group;
-    const int gw = min(G, tiles_n - g * G);
-    const int tm = rem / gw, tn = g * G + rem % gw;
-    const int m0 = tm * BM, n0 = tn * HBN;
-
+    const int tiles_n = (a.N + 15) / 16;
+    const int ks = blockIdx.x / tiles_n, tn = blockIdx.x - ks * tiles_n;
+    const int n0 = tn * 16;
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
-    const int swave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = swave >> 2, wn = swave & 3;
-    const int drow = 16 * swave + (lane >> 2);
-    const int dchunk = (lane & 3) ^ ((drow >> 2) & 3);
-    const int xrow = min(m0 + drow, a.M - 1), wrow = min(n0 + drow, a.N - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kt0 = ks * a.k_per_split;
-    const int nk = min(a.K / HBK - kt0, a.k_per_split);
-    const uint32_t lx = (uint32_t)(xrow * 32 + 8 * dchunk) * 2u, lw = (uint32_t)(wrow * 32 + 8 * dchunk) * 2u;
-    const char* const bx = reinterpret_cast<const char*>(a.X + (size_t)kt0 * a.M * 32);
-    const char* const bw = reinterpret_cast<const char*>(a.W + (size_t)kt0 * a.N * 32);
-    auto issue4 = [&](int t) {
-        uint16_t* st = hsm + (t & 3) * H2_STAGE + swave * 512;
+    const int nk = min(a.K / HBK - kt0, a.k_per_split);                    // <= 8 NW (host)
+    // lane l of a fragment: row l15 of the 16-row tile, k 8 lq .. 8 lq + 7 of the K-step: 16 bytes at ((kt rows + row) 32 + 8 lq) elements of the plane
+    const uint16_t* pw = a.W + ((size_t)kt0 * a.N + min(n0 + l15, a.N - 1)) * 32 + 8 * lq;
+    const uint16_t* px[MT];
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            SDVAR_DMA16(lx, bx + ((size_t)t * a.M * 32 + p * a.xps) * 2, SDVAR_LDS_ADDR(st + p * 4096));
-            SDVAR_DMA16(lw, bw + ((size_t)t * a.N * 32 + p * a.wps) * 2, SDVAR_LDS_ADDR(st + (2 + p) * 4096));
+    for (int i = 0; i < MT; ++i) px[i] = a.X + ((size_t)kt0 * a.M + min(16 * i + l15, a.M - 1)) * 32 + 8 * lq;
+    const size_t wstep = (size_t)a.N * 32, xstep = (size_t)a.M * 32;
+    f16x8 fw[8][2];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int t = wave + s * NW;
+        if (t < nk) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) fw[s][p] = __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(pw + (size_t)t * wstep + p * a.wps));
         }
-    };
-    auto wait_next = [&](int t) {
-        const int after = nk - t - 2;
-        if (after >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (after == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-
-    f32x4v acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
-    // stage = X planes h, l [128][64 B] at 0 / 8192, W planes at 16384 / 24576 (bytes); fragment = row l15 of a 16-row tile, chunk lq swizzled by (l15 >> 2) & 3
-    const uint32_t fro = (uint32_t)(l15 * 64 + 16 * (lq ^ ((l15 >> 2) & 3)));
-    const uint32_t lds0 = SDVAR_LDS_ADDR(hsm);
-    const uint32_t ax = lds0 + (uint32_t)(wm * 64 * 64) + fro, aw = lds0 + 16384u + (uint32_t)(wn * 32 * 64) + fro;
-    const int late = wm;
-#define SDVAR_H6_SLOT() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
-    for (int tt = 0; tt < 3 && tt < nk; ++tt) issue4(tt);
-    wait_next(-1);
-    SDVAR_H6_SLOT();
-    if (late) SDVAR_H6_SLOT();
-    f16x8 fx[4][2], fw[2][2];
-#pragma unroll 1
-    for (int t = 0; t < nk; ++t) {
-        const uint32_t so = (uint32_t)(t & 3) * (uint32_t)(H2_STAGE * 2);
-        const uint32_t x0 = ax + so, w0 = aw + so;
-        SDVAR_LDS_RDH(fx[0][0], x0, 0);     SDVAR_LDS_RDH(fx[0][1], x0, 8192);  SDVAR_LDS_RDH(fw[0][0], w0, 0);     SDVAR_LDS_RDH(fw[0][1], w0, 8192);
-        SDVAR_LDS_RDH(fx[1][0], x0, 1024);  SDVAR_LDS_RDH(fx[1][1], x0, 9216);  SDVAR_LDS_RDH(fw[1][0], w0, 1024);  SDVAR_LDS_RDH(fw[1][1], w0, 9216);
-        SDVAR_LDS_RDH(fx[2][0], x0, 2048);  SDVAR_LDS_RDH(fx[2][1], x0, 10240); SDVAR_LDS_RDH(fx[3][0], x0, 3072);  SDVAR_LDS_RDH(fx[3][1], x0, 11264);
-        if (t + 3 < nk) issue4(t + 3);
-        if (late) wait_next(t);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        SDVAR_H6_SLOT();
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) { SDVAR_MFMA3_16(acc[i][j], fx[i][0], fx[i][1], fw[j][0], fw[j][1]); }
-        if (!late) wait_next(t);
-        SDVAR_H6_SLOT();
     }
-    if (!late) SDVAR_H6_SLOT();
-
+    f32x4v acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
+    constexpr int XB = MT <= 2 ? 8 : 4;                      // K-steps per batch of X fragments (registers: XB x MT x 2 planes x 4)
+#pragma unroll
+    for (int b0 = 0; b0 < 8; b0 += XB) {
+        f16x8 fx[XB][MT][2];
+#pragma unroll
+        for (int s = 0; s < XB; ++s) {
+            const int t = wave + (b0 + s) * NW;
+            if (t < nk) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) fx[s][i][p] = *reinterpret_cast<const f16x8*>(px[i] + (size_t)t * xstep + p * a.xps);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < XB; ++s) {
+            const int t = wave + (b0 + s) * NW;
+            if (t < nk) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) { SDVAR_MFMA3_16(acc[i], fx[s][i][0], fx[s][i][1], fw[b0 + s][0], fw[b0 + s][1]); }
+            }
+        }
+    }
+    // cross-wave sum through LDS: red[wave][mt][lane] (16 bytes per lane), then wave mt (mod NW) owns row tile mt
+    f32x4v* red = reinterpret_cast<f32x4v*>(hsm);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) red[(wave * MT + i) * 64 + lane] = acc[i];
+    __syncthreads();
     const float wsi = a.wsi ? *a.wsi : 1.0f;
-    const int mrow = m0 + wm * 64 + l15, ncol = n0 + wn * 32 + 4 * lq;              // + 16 i, + 16 j
-    if (EPI == HEPI_QKV) {             // the wave's 32 columns are half a head: the row norms of the wave pair (wn, wn ^ 1) are exchanged through LDS
-        const QkvEpi& e = a.qk;
-        const int Cq = e.H * 64, which = n0 / Cq, nh = n0 - which * Cq + (wn >> 1) * 64, h = nh >> 6, cbase = (wn & 1) * 32;
-        const bool l2 = e.scale_mul != nullptr;
-        const int NP = e.fmt == 3 ? 2 : 1;
-        const size_t ps = (size_t)e.Lp * 64;
-        f32x4 bv[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) bv[j] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + ncol + 16 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
-        float v[4][2][4], sq[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            sq[i] = 0.f;
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int x = 0; x < 4; ++x) { v[i][j][x] = acc[i][j][x] * wsi + bv[j][x]; sq[i] += v[i][j][x] * v[i][j][x]; }
-        }
-        if (which != 2 && l2) {
-            float* ex = reinterpret_cast<float*>(hsm);           // [4 wn][128 rows]; the ring's last reads are behind the final barrier of the loop
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                sq[i] += __shfl_xor(sq[i], 16, 64); sq[i] += __shfl_xor(sq[i], 32, 64);
-                if (lq == 0) ex[wn * 128 + wm * 64 + 16 * i + l15] = sq[i];
-            }
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float other = ex[(wn ^ 1) * 128 + wm * 64 + 16 * i + l15];
-                sq[i] = (wn & 1) ? other + sq[i] : sq[i] + other;               // lower half of the head first in both waves
-            }
-        }
-        const float sm = (which == 0) ? (l2 ? expf(fminf(e.scale_mul[h], 4.605170249938965f)) : 0.03125f) : 1.0f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = mrow + 16 * i;
-            if (m >= a.M) continue;
-            const float nrm = l2 ? fmaxf(sqrtf(sq[i]), 1e-12f) : 1.0f;
-            const int r = m / e.l, tt = m - r * e.l;
-            if (which == 0) {
-                float* pq = e.q_out + (((size_t)r * e.H + h) * e.l + tt) * 64 + cbase + 4 * lq;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    f32x4 o;
-#pragma unroll
-                    for (int x = 0; x < 4; ++x) o[x] = l2 ? (v[i][j][x] / nrm) * sm : v[i][j][x] * sm;
-                    *reinterpret_cast<f32x4*>(pq + 16 * j) = o;
-                }
-            } else {
-                const bool nkk = l2 && which == 1;
-                uint16_t* pk = (which == 1 ? e.k_cache : e.v_cache) + ((size_t)r * e.H + h) * NP * ps + (size_t)(e.pos0 + tt) * 64 + cbase + 4 * lq;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    float kv[4];
-#pragma unroll
-                    for (int x = 0; x < 4; ++x) kv[x] = nkk ? v[i][j][x] / nrm : v[i][j][x];
-                    uint2 wh, wl;
-                    split4h_pk(kv, wh, wl);
-                    *reinterpret_cast<uint2*>(pk + 16 * j) = wh;
-                    if (e.fmt == 3) *reinterpret_cast<uint2*>(pk + ps + 16 * j) = wl;
-                }
-            }
-        }
-        return;
-    }
     float* outp = (EPI == HEPI_PARTIAL) ? a.out + (size_t)ks * a.M * a.ldo : a.out;
-    const bool fast = a.vec && n0 + HBN <= a.N;
+    const bool fast = a.vec && n0 + 16 <= a.N;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i) {
+        if (i % NW != wave) continue;                                      // wave-uniform
+        f32x4v sum = red[i * 64 + lane];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) h_store4<EPI>(a, outp, acc[i][j], wsi, mrow + 16 * i, ncol + 16 * j, fast);
-#undef SDVAR_H6_SLOT
+        for (int w = 1; w < NW; ++w) { const f32x4v q = red[(w * MT + i) * 64 + lane]; sum[0] += q[0]; sum[1] += q[1]; sum[2] += q[2]; sum[3] += q[3]; }
+        h_store4<EPI>(a, outp, sum, wsi, 16 * i + l15, n0 + 4 * lq, fast);
+    }
 }
 
 // out = epi( sum_s slab[s] + bias ) for the split-K path; the GELU variant writes planes
@@ -1597,26 +1521,19 @@ static void choose_cfg_h(int M, int N, int K, size_t ws_floats, int* bm_out, int
 
 static thread_local int* g_defer_h = nullptr;     // set per call by gemm_bf16x3_nt; thread-local: host threads may drive different model objects concurrently
 
-static int g_h2_stages = -1;      // variant of the 128 x 128 kernel: 6 (default, round 3) = 4-stage ring, the two waves of a SIMD alternate (1 - 7 % faster than 4: profiles/r03_l_v2pp_ab.log);
+static int g_h2_stages = -1;      // variant of the 128 x 128 kernel: 6 (default, round 3) = 4-stage ring, the two waves of a SIMD alternate (1 - 7 % faster than 4: profiles/r03_l_v2pp_ab.log;
+                                   // the same kernel on 16x16x32 MFMAs was built, passed the suite and was no faster - this tile is DMA / CU-intake bound, not power bound: profiles/r03_r_v6_ab.log);
                                    // 4 (round-2 default) = 3-stage ring with software-pipelined fragment reads (3-10 % faster than 3 on the shapes
                                    // that use this tile); 3 = 3-stage ring, reads in front of the MFMAs; 2 = 2-stage ring, two workgroups per CU (SDVAR_GEMM_H2_STAGES for A/B runs)
 
 template <int EPI>
 static int launch_h2_kernel(const GemmHArgs& a, int grid, hipStream_t stream) {
-    if (g_h2_stages < 0) { const char* e = getenv("SDVAR_GEMM_H2_STAGES"); g_h2_stages = (e && atoi(e) == 2) ? 2 : (e && atoi(e) == 3) ? 3 : (e && atoi(e) == 5) ? 5 : (e && atoi(e) == 4) ? 4 : (e && atoi(e) == 7) ? 7 : 6; }
+    if (g_h2_stages < 0) { const char* e = getenv("SDVAR_GEMM_H2_STAGES"); g_h2_stages = (e && atoi(e) == 2) ? 2 : (e && atoi(e) == 3) ? 3 : (e && atoi(e) == 5) ? 5 : (e && atoi(e) == 4) ? 4 : 6; }
     if (g_h2_stages == 5) {        // 5-stage ring (160 KB): four K-steps in flight
         const size_t lds = 5 * (size_t)H2_STAGE * sizeof(uint16_t);
         static LdsOptIn opt_in5;
         SDVAR_LDS_OPT_IN(opt_in5, lds, (const void*)gemm_f16x2_v2_kernel<EPI, 5>);
         hipLaunchKernelGGL((gemm_f16x2_v2_kernel<EPI, 5>), dim3(grid), dim3(512), lds, stream, a);
-        SDVAR_LAUNCH_CHECK();
-        return SDVAR_OK;
-    }
-    if (g_h2_stages == 7) {        // 4 stages (128 KB), ping-pong halves, 16x16x32 MFMAs
-        const size_t lds = 4 * (size_t)H2_STAGE * sizeof(uint16_t);
-        static LdsOptIn opt_in7;
-        SDVAR_LDS_OPT_IN(opt_in7, lds, (const void*)gemm_f16x2_v6_kernel<EPI>);
-        hipLaunchKernelGGL((gemm_f16x2_v6_kernel<EPI>), dim3(grid), dim3(512), lds, stream, a);
         SDVAR_LAUNCH_CHECK();
         return SDVAR_OK;
     }
@@ -1731,6 +1648,44 @@ static int launch_h4(GemmHArgs a, int epi, int split, hipStream_t stream) {
         case HEPI_BIAS: return launch_h4_kernel<HEPI_BIAS>(a, tiles, stream);
         case HEPI_BIAS_GELU_PLANES: return launch_h4_kernel<HEPI_BIAS_GELU_PLANES>(a, tiles, stream);
         default: return launch_h4_kernel<HEPI_GATED_RES>(a, tiles, stream);
+    }
+}
+
+template <int MT, int NW>
+static int launch_skinny_mt(GemmHArgs a, int epi, int split, hipStream_t stream) {
+    const int tiles_n = (a.N + 15) / 16, nkt = a.K / HBK;
+    const size_t lds = (size_t)NW * MT * 64 * 16;
+    GemmHArgs p = a;
+    p.split = split; p.k_per_split = (nkt + split - 1) / split;
+    const dim3 grid(tiles_n * split), block(64 * NW);
+    if (split > 1) {
+        size_t wsf = 0;
+        float* ws = splitk_workspace(&wsf);
+        if (!ws) return SDVAR_ERR_HIP;
+        p.out = ws; p.ldo = a.N;
+        hipLaunchKernelGGL((gemm_f16x2_skinny_kernel<MT, NW, HEPI_PARTIAL>), grid, block, lds, stream, p);
+        SDVAR_LAUNCH_CHECK();
+        if (g_defer_h) { *g_defer_h = split; return SDVAR_OK; }
+        return launch_reduce_h(a, ws, split, epi, stream);
+    }
+    switch (epi) {
+        case HEPI_BIAS: hipLaunchKernelGGL((gemm_f16x2_skinny_kernel<MT, NW, HEPI_BIAS>), grid, block, lds, stream, p); break;
+        case HEPI_BIAS_GELU_PLANES: hipLaunchKernelGGL((gemm_f16x2_skinny_kernel<MT, NW, HEPI_BIAS_GELU_PLANES>), grid, block, lds, stream, p); break;
+        default: hipLaunchKernelGGL((gemm_f16x2_skinny_kernel<MT, NW, HEPI_GATED_RES>), grid, block, lds, stream, p); break;
+    }
+    SDVAR_LAUNCH_CHECK();
+    return SDVAR_OK;
+}
+// M <= 80 rows: NW waves per workgroup and the K split so that a wave streams at most 8 K-steps
+template <int NW>
+static int launch_skinny(const GemmHArgs& a, int epi, int split, hipStream_t stream) {
+    const int mt = (a.M + 15) / 16;
+    switch (mt) {
+        case 1: return launch_skinny_mt<1, NW>(a, epi, split, stream);
+        case 2: return launch_skinny_mt<2, NW>(a, epi, split, stream);
+        case 3: return launch_skinny_mt<3, NW>(a, epi, split, stream);
+        case 4: return launch_skinny_mt<4, NW>(a, epi, split, stream);
+        default: return launch_skinny_mt<5, NW>(a, epi, split, stream);
     }
 }
 
@@ -1879,6 +1834,24 @@ int gemm_f16x2_nt(const uint16_t* X, size_t xps, const uint16_t* W, size_t wps, 
         split = (nkt + kps - 1) / kps;
     }
     g_last_cfg_h[0] = bm; g_last_cfg_h[1] = split; g_last_cfg_h[2] += (bm == 256 && tail > 0) ? 1 : 0; g_last_cfg_h[3] += (qkv && split == 1 && tail == 0) ? 1 : 0;
+    // bm code 16: the skinny kernel (M <= 80 rows, N % 16 == 0): chosen for every such shape unless a tile is forced; its own K split (a wave streams <= 8 K-steps)
+    static const int skinny_max = getenv("SDVAR_GEMM_SKINNY_MAX") ? atoi(getenv("SDVAR_GEMM_SKINNY_MAX")) : 80;          // A/B runs: 0 switches it off
+    if ((g_force_bm_h == 16 || (!g_force_bm_h && M <= skinny_max)) && M <= 80 && N % 16 == 0) {
+        const int nkt = K / HBK;
+        int sp = (nkt + 31) / 32;                            // 4 waves x 8 K-steps per workgroup (a 16-wave workgroup for K = 4096 is capped at 128 VGPRs and spills)
+        if (g_force_bm_h == 16 && g_force_split_h > sp) sp = g_force_split_h;
+        while (sp > 1 && (size_t)sp * M * N > wsf) --sp;
+        const int kps = (nkt + sp - 1) / sp;
+        // automatic choice: only where ONE workgroup streams the whole K (K <= 1024): with a split over workgroups (fc2, K = 4096) the slab path of the ring kernels is
+        // as fast or faster (M = 64: 13.5 against 14.9 us, profiles/r03_s_skinny_ab.log); a forced tile (tests) takes any K
+        if (kps <= 32 && (sp == 1 || (g_force_bm_h == 16 && N % 4 == 0))) {
+            sp = (nkt + kps - 1) / kps;
+            g_last_cfg_h[0] = 16; g_last_cfg_h[1] = sp;
+            if (trace) fprintf(stderr, "[gemm_f16x2] M=%d N=%d K=%d epi=%d -> skinny split=%d\n", M, N, K, epi, sp);
+            return launch_skinny<4>(a, epi, sp, stream);
+        }
+    }
+    if (bm == 16) bm = 32;
     if (qkv && split == 1 && tail == 0) {
         a.qk = *g_qkv_epi; a.split = 1; a.k_per_split = K / HBK;
         *g_qkv_fused = 1;

@@ -61,6 +61,7 @@ _SIGNATURES = {
     "sdvar_model_bind_shared_aln": (_I, [_P, _P, _P]),
     "sdvar_model_bind_head": (_I, [_P] * 6),
     "sdvar_model_begin": (_I, [_P, _I, _P, _P]),
+    "sdvar_model_begin_cond": (_I, [_P, _I, _P, _P]),
     "sdvar_model_export_prologue": (_I, [_P, _P, _P, _P, _P]),
     "sdvar_model_place_first": (_I, [_P, _P, _I, _P]),
     "sdvar_kv_len": (_I, [_P]),
@@ -68,6 +69,7 @@ _SIGNATURES = {
     "sdvar_kv_set_origin": (_I, [_P, _I]),
     "sdvar_head_forward": (_I, [_P, _P, _I, _P, _P]),
     "sdvar_embed_next": (_I, [_P, _P, _I, _P, _I, _I, _P]),
+    "sdvar_embed_next_at": (_I, [_P, _P, _I, _I, _P, _I, _I, _P]),
     "sdvar_stage_forward": (_I, [_P, _P, _I, _I, _P, _P]),
     "sdvar_stage_forward_masked": (_I, [_P, _P, _I, _I, _P, _P, _P]),
     "sdvar_quant_create": (_I, [_I, C.POINTER(_I), _I, _I, _I, _I, C.POINTER(_P)]),
@@ -203,6 +205,12 @@ class ModelCtx:
         self.B = labels.shape[0]
         _check(self.lib.sdvar_model_begin(self.h, self.B, _ptr(labels), _stream()))
 
+    def begin_cond(self, cond: torch.Tensor):
+        """The prologue from the conditioning rows (2B, C) themselves (`sos` of var.py:319-345) instead of labels."""
+        assert cond.dtype == torch.float32 and cond.is_cuda and cond.dim() == 2 and cond.shape[1] == self.Cw and cond.shape[0] % 2 == 0
+        self.B = cond.shape[0] // 2
+        _check(self.lib.sdvar_model_begin_cond(self.h, self.B, _ptr(cond.contiguous()), _stream()))
+
     def export_prologue(self):
         """(cond (2B,C), lvl_pos (1,L,C), first_token_map (2B,1,C)) of the current call, as SDVAR.init_param returns them."""
         f = dict(device=self.device, dtype=torch.float32)
@@ -215,6 +223,10 @@ class ModelCtx:
 
     def embed_next(self, nxt: torch.Tensor, s_next: int, x: torch.Tensor, ltot: int, tok_off: int):
         _check(self.lib.sdvar_embed_next(self.h, _ptr(nxt), s_next, _ptr(x), ltot, tok_off, _stream()))
+
+    def embed_next_at(self, nxt: torch.Tensor, s_next: int, pos_begin: int, x: torch.Tensor, ltot: int, tok_off: int):
+        """embed_next with explicit lvl_pos rows (the resumed sampler of var.py:319-443 counts positions from the stage it starts at)."""
+        _check(self.lib.sdvar_embed_next_at(self.h, _ptr(nxt), s_next, pos_begin, _ptr(x), ltot, tok_off, _stream()))
 
     def forward(self, x: torch.Tensor, s0: int, n: int, logits: torch.Tensor, bias: Optional[torch.Tensor] = None):
         """All blocks + head over stages s0 .. s0+n-1.  bias: explicit additive mask (l, K) instead of the block-causal rows (mask ablations)."""
@@ -249,7 +261,7 @@ class ModelCtx:
 
 
 class QuantCtx:
-    """sdvar_quant_t from the VQVAE state_dict (quantize.embedding / quantize.quant_resi.qresi_ls.*)."""
+    """sdvar_quant_t from the VQVAE state_dict (quantize.embedding / quantize.quant_resi.*, any of the three Phi layouts)."""
 
     def __init__(self, vae_sd: Dict[str, torch.Tensor], patch_nums: Sequence[int], max_batch: int, device, prefix: str = "quantize."):
         self.lib = load_library()
@@ -257,13 +269,13 @@ class QuantCtx:
         self.device = torch.device(device)
         self.codebook = _f32(vae_sd[prefix + "embedding.weight"], self.device)
         self.V, self.Cv = self.codebook.shape
-        n_phi = 0
-        while f"{prefix}quant_resi.qresi_ls.{n_phi}.weight" in vae_sd:
-            n_phi += 1
+        from .weights import phi_names_in
+        names = phi_names_in(vae_sd, prefix + "quant_resi.")          # PhiPartiallyShared (qresi_ls.<k>), PhiShared (qresi) or PhiNonShared (<k>): quant.py:27-32
+        n_phi = len(names)
         if n_phi == 0:
-            raise SdvarError("only the partially-shared Phi layout (share_quant_resi=4) is supported")
-        self.pw = [_f32(vae_sd[f"{prefix}quant_resi.qresi_ls.{k}.weight"], self.device) for k in range(n_phi)]
-        self.pb = [_f32(vae_sd[f"{prefix}quant_resi.qresi_ls.{k}.bias"], self.device) for k in range(n_phi)]
+            raise SdvarError(f"no Phi convolution under {prefix}quant_resi.* in the state_dict")
+        self.pw = [_f32(vae_sd[n + ".weight"], self.device) for n in names]
+        self.pb = [_f32(vae_sd[n + ".bias"], self.device) for n in names]
         pn = (_I * self.lad.S)(*self.lad.patch_nums)
         self.h = C.c_void_p()
         self.max_batch = int(max_batch)
@@ -549,18 +561,18 @@ class Sampler:
         return t
 
     def _sample_stage(self, logits: torch.Tensor, B: int, si: int, cfg: float, top_k: int, top_p: float, noise: Noise, draw: int,
-                      more_smooth: bool, f_hat: torch.Tensor, nxt: Optional[torch.Tensor], f_in: Optional[torch.Tensor] = None):
+                      more_smooth: bool, f_hat: torch.Tensor, nxt: Optional[torch.Tensor], f_in: Optional[torch.Tensor] = None, keep_masked: bool = False):
         """CFG + top-k/top-p + multinomial (var.py:199-202), then the token -> feature step (var.py:205-211): codebook rows of the sampled ids,
         or with more_smooth=True the gumbel-softmax mix of the masked logits (var.py:206-208)."""
         lad, V, L, qz = self.lad, self.t.V, self.lad.L, self.q
         l = lad.lens[si]
         q = noise.tensor(draw, B, l, V, self.dev)
-        masked = self._buf("masked", B * lad.lens[-1] * V) if more_smooth else None
+        masked = self._buf("masked", B * lad.lens[-1] * V) if (more_smooth or keep_masked) else None          # the CFG logits after top-k / top-p (-inf = removed)
         cfg_sample(logits, B, l, V, lad.cfg_t(cfg, si), top_k, top_p, q, noise.seed, draw, noise.image_offset, self.ids, lad.begin(si), L, masked)
         last = si == lad.S - 1
         if not more_smooth:
             qz.next(si, self.ids[:, lad.begin(si):], L, f_hat, None if last else nxt, B, f_in=f_in)
-            return
+            return masked
         assert f_in is None
         ratio = si / (lad.S - 1)
         tau = max(0.27 * (1 - ratio * 0.95), 0.005)                           # var.py:207
@@ -568,6 +580,7 @@ class Sampler:
         h = self._buf("h_soft", B * lad.lens[-1] * qz.Cv)
         qz.gumbel_mix(masked, B, l, ratio, tau, e, noise.seed, draw | GUMBEL_DRAW, noise.image_offset, h)
         qz.next_h(si, h, f_hat, None if last else nxt, B)
+        return masked
 
     @property
     def f_snap(self):
@@ -600,6 +613,58 @@ class Sampler:
         if _GUARD_ON:
             res.stats["f16x2_guard"] = f16x2_guard_collect()
         return res
+
+    # ---- VAR.autoregressive_infer_cfg_sd_helper1 (var.py:319-443): a run of `step` stages of the plain sampler from a handed-in state
+    def resume_ar(self, cond: torch.Tensor, current_step: int, step: int, next_map: Optional[torch.Tensor], f_hat: torch.Tensor, cfg: float, top_k: int,
+                  top_p: float, noise: Noise, more_smooth: bool = False):
+        """Stages current_step .. current_step + step - 1 with the conditioning rows `cond` (2B, C) = `sos`, the next-scale map `next_map`
+        (B, Cvae, pn, pn) of stage current_step and the running f_hat, which is updated IN PLACE as the reference's quantizer does (quant.py:191).
+        The KV cache starts EMPTY: var.py:368 toggles kv_caching(True), which drops it (basic_var.py:87), so the resumed stages attend to themselves
+        and to each other, not to the stages before current_step; and `cur_L` starts at 0 there too (var.py:352: the skipped stages do not advance
+        it), so stage si is embedded with the lvl_pos rows begin(si) - begin(current_step) .. - both are the reference's behaviour, pinned by
+        tests/golden/ar_d4_256_helper1.npz.  Draw index of stage si = si.
+        Returns the four histories of var.py:436-443: input maps (B, l, Cvae) of the stages run that are not stage 0, then the raw next map
+        (B, Cvae, pn', pn') after the last one (f_hat itself after the final stage); f_hat (the same tensor step + 1 times - the reference appends
+        the object it then updates in place); CFG-combined logits (B, l, V) as the sampler left them (-inf at the entries top-k / top-p removed:
+        helpers.py:10,15 mask the appended tensor in place); token ids (B, l)."""
+        m, qz, lad = self.t, self.q, self.lad
+        S, V, L, lens, Cv = lad.S, m.V, lad.L, lad.lens, qz.Cv
+        B = cond.shape[0] // 2
+        if not (0 <= current_step < S and step >= 1):
+            raise SdvarError(f"resume_ar: current_step {current_step}, step {step} (ladder has {S} stages)")
+        if f_hat.shape != (B, Cv, lad.patch_nums[-1], lad.patch_nums[-1]) or not f_hat.is_cuda or f_hat.dtype != torch.float32 or not f_hat.is_contiguous():
+            raise SdvarError("resume_ar: f_hat must be a contiguous fp32 GPU tensor (B, Cvae, pn_last, pn_last)")
+        if current_step > 0 and (next_map is None or next_map.numel() != B * Cv * lens[current_step]):
+            raise SdvarError(f"resume_ar: stage {current_step} needs its next-scale map (B, Cvae, {lad.patch_nums[current_step]}, {lad.patch_nums[current_step]})")
+        inputs, f_hist, logit_hist, id_hist = [], [], [], []
+        end = min(current_step + step, S)
+        with torch.cuda.device(self.dev):
+            m.begin_cond(cond)
+            m.kv_set_origin(current_step)
+            nxt = self.nxt[0]
+            for si in range(current_step, end):
+                l = lens[si]
+                if si == 0:
+                    m.place_first(self.x_t, l)
+                else:
+                    if si == current_step:
+                        rows = next_map.to(torch.float32).reshape(B, Cv, l).transpose(1, 2).contiguous()          # var.py:382
+                        nxt[:B * l * Cv].view(B, l, Cv).copy_(rows)
+                    inputs.append(nxt[:B * l * Cv].view(B, l, Cv).clone())
+                    m.embed_next_at(nxt, si, lad.begin(si) - lad.begin(current_step), self.x_t, l, 0)              # var.py:385 with cur_L counted from current_step
+                f_hist.append(f_hat)
+                m.forward(self.x_t, si, 1, self.logits_t)
+                masked = self._sample_stage(self.logits_t, B, si, cfg, top_k, top_p, noise, si, more_smooth, f_hat, nxt, keep_masked=True)
+                logit_hist.append(masked[:B * l * V].view(B, l, V).clone())           # var.py:405-408: the CFG logits, masked in place by helpers.py:10,15 before the caller sees them
+                id_hist.append(self.ids[:B, lad.begin(si):lad.begin(si) + l].clone())
+            f_hist.append(f_hat)
+            if end == S:
+                inputs.append(f_hat)                                                                               # quant.py:196: the last stage hands back f_hat twice
+            else:
+                pn = lad.patch_nums[end]
+                inputs.append(nxt[:B * pn * pn * Cv].view(B, pn * pn, Cv).transpose(1, 2).reshape(B, Cv, pn, pn).clone())
+            m.kv_set_len(0)
+        return inputs, f_hist, logit_hist, id_hist
 
     # ---- SDVAR.sdvar_autoregressive_infer_cfg_sd_test3 (var.py:604-865): the draft samples stages < entry_num, the target the rest
     def handoff(self, labels: torch.Tensor, cfg: float, top_k: int, top_p: float, noise: Noise, entry_num: int, sd_mask: int = 0,

@@ -181,6 +181,34 @@ class VAR(nn.Module):
         self.last_result = res
         return self.vae_proxy[0].fhat_to_img(res.f_hat.clone()).add_(1).mul_(0.5)
 
+    @torch.no_grad()
+    def autoregressive_infer_cfg_sd_helper1(self, B: int, current_step: int, step: int, next_token_map, f_hat, rng, sos, lvl_pos, cfg=1.5, top_k=0, top_p=0.0,
+                                            more_smooth=False):
+        """var.py:319-443: `step` stages of the sampler from stage `current_step`, from a handed-in (next_token_map, f_hat) and the conditioning rows `sos`
+        (2B, C) of SDVAR.init_param; returns (input_token_history, f_hat_history, logits_history, token_id_history) as the reference builds them.  `lvl_pos`
+        is the model's own table (init_param hands it back unchanged, var.py:598): it is checked for shape and otherwise taken from the bound weights.
+        `rng`: a CPU torch.Generator (the reference's stream on this host), an engine.Noise, or None (device Philox, fresh seed)."""
+        S = len(self.patch_nums)
+        assert 0 <= current_step < S and step >= 1
+        assert sos.shape == (2 * B, self.C), tuple(sos.shape)
+        assert lvl_pos is None or tuple(lvl_pos.shape[-2:]) == (self.L, self.C), tuple(lvl_pos.shape)
+        dev = self._device()
+        ctx = self.engine_ctx(B, 1)
+        qc = self.quant_ctx(ctx.max_batch)
+        if self._sampler is None or self._sampler.t is not ctx or self._sampler.q is not qc:
+            self._sampler = E.Sampler(ctx, qc)
+        if isinstance(rng, E.Noise):
+            noise = rng
+        elif rng is not None:
+            noise = E.Noise("torch", 0, generator=rng)
+        else:
+            noise = self._noise(None)
+        if not (f_hat.is_cuda and f_hat.dtype == torch.float32 and f_hat.is_contiguous()):
+            raise E.SdvarError("autoregressive_infer_cfg_sd_helper1: f_hat must be a contiguous fp32 GPU tensor (it is updated in place, quant.py:191)")
+        nm = None if (next_token_map is None or current_step == 0) else next_token_map.to(dev)
+        return self._sampler.resume_ar(sos.to(device=dev, dtype=torch.float32).contiguous(), current_step, step, nm, f_hat, cfg, top_k, top_p, noise,
+                                       more_smooth=bool(more_smooth))
+
     def forward(self, *a, **kw):
         raise NotImplementedError("teacher-forced training forward (var.py:217-259) is outside the sampling hot path")
 

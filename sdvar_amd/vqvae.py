@@ -120,20 +120,30 @@ class Encoder(nn.Module):
         self.norm_out, self.conv_out = _gn(bi), nn.Conv2d(bi, z, 3, 1, 1)
 
 
-class _PhiList(nn.Module):
+class _PhiList(nn.Module):          # PhiPartiallyShared (quant.py:219-229): quant_resi.qresi_ls.<k>
     def __init__(self, n, c):
         super().__init__()
         self.qresi_ls = nn.ModuleList([nn.Conv2d(c, c, 3, 1, 1) for _ in range(n)])
 
 
+class _PhiOne(nn.Module):           # PhiShared (quant.py:209-216): quant_resi.qresi
+    def __init__(self, c):
+        super().__init__()
+        self.qresi = nn.Conv2d(c, c, 3, 1, 1)
+
+
 class Quantizer(nn.Module):
-    """quantize.* tensors of the checkpoint (models/quant.py:15-43); the arithmetic lives in csrc/quant.hip."""
+    """quantize.* tensors of the checkpoint (models/quant.py:15-43) in the layout `share_quant_resi` selects there (quant.py:27-32): 0 = one Phi per scale
+    (PhiNonShared, an nn.ModuleList: quant_resi.<k>), 1 = one Phi for all (PhiShared), >= 2 = partially shared.  The arithmetic lives in csrc/quant.hip."""
     def __init__(self, vocab_size, Cvae, v_patch_nums, share_quant_resi=4):
         super().__init__()
-        if share_quant_resi < 2:
-            raise NotImplementedError("only the partially-shared Phi layout (share_quant_resi >= 2, reference default 4) is built")
         self.vocab_size, self.Cvae, self.v_patch_nums = vocab_size, Cvae, tuple(v_patch_nums)
-        self.quant_resi = _PhiList(share_quant_resi, Cvae)
+        if share_quant_resi == 0:
+            self.quant_resi = nn.ModuleList([nn.Conv2d(Cvae, Cvae, 3, 1, 1) for _ in range(len(v_patch_nums))])
+        elif share_quant_resi == 1:
+            self.quant_resi = _PhiOne(Cvae)
+        else:
+            self.quant_resi = _PhiList(share_quant_resi, Cvae)
         self.register_buffer("ema_vocab_hit_SV", torch.zeros(len(v_patch_nums), vocab_size))
         self.embedding = nn.Embedding(vocab_size, Cvae)
 

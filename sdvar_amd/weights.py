@@ -116,6 +116,29 @@ def var_state_dict(depth: int, patch_nums: Sequence[int], mode: str = "perf", se
 
 
 # ---- VQVAE ---------------------------------------------------------------------------------------------------------
+def phi_names(share_quant_resi: int, n_scales: int, prefix: str = "quantize.quant_resi."):
+    """Module names of the Phi convolutions for the three layouts of VectorQuantizer2 (quant.py:27-32): 0 = PhiNonShared (an nn.ModuleList: one Phi per scale,
+    "<k>"), 1 = PhiShared (one Phi, "qresi"), >= 2 = PhiPartiallyShared ("qresi_ls.<k>", the released checkpoints use 4)."""
+    if share_quant_resi == 0:
+        return [f"{prefix}{k}" for k in range(n_scales)]
+    if share_quant_resi == 1:
+        return [f"{prefix}qresi"]
+    return [f"{prefix}qresi_ls.{k}" for k in range(share_quant_resi)]
+
+
+def phi_names_in(sd, prefix: str = "quantize.quant_resi."):
+    """The Phi module names a VQVAE state_dict holds, whichever of the three layouts it was saved with ([] if none)."""
+    if f"{prefix}qresi.weight" in sd:
+        return [f"{prefix}qresi"]
+    for stem in (f"{prefix}qresi_ls.", prefix):
+        n = 0
+        while f"{stem}{n}.weight" in sd:
+            n += 1
+        if n:
+            return [f"{stem}{k}" for k in range(n)]
+    return []
+
+
 def _vae_shapes(V: int, Cvae: int, ch: int, patch_nums: Sequence[int], n_phi: int = 4, with_encoder: bool = True):
     """(name, shape, kind) for every VQVAE tensor; kind in conv_w|conv_b|gn_w|gn_b|emb|buf.
     Structure follows models/basic_vae.py:99-226 with ch_mult=(1,1,2,2,4), 2 res blocks, attention at the lowest
@@ -155,7 +178,7 @@ def _vae_shapes(V: int, Cvae: int, ch: int, patch_nums: Sequence[int], n_phi: in
             if lv == nres - 1: attn(f"decoder.up.{lv}.attn.{ib}", bi)
         if lv != 0: conv(f"decoder.up.{lv}.upsample.conv", bi, bi, 3)
     gn("decoder.norm_out", bi); conv("decoder.conv_out", bi, 3, 3)
-    for k in range(n_phi): conv(f"quantize.quant_resi.qresi_ls.{k}", Cvae, Cvae, 3)
+    for name in phi_names(n_phi, len(patch_nums)): conv(name, Cvae, Cvae, 3)          # n_phi = share_quant_resi of the reference constructor
     out.append(("quantize.ema_vocab_hit_SV", (len(patch_nums), V), "buf"))
     out.append(("quantize.embedding.weight", (V, Cvae), "emb"))
     conv("quant_conv", Cvae, Cvae, 3); conv("post_quant_conv", Cvae, Cvae, 3)
@@ -163,10 +186,10 @@ def _vae_shapes(V: int, Cvae: int, ch: int, patch_nums: Sequence[int], n_phi: in
 
 
 def vae_state_dict(patch_nums: Sequence[int], mode: str = "perf", seed: int = 1234, V: int = 4096, Cvae: int = 32,
-                   ch: int = 160, with_encoder: bool = True) -> "OrderedDict[str, torch.Tensor]":
+                   ch: int = 160, with_encoder: bool = True, share_quant_resi: int = 4) -> "OrderedDict[str, torch.Tensor]":
     stress = mode == "stress"
     sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
-    for name, shape, kind in _vae_shapes(V, Cvae, ch, patch_nums, with_encoder=with_encoder):
+    for name, shape, kind in _vae_shapes(V, Cvae, ch, patch_nums, n_phi=share_quant_resi, with_encoder=with_encoder):
         g = _gen(seed * 31 + 17, name)
         if kind == "conv_w":
             fan_in = shape[1] * shape[2] * shape[3]

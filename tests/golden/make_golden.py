@@ -285,6 +285,95 @@ def quant_fixture():
         print(f"[golden] quant_{lname} ok")
 
 
+def quant_layouts_fixture():
+    """The other two Phi layouts of VectorQuantizer2 (quant.py:27-32): share_quant_resi = 0 (PhiNonShared: one Phi per scale, quant.py:232-243) and 1 (PhiShared: a single
+    Phi, quant.py:209-216), 256 ladder, through the reference's get_next_autoregressive_input; the Phi index every stage picks is stored too."""
+    pns = LADDER_256
+    out = {"patch_nums": np.array(pns)}
+    for share in (0, 1):
+        vae = ref_models.VQVAE(vocab_size=4096, z_channels=32, ch=32, test_mode=True, share_quant_resi=share, v_patch_nums=pns)
+        sd_vae = vae_state_dict(pns, "stress", 1234, ch=32, share_quant_resi=share)
+        vae.load_state_dict(sd_vae, strict=True)                       # the key names of the layout are the reference's own
+        quant = orc.OracleQuant(sd_vae, pns)
+        assert len(quant.phi) == (len(pns) if share == 0 else 1)
+        rng = np.random.Generator(np.random.Philox(key=[11, share]))
+        B, S = 2, len(pns)
+        f_ref = torch.zeros(B, 32, pns[-1], pns[-1]); f_o = f_ref.clone()
+        nxt_digest, ids_all, picks = [], [], []
+        for si, pn in enumerate(pns):
+            ids = torch.from_numpy(rng.integers(0, 4096, size=(B, pn * pn)))
+            ids_all.append(ids.numpy().astype(np.int16))
+            h = vae.quantize.embedding(ids).transpose_(1, 2).reshape(B, 32, pn, pn)
+            phi_ref = vae.quantize.quant_resi[si / (S - 1)]
+            mods = [vae.quantize.quant_resi.qresi] if share == 1 else list(vae.quantize.quant_resi)
+            picks.append([m is phi_ref for m in mods].index(True))
+            assert quant.phi_of(si) == picks[-1], (share, si)
+            f_ref, nxt_ref = vae.quantize.get_next_autoregressive_input(si, S, f_ref, h)
+            f_o, nxt_o = quant.next_input(si, f_o, quant.embed_ids(ids, pn))
+            assert (f_ref - f_o).abs().max().item() <= 1e-5 and (nxt_ref - nxt_o).abs().max().item() <= 1e-5
+            nxt_digest.append(digest(nxt_ref))
+        out[f"s{share}_ids"] = np.concatenate(ids_all, 1); out[f"s{share}_f_hat"] = f_ref.numpy()
+        out[f"s{share}_next_digest"] = np.stack(nxt_digest); out[f"s{share}_phi_of"] = np.array(picks)
+    np.savez_compressed(os.path.join(OUT, "quant_layouts_256.npz"), **out)
+    print("[golden] quant_layouts_256 ok", out["s0_phi_of"].tolist())
+
+
+def helper1_fixture():
+    """VAR.autoregressive_infer_cfg_sd_helper1 (var.py:319-443) of the reference, d4, B = 2, portable noise (draw = stage): three chained calls
+    (stages 0-2, 3-6, 7-9), each handed the previous call's last next-map and f_hat.  Every call starts with an empty KV cache (var.py:368), so
+    calls 2 and 3 are NOT a continuation of plain AR - that is the behaviour pinned here."""
+    depth, pns, B, cfg, top_k, top_p, wseed = 4, LADDER_256, 2, 1.5, 900, 0.96, 1234
+    vae, var, sd_var, sd_vae = build_ref(depth, pns, "stress", wseed)
+    model, quant = orc.OracleVAR(sd_var, depth, pns), orc.OracleQuant(sd_vae, pns)
+    label_B = torch.tensor([3, 977])
+    V, S = 4096, len(pns)
+    plan = [(0, 3), (3, 4), (7, 3)]
+
+    def chain(seed, with_ref):
+        nfn = orc.array_noise(lambda d, B_, l, V_: exponential_noise(seed, d, B_, l, V_))
+        cond, lvl_pos, _ = model.prologue(label_B)
+        f_o, nm_o = torch.zeros(B, 32, pns[-1], pns[-1]), None
+        f_r, nm_r = f_o.clone(), None
+        margins, calls = [], []
+        for (cs, st) in plan:
+            inp_o, fh_o, lg_o, id_o = orc.resume_ar(model, quant, cond, cs, st, nm_o, f_o, cfg, top_k, top_p, nfn, margins=margins)
+            f_o, nm_o = fh_o[-1], inp_o[-1]
+            if not with_ref:
+                continue
+            with PortableMultinomial(seed, B, V) as pm:
+                pm.draw = cs                                            # draw index = stage, whatever stage the call starts at
+                inp_r, fh_r, lg_r, id_r = var.autoregressive_infer_cfg_sd_helper1(B, cs, st, nm_r, f_r, None, cond.clone(), lvl_pos.clone(), cfg=cfg, top_k=top_k, top_p=top_p)
+            assert len(inp_r) == len(inp_o) and len(fh_r) == st + 1 and len(lg_r) == len(id_r) == st
+            assert all(x is fh_r[0] for x in fh_r)                     # the reference's f_hat history is ONE aliased tensor (quant.py:191)
+            for a, b in zip(id_r, id_o):
+                assert torch.equal(a, b), ("helper1 ids", cs)
+            for a, b in zip(lg_r, lg_o):                           # the history holds the logits AFTER helpers.py:10,15 masked them in place (-inf at removed entries)
+                keep = torch.isfinite(a)
+                assert torch.equal(keep, torch.isfinite(b)) and keep.any(-1).all(), ("helper1 kept sets", cs)
+                assert (a[keep] - b[keep]).abs().max().item() <= LOGIT_RTOL * max(1.0, a[keep].abs().max().item()), ("helper1 logits", cs)
+            for a, b in zip(inp_r, inp_o):
+                assert a.shape == b.shape and (a - b).abs().max().item() <= 1e-5, ("helper1 inputs", cs, a.shape, b.shape)
+            assert (fh_r[-1] - fh_o[-1]).abs().max().item() <= 1e-5
+            f_r, nm_r = fh_r[-1], inp_r[-1]
+            calls.append((id_r, lg_r, inp_r, fh_r[-1].clone()))
+        return min(margins), calls
+
+    seed, m0 = pick_seed(lambda sd_: chain(sd_, False)[0], start=0)
+    _, calls = chain(seed, True)
+    out = dict(depth=depth, patch_nums=np.array(pns), B=B, labels=label_B.numpy(), cfg=cfg, top_k=top_k, top_p=top_p, g_seed=seed, wseed=wseed,
+               plan=np.array(plan), min_margin=m0)
+    for ci, (ids, lgs, inps, fh) in enumerate(calls):
+        out[f"c{ci}_ids"] = np.concatenate([i.numpy().astype(np.int16) for i in ids], 1)
+        out[f"c{ci}_logits_digest"] = np.stack([digest(torch.where(torch.isfinite(x), x, torch.zeros(()))) for x in lgs])     # over the kept entries
+        out[f"c{ci}_n_keep"] = np.stack([int(torch.isfinite(x).sum()) for x in lgs])
+        out[f"c{ci}_logits_row0"] = np.stack([x[0, 0].numpy() for x in lgs])                # token 0 of image 0, every stage of the call (-inf = removed)
+        out[f"c{ci}_inputs_digest"] = np.stack([digest(x) for x in inps])
+        out[f"c{ci}_next_map"] = inps[-1].numpy()
+        out[f"c{ci}_f_hat"] = fh.numpy()
+    np.savez_compressed(os.path.join(OUT, "ar_d4_256_helper1.npz"), **out)
+    print(f"[golden] ar_d4_256_helper1 ok: seed {seed}, min margin {m0:.2e}")
+
+
 def sd_fixture():
     """Reference SDVAR components that run: basic_token_matching known answers, round 1 of
     draft_generate_batch for gamma 1..3, chunk-verify == stage-wise (I2) with reference modules, sd_test3 hand-off."""
@@ -528,6 +617,8 @@ if __name__ == "__main__":
     check_multinomial_equivalence()
     if "all" in which or "sampler" in which: sampler_fixture()
     if "all" in which or "quant" in which: quant_fixture()
+    if "all" in which or "quant_layouts" in which: quant_layouts_fixture()
+    if "all" in which or "helper1" in which: helper1_fixture()
     if "all" in which or "ar" in which:
         plain_ar_fixture("ar_d4_256_stress", 4, LADDER_256, 2, [3, 977], 1.5, 900, 0.96, 0, "stress", 1234)
         plain_ar_fixture("ar_d6_256_stress", 6, LADDER_256, 2, [3, 977], 1.5, 900, 0.96, 0, "stress", 1234)

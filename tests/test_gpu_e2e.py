@@ -59,6 +59,44 @@ def test_plain_ar_vs_reference_fixture(dev, name, gm):
     ctx.close(); qc.close()
 
 
+def test_resumed_sampler_helper1_vs_reference_fixture(dev):
+    """VAR.autoregressive_infer_cfg_sd_helper1 through the module mirror (sdvar_amd.var.VAR) -> engine.Sampler.resume_ar -> sdvar_model_begin_cond /
+    sdvar_kv_set_origin / sdvar_embed_next_at, against the reference's own three chained calls (tests/golden/make_golden.py helper1): ids bit-exact,
+    CFG logits <= 1e-3, the next map and f_hat handed from call to call, the history shapes of var.py:436-443 and the in-place f_hat aliasing."""
+    from sdvar_amd.var import build_vae_var
+    g = golden("ar_d4_256_helper1")
+    pns = tuple(int(p) for p in g["patch_nums"])
+    lad = as_ladder(pns)
+    sd_var, sd_vae = state_dicts(4, pns, "stress", int(g["wseed"]))
+    vae, var = build_vae_var(dev, patch_nums=pns, depth=4)
+    sd_full = dict(vae.state_dict()); sd_full.update(sd_vae)
+    vae.load_state_dict(sd_full, strict=True); var.load_state_dict(sd_var, strict=True)
+    B = int(g["B"])
+    om = orc.OracleVAR(sd_var, 4, pns)
+    cond, lvl_pos, _ = om.prologue(torch.from_numpy(g["labels"]).long())
+    f = torch.zeros(B, 32, pns[-1], pns[-1], device=dev); nm = None
+    for ci, (cs, st) in enumerate(g["plan"].tolist()):
+        inp, fh, lgs, ids = var.autoregressive_infer_cfg_sd_helper1(B, cs, st, nm, f, E.Noise("host", int(g["g_seed"])), cond.to(dev), lvl_pos.to(dev),
+                                                                    cfg=float(g["cfg"]), top_k=int(g["top_k"]), top_p=float(g["top_p"]))
+        assert len(fh) == st + 1 and all(x is f for x in fh)                                  # one aliased tensor, updated in place
+        assert len(lgs) == len(ids) == st and len(inp) == len(g[f"c{ci}_inputs_digest"])
+        got = torch.cat(ids, 1).cpu().numpy()
+        assert np.array_equal(got, g[f"c{ci}_ids"].astype(np.int64)), (ci, _flip_report(got, g[f"c{ci}_ids"].astype(np.int64), lad) if cs == 0 else "")
+        for k, x in enumerate(lgs):
+            assert x.shape == (B, lad.lens[cs + k], 4096)
+            row, want = x[0, 0].cpu().numpy(), g[f"c{ci}_logits_row0"][k]                   # masked in place by the sampler, as helpers.py:10,15 do
+            fin = np.isfinite(want)
+            assert (np.isfinite(row) != fin).sum() <= 2 and np.abs(row[fin & np.isfinite(row)] - want[fin & np.isfinite(row)]).max() <= LOGIT_TOL, (ci, k)
+            assert abs(int(torch.isfinite(x).sum()) - int(g[f"c{ci}_n_keep"][k])) <= 2 * x.shape[0] * x.shape[1]      # a near-tie at the top-p edge may move one entry per token
+        for k, x in enumerate(inp[:-1]):
+            si = cs + k + (1 if cs == 0 else 0)
+            assert x.shape == (B, lad.lens[si], 32)
+        np.testing.assert_allclose(inp[-1].cpu().numpy(), g[f"c{ci}_next_map"], atol=1e-4)
+        np.testing.assert_allclose(f.cpu().numpy(), g[f"c{ci}_f_hat"], atol=1e-4)
+        nm = inp[-1]
+    var.invalidate_engine()
+
+
 @pytest.mark.parametrize("gm", GEMM_MODES)
 def test_d16_b1_vs_reference_fixture(dev, gm):
     g = golden("ar_d16_256_stress_B1")

@@ -266,6 +266,34 @@ def test_quant_next_vs_reference_fixture_and_oracle(dev, lname, pns):
     np.testing.assert_allclose(f.cpu().numpy(), g["f_hat"], atol=3e-5)         # the reference's own f_hat
 
 
+@pytest.mark.parametrize("share", [0, 1])
+def test_quant_phi_layouts_vs_reference_fixture(dev, share):
+    """VectorQuantizer2 built with share_quant_resi = 0 (PhiNonShared: quant_resi.<k>, one Phi per scale) or 1 (PhiShared: quant_resi.qresi), quant.py:27-32,
+    209-216, 232-243: QuantCtx reads either layout from the state_dict; f_hat against the reference's own (tests/golden/make_golden.py quant_layouts)."""
+    from sdvar_amd.weights import vae_state_dict
+    g = golden("quant_layouts_256")
+    pns = tuple(int(p) for p in g["patch_nums"])
+    sd_vae = vae_state_dict(pns, "stress", 1234, ch=32, share_quant_resi=share, with_encoder=False)
+    oq = orc.OracleQuant(sd_vae, pns)
+    qc = E.QuantCtx(sd_vae, pns, 2, dev)
+    assert len(qc.pw) == (len(pns) if share == 0 else 1)
+    B, L = 2, sum(p * p for p in pns)
+    ids_all = torch.from_numpy(g[f"s{share}_ids"].astype(np.int64)).to(dev).contiguous()
+    f = torch.zeros(B, 32, pns[-1], pns[-1], device=dev); f_o = torch.zeros(B, 32, pns[-1], pns[-1])
+    off = 0
+    for si, pn in enumerate(pns):
+        last = si == len(pns) - 1
+        nxt = None if last else torch.empty(B, pns[si + 1] ** 2, 32, device=dev)
+        qc.next(si, ids_all[:, off:], L, f, nxt, B)
+        f_o, nxt_o = oq.next_input(si, f_o, oq.embed_ids(ids_all[:, off:off + pn * pn].cpu(), pn))
+        off += pn * pn
+        assert (f.cpu() - f_o).abs().max().item() <= 2e-5, si
+        if not last:
+            assert (nxt.cpu() - nxt_o.view(B, 32, -1).transpose(1, 2)).abs().max().item() <= 2e-5, si
+    np.testing.assert_allclose(f.cpu().numpy(), g[f"s{share}_f_hat"], atol=3e-5)         # the reference's own f_hat
+    qc.close()
+
+
 def test_fp16_kv_cache_append_and_attention(dev):
     """BASELINE config P4: the cache holds fp16 (round-to-nearest-even of the fp32 values); attention widens while staging."""
     lib = E.load_library()
@@ -563,6 +591,46 @@ def test_gemm_f16x2_kernels_forced_tile(dev, M, N, K, split, epi, bm):
         got = out.cpu().double()
     err = (got - ref).abs().max().item()
     assert err <= 2e-5 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("M,N,K,split", [(16, 3072, 1024, 0), (1, 16, 32, 0), (16, 768, 4096, 0), (17, 1024, 4096, 0), (33, 2304, 768, 0), (64, 4096, 1024, 0), (80, 1024, 1024, 0),
+                                         (80, 768, 3072, 0), (48, 1024, 96, 0), (64, 1024, 4096, 8), (16, 528, 160, 3)])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_gemm_f16x2_skinny_kernel(dev, M, N, K, split, epi):
+    """The skinny kernel of stages 0 - 1 (M <= 80 rows: 16 output columns x all rows per workgroup, weights straight to registers, waves split K, LDS reduce):
+    every row-tile count 1..5, ragged M, K loops of 1 .. 128 steps (1 .. 4 workgroups along K, forced more), all three epilogues, against fp64; and it IS what the
+    automatic choice launches for these shapes."""
+    lib = E.load_library()
+    X, W, b = rnd(1, (M, K)), rnd(2, (N, K), 1 / math.sqrt(K)), rnd(3, (N,)).to(dev)
+    (Xp, _), (Wp, sc) = _planes_h(X, dev), _planes_h(W, dev, scaled=True)
+    rows_per_gate = 5 if M > 5 else 1
+    R = (M + rows_per_gate - 1) // rows_per_gate
+    res, gate = rnd(4, (M, N)).to(dev), rnd(5, (R, 2 * N)).to(dev)
+
+    def run(force):
+        out = res.clone() if epi == 2 else torch.full((M, N), float("nan"), device=dev)
+        outp = torch.zeros(2, (N + 31) // 32, M, 32, dtype=torch.int16, device=dev) if epi == 1 and N % 32 == 0 else None
+        if force:
+            E._check(lib.sdvar_debug_set_gemm_cfg(16, split))
+        try:
+            E.last_gemm_cfg()
+            E._check(lib.sdvar_op_gemm_f16x2(_p(Xp), M * K, _p(Wp), N * K, _p(sc), _p(b), _p(out), N, _p(outp), M * N, M, N, K, epi, _p(out) if epi == 2 else None, N,
+                                             _p(gate) if epi == 2 else None, rows_per_gate, 2 * N, _st()))
+            assert E.last_gemm_cfg()["bm"] == 16 or (not force and K > 1024), "not the skinny kernel"          # the automatic choice takes it up to K = 1024 (one workgroup per column panel)
+        finally:
+            E._check(lib.sdvar_debug_set_gemm_cfg(0, 0))
+        return _unplanes_h(outp).cpu() if epi == 1 else out.cpu().double()
+    if epi == 1 and N % 32:
+        pytest.skip("plane outputs are K-blocked by 32 columns")
+    ref = X.double() @ W.double().t() + b.cpu().double()
+    if epi == 1:
+        ref = F.gelu(ref, approximate="tanh")
+    elif epi == 2:
+        ref = res.cpu().double() + ref * gate.cpu()[:, :N].double().repeat_interleave(rows_per_gate, 0)[:M]
+    for force in (True, False):
+        got = run(force)
+        err = (got - ref).abs().max().item()
+        assert err <= 2e-5 * max(1.0, ref.abs().max().item()), (force, err)
 
 
 @pytest.mark.parametrize("bm", [32, 64, 128, 256, 512])

@@ -58,8 +58,10 @@ PFMTS = [3, 2]          # bf16x3 and f16x2 operand planes
 @pytest.mark.parametrize("B,Cin,Cout,H,taps,res,split", [(2, 64, 96, 8, 9, False, 0), (1, 32, 32, 16, 9, False, 0), (2, 160, 160, 12, 9, True, 0),
                                                          (2, 320, 160, 6, 1, False, 0), (2, 128, 320, 5, 9, True, 3), (1, 640, 1920, 4, 1, False, 4),
                                                          (3, 96, 40, 7, 9, False, 2), (2, 32, 64, 9, 1, False, 0), (2, 64, 64, 9, 1, False, 0)])
-def test_conv_matches_torch(dev, B, Cin, Cout, H, taps, res, split, pf):
+def test_conv_matches_torch(dev, B, Cin, Cout, H, taps, res, split, pf, monkeypatch):
     lib = E.load_library()
+    if pf == 2 and (B + H) % 2:          # half of the f16x2 cases on the 32x32x16 ping-pong loop (the default is the 16x16x32 one)
+        monkeypatch.setenv("SDVAR_CONV_PP", "1")
     W = H + 1                                                                  # non-square on purpose
     x = rnd(1, (B, Cin, H, W)).to(dev)
     k = 3 if taps == 9 else 1
@@ -137,9 +139,13 @@ def test_decoder_small_width_matches_pytorch(dev, cm):
     assert (sub - got[:1]).abs().max().item() <= 2e-5
 
 
-@pytest.mark.parametrize("cm", ["bf16x3", "f16x2"])
-def test_decoder_reference_width_matches_pytorch(dev, cm):
-    """vae_ch160v4096z32 geometry (the checkpoint the reference loads): ch = 160, widths 640/320/160, 256^2 output."""
+@pytest.mark.parametrize("cm", ["bf16x3", "f16x2", "f16x2:pp1", "f16x2:pp0"])
+def test_decoder_reference_width_matches_pytorch(dev, cm, monkeypatch):
+    """vae_ch160v4096z32 geometry (the checkpoint the reference loads): ch = 160, widths 640/320/160, 256^2 output.  The f16x2 conv kernel has three K-loops
+    (SDVAR_CONV_PP: 2 = ping-pong on v_mfma_f32_16x16x32_f16 with the 16-byte epilogue, the default; 1 = ping-pong on 32x32x16; 0 = the round-2 loop):
+    all three against PyTorch, fused GroupNorm statistics and the up-sampling phase scatter included."""
+    if ":pp" in cm:
+        monkeypatch.setenv("SDVAR_CONV_PP", cm[-1]); cm = "f16x2"
     vae, ctx, f_hat = _decode_pair(dev, 160, 2, conv_mode=cm)
     got = ctx.decode(f_hat)
     want = vae.fhat_to_img_torch(f_hat.clone())
