@@ -24,6 +24,8 @@ int gemm_f16x2_qkv(const uint16_t* X, size_t xps, const uint16_t* W, size_t wps,
                    const float* scale_mul, float* q_out, void* k_cache, void* v_cache, int l, int H, int Lp, int pos0, int kv_fmt, int* defer, int* fused, hipStream_t stream);
 int silu_rows(const float* x, float* y, int n, hipStream_t stream);
 int add_row_vector(const float* src, const float* vec, float* out, int rows, int cols, hipStream_t stream);
+int ada_gather(const long long* labels, const float* tab, size_t row_floats, int depth, int C, float* ada, size_t blk_stride, float* ada_head, int B, int num_classes,
+               hipStream_t stream);
 int prologue(const long long* labels, const float* cond_in, const float* class_emb, const float* pos_start, const float* lvl_pos, float* cond, float* x0, int B, int C, int num_classes, hipStream_t stream);
 int build_lvl_pos(const float* lvl_embed, const float* pos, const int* stage_of_tok, float* out, int L, int C, hipStream_t stream);
 int embed_next(const float* nxt, const float* Ww, const float* bw, const float* lvl_pos, float* x, int B, int l, int C, int t0, int ltot, int tok_off, hipStream_t stream);
@@ -128,6 +130,11 @@ struct sdvar_model {
     int kv_fmt, Lkv;     // cache format handed to the kernels (0 fp32, 1 fp16, 2 planes) and its row capacity
     const float *shared_w = nullptr, *shared_b = nullptr;   // shared_aln=True: shared_ada_lin.1.{weight (6C,C), bias} (var.py:16-19, 81)
     float* gss_lin = nullptr;  // owned (Rmax, 6C): shared_ada_lin(cond) of the current call
+    // owned (num_classes + 1, depth * 6C + 2C) + scratch: the adaLN parameters of EVERY class (ada_lin / head_nm.ada_lin of silu(class_emb)), built by the first
+    // sdvar_model_begin after a bind with the GEMMs that call used to run (30 launches streaming 25 MB of fp32 weights each, 1.4 ms per d12 + d16 step); a call
+    // gathers its 2B rows.  0.4 GB for d16, 1.4 GB for d30 - HBM the card has.  Not for shared_aln models (one GEMM per call there) nor for sdvar_model_begin_cond.
+    float* ada_tab = nullptr;
+    bool ada_tab_ready = false;
     float* ws_own = nullptr;   // this model's split-K slabs: two models of one host thread may run on different streams
     int lens[SDVAR_MAX_STAGES], cum[SDVAR_MAX_STAGES];
     // borrowed
@@ -266,7 +273,7 @@ int sdvar_model_create(const sdvar_model_desc* desc, sdvar_model_t** out) {
 
 int sdvar_model_destroy(sdvar_model_t* m) {
     if (!m) return SDVAR_OK;
-    float* bufs[] = {m->lvl_pos, m->cond, m->cond_silu, m->x0, m->ada, m->ada_head, m->xn, m->qkv, m->qbuf, m->att, m->hid, m->ws_own, m->gss_lin, m->head_wsc};
+    float* bufs[] = {m->lvl_pos, m->cond, m->cond_silu, m->x0, m->ada, m->ada_head, m->xn, m->qkv, m->qbuf, m->att, m->hid, m->ws_own, m->gss_lin, m->head_wsc, m->ada_tab};
     for (float* p : bufs) if (p) (void)hipFree(p);
     if (m->stage_of_tok) (void)hipFree(m->stage_of_tok);
     uint16_t* pb[] = {m->xn_p, m->att_p, m->hid_p, m->head_wp};
@@ -282,7 +289,7 @@ int sdvar_model_bind_embed(sdvar_model_t* m, const float* class_emb, const float
     SDVAR_CHECK_ARG(m && class_emb && pos_start && pos_1LC && lvl_embed && word_w && word_b, "bind_embed: null argument");
     m->class_emb = class_emb; m->pos_start = pos_start; m->word_w = word_w; m->word_b = word_b;
     SDVAR_TRY(build_lvl_pos(lvl_embed, pos_1LC, m->stage_of_tok, m->lvl_pos, m->L, m->C, (hipStream_t)stream));
-    m->embed_bound = true;
+    m->embed_bound = true; m->ada_tab_ready = false;
     return SDVAR_OK;
 }
 
@@ -315,7 +322,7 @@ int sdvar_model_bind_block(sdvar_model_t* m, int32_t i, const float* ada_w, cons
             SDVAR_TRY(split_planes_f16(ws[k], wp[k], rows[k], cols[k], (size_t)rows[k] * cols[k], b.wsc + 4 * k, s));
         }
     }
-    b.bound = true;
+    b.bound = true; m->ada_tab_ready = false;
     return SDVAR_OK;
 }
 
@@ -328,7 +335,7 @@ int sdvar_model_bind_shared_aln(sdvar_model_t* m, const float* w, const float* b
 
 int sdvar_model_bind_head(sdvar_model_t* m, const float* nm_w, const float* nm_b, const float* head_w, const float* head_b, void* stream) {
     SDVAR_CHECK_ARG(m && nm_w && nm_b && head_w && head_b, "bind_head: null argument");
-    m->nm_w = nm_w; m->nm_b = nm_b; m->head_w = head_w; m->head_b = head_b; m->head_bound = true;
+    m->nm_w = nm_w; m->nm_b = nm_b; m->head_w = head_w; m->head_b = head_b; m->head_bound = true; m->ada_tab_ready = false;
     if (m->d.gemm_mode == 1) SDVAR_TRY(split_planes(head_w, m->head_wp, m->d.vocab, m->C, (size_t)m->d.vocab * m->C, (hipStream_t)stream));
     if (m->d.gemm_mode == 2) {
         SDVAR_TRY(weight_scale_f16(head_w, (size_t)m->d.vocab * m->C, m->head_wsc, (hipStream_t)stream));
@@ -368,7 +375,25 @@ static int model_begin_impl(sdvar_model_t* m, int32_t B, const int64_t* labels, 
         SDVAR_TRY(prologue((const long long*)labels, cond_in, m->class_emb, m->pos_start, m->lvl_pos, m->cond, m->x0, B, C, m->d.num_classes, s));
         SDVAR_TRY(silu_rows(m->cond, m->cond_silu, R * C, s));
     }
-    // adaLN parameters of every block: stage-invariant, computed once per call instead of once per stage
+    // adaLN parameters of every block: stage-invariant, computed once per call instead of once per stage - or, for label-conditioned calls, once per BIND:
+    static const bool tab_off = getenv("SDVAR_ADALN_TABLE") && atoi(getenv("SDVAR_ADALN_TABLE")) == 0;          // A/B runs
+    const size_t NC = (size_t)m->d.num_classes + 1, row = (size_t)m->d.depth * 6 * C + 2 * C;
+    if (labels && !m->shared_w && !tab_off && NC * (row + C) * sizeof(float) <= ((size_t)8 << 30)) {
+        if (!m->ada_tab_ready) {
+            if (!m->ada_tab) SDVAR_TRY(dmalloc(&m->ada_tab, NC * (row + C)));
+            float* sil = m->ada_tab + NC * row;                  // silu(class_emb), scratch behind the table
+            ProfScope ps(9, 2.0 * NC * (double)row * C, 4.0 * (double)row * (C + NC), s);
+            SDVAR_TRY(silu_rows(m->class_emb, sil, (int)(NC * C), s));
+            for (int i = 0; i < m->d.depth; ++i)
+                SDVAR_TRY(gemm_f32_nt(sil, C, m->blk[i].ada_w, m->blk[i].ada_b, m->ada_tab + (size_t)i * 6 * C, (int)row, (int)NC, 6 * C, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, s));
+            SDVAR_TRY(gemm_f32_nt(sil, C, m->nm_w, m->nm_b, m->ada_tab + (size_t)m->d.depth * 6 * C, (int)row, (int)NC, 2 * C, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, s));
+            m->ada_tab_ready = true;
+        }
+        ProfScope ps(7, 0, 8.0 * R * (double)row, s);
+        SDVAR_TRY(ada_gather((const long long*)labels, m->ada_tab, row, m->d.depth, C, m->ada, (size_t)m->Rmax * 6 * C, m->ada_head, B, m->d.num_classes, s));
+        m->begun = true;
+        return SDVAR_OK;
+    }
     if (m->shared_w) {          // shared_aln: one Linear for all blocks (var.py:192), each block adds its ada_gss (basic_var.py:153-154)
         ProfScope ps(9, 2.0 * R * 6.0 * C * C, 4.0 * (6.0 * C * C + R * 7.0 * C), s);
         SDVAR_TRY(gemm_f32_nt(m->cond_silu, C, m->shared_w, m->shared_b, m->gss_lin, 6 * C, R, 6 * C, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, s));

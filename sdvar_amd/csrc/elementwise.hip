@@ -558,6 +558,25 @@ int prologue(const long long* labels, const float* cond_in, const float* class_e
     return SDVAR_OK;
 }
 
+// adaLN parameters of a call from the per-class table (api.hip: model_begin): row r of block i = tab[label(r)][i * 6C ..], head row = tab[label(r)][depth * 6C ..]
+__global__ __launch_bounds__(256) void ada_gather_kernel(const long long* __restrict__ labels, const float* __restrict__ tab, size_t row_floats, int depth, int C,
+                                                         float* __restrict__ ada, size_t blk_stride, float* __restrict__ ada_head, int B, int num_classes) {
+    const int r = blockIdx.x, i = blockIdx.y;
+    long long lab = (r < B) ? labels[r] : (long long)num_classes;
+    if (lab < 0 || lab > num_classes) lab = num_classes;
+    const int n4 = (i < depth ? 6 * C : 2 * C) / 4;
+    const float4* src = reinterpret_cast<const float4*>(tab + (size_t)lab * row_floats + (size_t)i * 6 * C);
+    float4* dst = reinterpret_cast<float4*>(i < depth ? ada + (size_t)i * blk_stride + (size_t)r * 6 * C : ada_head + (size_t)r * 2 * C);
+    for (int c = threadIdx.x; c < n4; c += 256) dst[c] = src[c];
+}
+
+int ada_gather(const long long* labels, const float* tab, size_t row_floats, int depth, int C, float* ada, size_t blk_stride, float* ada_head, int B, int num_classes,
+               hipStream_t stream) {
+    hipLaunchKernelGGL(ada_gather_kernel, dim3(2 * B, depth + 1), dim3(256), 0, stream, labels, tab, row_floats, depth, C, ada, blk_stride, ada_head, B, num_classes);
+    SDVAR_LAUNCH_CHECK();
+    return SDVAR_OK;
+}
+
 // lvl_pos[t][c] = lvl_embed[stage(t)][c] + pos_1LC[t][c]
 __global__ void build_lvl_pos_kernel(const float* __restrict__ lvl_embed, const float* __restrict__ pos, const int* __restrict__ stage_of_tok,
                                      float* __restrict__ out, int L, int C) {

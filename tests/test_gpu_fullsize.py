@@ -201,8 +201,8 @@ def test_d36_shared_aln_width(dev):
 
 @pytest.mark.parametrize("kv_fp16", [False, True])
 def test_qkv_epilogue_equals_qk_norm_append(dev, kv_fp16):
-    """From M = 1024 rows the QKV launch of a block is unsplit and finishes q and k in its epilogue (gemm_f16x2.hip HEPI_QKV; qk_norm_append then runs its
-    v-only pass).  Same stages with the epilogue switched off: logits within 2e-5 of the logits' scale, both cache formats (two fp16 planes / one)."""
+    """An unsplit QKV launch of a block finishes q, k AND v in its epilogue (gemm_f16x2.hip HEPI_QKV: bias, head L2 norm, q scale, k / v rows appended to the
+    cache planes) and qk_norm_append does not run at all.  Same stages with the epilogue switched off (the separate qk_norm_append_rows pass): logits within 2e-5 of the logits' scale, both cache formats (two fp16 planes / one)."""
     pns, B, depth = LADDER_256, 8, 16
     lad = as_ladder(pns)
     sd = var_state_dict_device(depth, pns, dev, mode="stress")
