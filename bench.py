@@ -366,7 +366,7 @@ def main():
                 kname, note = "gemm_bf16x3_{v3,v2,}_kernel", "peak = dense bf16 MFMA peak / 6 (split-operand products per fp32 product)"
             elif tc.gemm_mode == "f16x2":
                 peak = PEAK_BF16_MFMA_TFLOPS / 3.0   # 3 fp16 MFMA products per algorithmic fp32 product (f16 MFMA = bf16 MFMA rate)
-                kname, note = "gemm_f16x2_{v4,v3,v2,small}_kernel", "peak = dense f16 MFMA peak / 3 (split-operand products per fp32 product)"
+                kname, note = ("gemm_f16x2_{v5,v3,v2}_kernel" if name == "gemm" else "gemm_f16x2_{small_pp,small,skinny,v2}_kernel"), "peak = dense f16 MFMA peak / 3 (split-operand products per fp32 product)"
             else:
                 peak, kname, note = PEAK_F32_MFMA_TFLOPS, "gemm_f32_nt_kernel", "peak = fp32-in MFMA"
             regime = "launches with M >= 1024 rows (stages 6-9, large verify chunks): matrix-pipe regime" if name == "gemm" else \

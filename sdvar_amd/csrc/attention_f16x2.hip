@@ -91,7 +91,11 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 //          almost every tile.  Exact in exact arithmetic: O and l carry the same reference.
 //   pp     P^T operand planes of the two k16 steps
 constexpr float ATT_DEFER = 6.0f;
-__device__ __forceinline__ void softmax_tile(f32x16& s, int k0, int vis_q, int lh, float& M_run, float& l_run, f32x16& o0, f32x16& o1, f16x8 (&pp)[2][2]) {
+struct NoMid { __device__ __forceinline__ void operator()() const {} };
+// `mid` runs between the exponentials and the two-plane split of P: the two-slot schedule of the 8-wave kernel issues its V fragment reads there (a wave can have
+// 15 LDS requests outstanding: 8 K reads before the arithmetic, 16 V reads in the middle, all landed when the split is done)
+template <class Mid = NoMid>
+__device__ __forceinline__ void softmax_tile(f32x16& s, int k0, int vis_q, int lh, float& M_run, float& l_run, f32x16& o0, f32x16& o1, f16x8 (&pp)[2][2], Mid mid = Mid()) {
     const float L2E = 1.4426950408889634f;
     if (__builtin_amdgcn_ballot_w64(k0 + AKT > vis_q) != 0) {            // only the tiles that reach past some query's visible keys: a real (wave-uniform) branch
         asm volatile("" ::: "memory");                                   // ... the 32 compare / select instructions are not to be if-converted into every tile
@@ -135,6 +139,7 @@ __device__ __forceinline__ void softmax_tile(f32x16& s, int k0, int vis_q, int l
         lsum = __uint_as_float(sw2[0]) + __uint_as_float(sw2[1]);
     }
     l_run += lsum;
+    mid();
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         u32x4 ph, pl;
@@ -296,12 +301,24 @@ __global__ __launch_bounds__(256, 2) void attention_f16x2_kernel(AttnHArgs a) {
 // so in every slot one wave of a SIMD feeds the matrix pipe and the other one the vector ALU / LDS.  A tile is completely in registers after V2(t-1): the ring
 // (3 stages of 16 KB) holds three tiles in flight.  Tile t+1 must have landed before ANY wave reads it in slot 4t+3: every wave waits for its own share
 // (counted vmcnt) at the end of the slot before - PV(t) for the early half, V1(t) for the late half; the waits stand in both segments of both halves.
-constexpr int PP_NST = 3;
+//
+// SCHED = 1 (default since the end of round 3): TWO slots per tile.  tools/micro/valu_rate.hip: ONE wave issues a vector instruction every ~5 cycles, two waves of a SIMD
+// together one every ~2.5 (profiles/r03_B_valu_rate.log) - a wave alone in its softmax slot runs the vector ALU at half its rate, and the in-kernel stamps of the
+// four-slot schedule show exactly that: ~1050 cycles for the ~110 instructions of V1, plus ~710 for the bare fragment reads of V2, against 384 cycles of MFMA
+// in the partner's slot (tile total 3550 cycles per half).  So the slots are re-cut to balance one wave's vector work against BOTH of the partner's MFMA groups:
+//     slot (s_barrier between slots):   2t                  2t+1
+//     waves 0-3:                        M(t)                V(t)
+//     waves 4-7 (one slot behind):      V(t-1)              M(t)
+//   M(t) = PV(t-1) then S(t): 24 MFMAs (768 matrix-pipe cycles), every fragment already in registers; then the counted vmcnt wait for tile t+1
+//   V(t) = the fragment reads of V(t) and K(t+1) are ISSUED first (they land under the arithmetic), then mask / online softmax / split of tile t, the LDS-DMA of
+//          tile t+3 into the stage tile t-1 left (its last reader, the late half's V(t-1), ended with the previous slot), lgkmcnt(0)
+// Ring of 4 stages (64 KB): tiles t (V part still unread), t+1, t+2 resident or in flight while t+3 is requested.
 
-template <int NKP>
+template <int NKP, int SCHED>
 __global__ __launch_bounds__(512, 2) void attention_f16x2_pp_kernel(AttnHArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint16_t att_sm[];
     constexpr int ASTAGE = 2 * NKP * APL;         // one K tile + one V tile, NKP planes each
+    constexpr int PP_NST = SCHED == 0 ? 3 : 2 * SCHED + 2;         // ring depth: 3 (four-slot schedule), 4 / 6 / 8 (two-slot schedule); the launcher sizes the LDS the same way
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -362,12 +379,15 @@ __global__ __launch_bounds__(512, 2) void attention_f16x2_pp_kernel(AttnHArgs a)
     const int ntiles = (kend + AKT - 1) / AKT;
 
     f16x8 kf[4][NKP], vf[2][2][NKP];
-    auto read_tile = [&](int t) {               // K and V^T fragments of tile t -> registers
+    auto read_k = [&](int t) {                  // K fragments of tile t -> registers
         const uint32_t sb = lds0 + (uint32_t)((t % PP_NST) * ASTAGE) * 2u;
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int p = 0; p < NKP; ++p) SDVAR_LDS_RDP(kf[c][p], sb + koff + (uint32_t)(p * APL * 2 + 16 * ((2 * c + lh) ^ swk)));
+    };
+    auto read_v = [&](int t) {                  // V^T fragments of tile t -> registers
+        const uint32_t sb = lds0 + (uint32_t)((t % PP_NST) * ASTAGE) * 2u;
         const uint32_t sv0 = sb + voff0, sv1 = sv0 ^ 64u;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -377,6 +397,7 @@ __global__ __launch_bounds__(512, 2) void attention_f16x2_pp_kernel(AttnHArgs a)
                 vf[j][1][p] = lds_read_tr8(sv1, j * 2048 + p * (APL * 2));
             }
     };
+    auto read_tile = [&](int t) { read_k(t); read_v(t); };
 #define SDVAR_PP_SLOT() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #ifdef SDVAR_ATT_STAMPS          // slot boundaries of tile 10 (waves 0 and 4 of workgroup (0, 0, 0)) -> stamps[16 (wave / 4) + k]; kernel phases -> stamps[32 ..]
     unsigned long long stm[5] = {0, 0, 0, 0, 0}, wsr[4] = {0, 0, 0, 0}, wsc[4] = {0, 0, 0, 0};
@@ -386,6 +407,78 @@ __global__ __launch_bounds__(512, 2) void attention_f16x2_pp_kernel(AttnHArgs a)
 #define SDVAR_PP_STAMP(k) do { } while (0)
 #endif
 
+    if constexpr (SCHED >= 1) {
+        // D = request distance in tiles (ring of D + 1 stages): tile t + D is requested in V(t).  SCHED 1: D = 3 (64 KB), 2: D = 5 (96 KB), 3: D = 7 (128 KB)
+        constexpr int D = PP_NST - 1;
+        auto wait_tiles = [&](int n) {              // of this wave's requests at most the newest n tiles (NKP instructions each) may stay in flight
+            switch (n * NKP) {
+                case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+                case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+                case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+                case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+                case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+                case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+                case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+            }
+        };
+        // requests before the loop: tiles 0 .. D-1 (tile D follows in V(0)); tile 0 must have landed before its K fragments are read
+        for (int t = 0; t < D && t < ntiles; ++t) issue(t);
+        wait_tiles(min(D, ntiles) - 1);
+        SDVAR_PP_SLOT();
+        if (late) SDVAR_PP_SLOT();                                  // wave-uniform
+        read_k(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        f16x8 pp[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { pp[j][0] = f16x8{0, 0, 0, 0, 0, 0, 0, 0}; pp[j][1] = pp[j][0]; }
+#ifdef SDVAR_ATT_STAMPS
+        wsr[1] = __builtin_amdgcn_s_memrealtime(); wsc[1] = __builtin_amdgcn_s_memtime();
+#endif
+#pragma unroll 1
+        for (int t = 0; t < ntiles; ++t) {
+            const int k0 = t * AKT;
+            SDVAR_PP_STAMP(0);
+            // ---------------- M(t): PV(t-1), S(t)
+            f32x16 s;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[i] = 0.f;
+            if (wave_active) {
+                if (t > 0) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        mfma_planes<NKP>(o0, vf[j][0], pp[j]);
+                        mfma_planes<NKP>(o1, vf[j][1], pp[j]);
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) mfma_planes<NKP>(s, kf[c], qp[c]);
+            }
+            if (t + 1 < ntiles) wait_tiles(min(D - 2, ntiles - 2 - t));          // tile t + 1 landed; the tiles requested after it stay in flight
+            SDVAR_PP_SLOT(); SDVAR_PP_STAMP(1);
+            // ---------------- V(t): reads first, then the arithmetic
+            if (t + 1 < ntiles) read_k(t + 1);
+            if (t + D < ntiles) issue(t + D);
+            __builtin_amdgcn_sched_barrier(0);
+            auto mid = [&]() { __builtin_amdgcn_sched_barrier(0); read_v(t); __builtin_amdgcn_sched_barrier(0); };
+            if (wave_active) softmax_tile(s, k0, vis_q, lh, M_run, l_run, o0, o1, pp, mid);
+            else mid();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            SDVAR_PP_SLOT(); SDVAR_PP_STAMP(2);
+        }
+        // ---------------- M(ntiles): the last PV
+        if (wave_active) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                mfma_planes<NKP>(o0, vf[j][0], pp[j]);
+                mfma_planes<NKP>(o1, vf[j][1], pp[j]);
+            }
+        }
+        SDVAR_PP_SLOT();
+        if (!late) SDVAR_PP_SLOT();                                 // matches the late half's extra slot
+    } else {
     const int npre = min(PP_NST, ntiles);
     for (int t = 0; t < npre; ++t) issue(t);
     // tile 0 landed: at most the other npre - 1 tiles (NKP instructions each) in flight
@@ -441,6 +534,7 @@ __global__ __launch_bounds__(512, 2) void attention_f16x2_pp_kernel(AttnHArgs a)
         SDVAR_PP_SLOT(); SDVAR_PP_STAMP(4);
     }
     if (!late) SDVAR_PP_SLOT();                                 // matches the late half's extra slot
+    }
 #ifdef SDVAR_ATT_STAMPS
     wsr[2] = __builtin_amdgcn_s_memrealtime(); wsc[2] = __builtin_amdgcn_s_memtime();
 #endif
@@ -499,10 +593,19 @@ int attention_f16x2(const float* q, const void* kc, const void* vc, int nkp, flo
     a.stamps = debug_get_gemm_stamps();
     const size_t lds = ANST * (size_t)(2 * nkp * APL) * sizeof(uint16_t);       // 48 KB / 24 KB: under the 64 KB default limit
     static const int pp_min = getenv("SDVAR_ATTN_PP_MIN") ? atoi(getenv("SDVAR_ATTN_PP_MIN")) : 129;      // A/B runs: queries per (row, head) from which the 8-wave kernel runs
+    static const int pp_sched = getenv("SDVAR_ATTN_PP_SCHED") ? atoi(getenv("SDVAR_ATTN_PP_SCHED")) : 1;   // A/B runs: 0 = the four-slot schedule (S / V1 / PV / V2); 1 / 2 / 3 = two slots, ring of 4 / 6 / 8 stages
     if (l >= pp_min) {
-        const size_t ldp = PP_NST * (size_t)(2 * nkp * APL) * sizeof(uint16_t);
-        if (nkp == 2) hipLaunchKernelGGL(attention_f16x2_pp_kernel<2>, dim3((l + 255) / 256, H, R), dim3(512), ldp, stream, a);
-        else hipLaunchKernelGGL(attention_f16x2_pp_kernel<1>, dim3((l + 255) / 256, H, R), dim3(512), ldp, stream, a);
+        const size_t ldp = (pp_sched == 0 ? 3 : 2 * pp_sched + 2) * (size_t)(2 * nkp * APL) * sizeof(uint16_t);                // 48 / 64 / 96 / 128 KB (two planes)
+        const dim3 grid((l + 255) / 256, H, R);
+#define SDVAR_PP_LAUNCH(NK, SC) do { static LdsOptIn oi; SDVAR_LDS_OPT_IN(oi, ldp, (const void*)attention_f16x2_pp_kernel<NK, SC>);                         \
+                                     hipLaunchKernelGGL((attention_f16x2_pp_kernel<NK, SC>), grid, dim3(512), ldp, stream, a); } while (0)
+        switch (pp_sched) {
+            case 0: if (nkp == 2) SDVAR_PP_LAUNCH(2, 0); else SDVAR_PP_LAUNCH(1, 0); break;
+            case 2: if (nkp == 2) SDVAR_PP_LAUNCH(2, 2); else SDVAR_PP_LAUNCH(1, 2); break;
+            case 3: if (nkp == 2) SDVAR_PP_LAUNCH(2, 3); else SDVAR_PP_LAUNCH(1, 3); break;
+            default: if (nkp == 2) SDVAR_PP_LAUNCH(2, 1); else SDVAR_PP_LAUNCH(1, 1); break;
+        }
+#undef SDVAR_PP_LAUNCH
         SDVAR_LAUNCH_CHECK();
         return SDVAR_OK;
     }

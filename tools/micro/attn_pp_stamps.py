@@ -28,7 +28,10 @@ for rep in range(3):
     s = stamps.cpu().tolist()
     for w in (0, 1):
         v = s[16 * w:16 * w + 5]
-        print(f"rep {rep} wave {4 * w}: S {v[1] - v[0]}  V1 {v[2] - v[1]}  PV {v[3] - v[2]}  V2 {v[4] - v[3]}   tile total {v[4] - v[0]}")
+        if v[3] == 0:            # two-slot schedule (SDVAR_ATTN_PP_SCHED=1, the default): stamps 0 / 1 / 2 = start of M(t), of V(t), end of V(t)
+            print(f"rep {rep} wave {4 * w}: M {v[1] - v[0]}  V {v[2] - v[1]}   tile total {v[2] - v[0]}")
+        else:
+            print(f"rep {rep} wave {4 * w}: S {v[1] - v[0]}  V1 {v[2] - v[1]}  PV {v[3] - v[2]}  V2 {v[4] - v[3]}   tile total {v[4] - v[0]}")
     r, c = s[32:36], s[36:40]
     us = [(r[k + 1] - r[k]) / 100.0 for k in range(3)]
     print(f"rep {rep}: prologue {us[0]:.2f} us, loop {us[1]:.2f} us ({(c[2] - c[1]) / max(1e-9, (r[2] - r[1]) * 10.0):.2f} GHz), epilogue {us[2]:.2f} us")

@@ -99,5 +99,5 @@ def both(sa, sb, n=5):
     return (time.perf_counter() - t0) * 1e3 / n
 
 
-both(full, s_full2, 2); both(s_small, s_dec, 2)
-print(f"both at once: two ordinary streams {both(full, s_full2):.3f} ms; partitioned {both(s_small, s_dec):.3f} ms per (stages 0-5 + decode)")
+both(full, s_full2, 2); both(s_small, s_dec, 2); both(full, s_dec, 2)
+print(f"both at once: two ordinary streams {both(full, s_full2):.3f} ms; partitioned {both(s_small, s_dec):.3f} ms; only the decode confined {both(full, s_dec):.3f} ms per (stages 0-5 + decode)")
