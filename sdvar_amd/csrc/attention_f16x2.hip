@@ -146,7 +146,11 @@ __device__ __forceinline__ void softmax_tile(f32x16& s, int k0, int vis_q, int l
 #pragma unroll
         for (int e = 0; e < 4; ++e) {                                    // p in [0, 2^ATT_DEFER]: inside the fp16 range, no clamp
             uint32_t hw, lw;
+#ifdef SDVAR_ATTN_P1
+            asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hw) : "v"(pr[4 * j + e][0]), "v"(pr[4 * j + e][1])); lw = 0u;
+#else
             split2h_pk_raw(pr[4 * j + e][0], pr[4 * j + e][1], hw, lw);
+#endif
             ph[e] = hw; pl[e] = lw;
         }
         pp[j][0] = __builtin_bit_cast(f16x8, ph); pp[j][1] = __builtin_bit_cast(f16x8, pl);
@@ -155,6 +159,17 @@ __device__ __forceinline__ void softmax_tile(f32x16& s, int k0, int vis_q, int l
 
 // The softmax / split arithmetic is written for instruction count (vector-ALU work does not hide under MFMAs on gfx950: see
 // attention_bf16x3.hip): packed fp32 ops on register pairs, v_max3, masking only in the tiles that straddle a visibility boundary.
+// O^T += V^T P^T.  -DSDVAR_ATTN_P1 (an EXPERIMENT, never the product build: tools/micro/attn_p1_exp.sh) drops the low plane of P - 2 instead of 3 products and no
+// second conversion pass in the softmax: P then carries 11 significand bits, 2^-11 relative per weight (DESIGN.md section 4a reports what that does to the logits).
+template <int NKP>
+__device__ __forceinline__ void mfma_pv(f32x16& acc, const f16x8* a, const f16x8* b) {
+#ifdef SDVAR_ATTN_P1
+    if (NKP == 2) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], acc, 0, 0, 0);
+#else
+    mfma_planes<NKP>(acc, a, b);
+#endif
+}
 template <int NKP>
 __global__ __launch_bounds__(256, 2) void attention_f16x2_kernel(AttnHArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint16_t att_sm[];
@@ -259,8 +274,8 @@ __global__ __launch_bounds__(256, 2) void attention_f16x2_kernel(AttnHArgs a) {
         // ---- O^T += V^T P^T
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            mfma_planes<NKP>(o0, vf[j][0], pp[j]);
-            mfma_planes<NKP>(o1, vf[j][1], pp[j]);
+            mfma_pv<NKP>(o0, vf[j][0], pp[j]);
+            mfma_pv<NKP>(o1, vf[j][1], pp[j]);
         }
     }
 
@@ -449,8 +464,8 @@ __global__ __launch_bounds__(512, 2) void attention_f16x2_pp_kernel(AttnHArgs a)
                 if (t > 0) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        mfma_planes<NKP>(o0, vf[j][0], pp[j]);
-                        mfma_planes<NKP>(o1, vf[j][1], pp[j]);
+                        mfma_pv<NKP>(o0, vf[j][0], pp[j]);
+                        mfma_pv<NKP>(o1, vf[j][1], pp[j]);
                     }
                 }
 #pragma unroll
@@ -472,8 +487,8 @@ __global__ __launch_bounds__(512, 2) void attention_f16x2_pp_kernel(AttnHArgs a)
         if (wave_active) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                mfma_planes<NKP>(o0, vf[j][0], pp[j]);
-                mfma_planes<NKP>(o1, vf[j][1], pp[j]);
+                mfma_pv<NKP>(o0, vf[j][0], pp[j]);
+                mfma_pv<NKP>(o1, vf[j][1], pp[j]);
             }
         }
         SDVAR_PP_SLOT();
@@ -520,8 +535,8 @@ __global__ __launch_bounds__(512, 2) void attention_f16x2_pp_kernel(AttnHArgs a)
         if (wave_active) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                mfma_planes<NKP>(o0, vf[j][0], pp[j]);
-                mfma_planes<NKP>(o1, vf[j][1], pp[j]);
+                mfma_pv<NKP>(o0, vf[j][0], pp[j]);
+                mfma_pv<NKP>(o1, vf[j][1], pp[j]);
             }
         }
         if (t + 2 < ntiles) { if (NKP == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); }
