@@ -387,6 +387,7 @@ static int model_begin_impl(sdvar_model_t* m, int32_t B, const int64_t* labels, 
             for (int i = 0; i < m->d.depth; ++i)
                 SDVAR_TRY(gemm_f32_nt(sil, C, m->blk[i].ada_w, m->blk[i].ada_b, m->ada_tab + (size_t)i * 6 * C, (int)row, (int)NC, 6 * C, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, s));
             SDVAR_TRY(gemm_f32_nt(sil, C, m->nm_w, m->nm_b, m->ada_tab + (size_t)m->d.depth * 6 * C, (int)row, (int)NC, 2 * C, C, EPI_BIAS, nullptr, 0, nullptr, 0, 0, s));
+            SDVAR_HIP(hipStreamSynchronize(s));          // once per bind: later calls may come on other streams and only READ the table
             m->ada_tab_ready = true;
         }
         ProfScope ps(7, 0, 8.0 * R * (double)row, s);
