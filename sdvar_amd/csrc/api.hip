@@ -8,6 +8,7 @@
 
 #include "../../include/sdvar_hip.h"
 #include "common.h"
+#include <string>
 
 namespace sdvar {
 
@@ -43,6 +44,11 @@ void debug_set_gemm_cfg_h(int bm, int split);
 void debug_set_gemm_cfg_p(int bm, int split);
 void debug_set_gemm_stamps(unsigned long long* p);
 void debug_set_qkv_fuse(int on);
+void debug_set_h4_var(int v);
+void debug_set_h2_stages(int v);
+void debug_set_small_pp(int v);
+void debug_set_attn_pp_sched(int v);
+void debug_set_conv_pp(int v);
 void debug_get_gemm_cfg_h(int* out);
 int planes_guard(const uint16_t* h_plane, size_t n, unsigned long long* cnt, hipStream_t stream);
 int cfg_sample(const float* logits, int B, int l, int V, float one_plus_t, float t, int top_k, int use_top_p, float top_p_thr, const float* q, uint64_t seed,
@@ -770,6 +776,20 @@ int sdvar_debug_set_gemm_cfg(int32_t bm, int32_t split) {
 }
 
 int sdvar_debug_set_qkv_fuse(int32_t on) { debug_set_qkv_fuse(on); return SDVAR_OK; }
+
+// Kernel variants that otherwise only an environment variable read at first use selects (A/B runs): tests switch them inside one process.  value < 0 = back to the
+// environment / default.
+int sdvar_debug_set_variant(const char* name, int32_t value) {
+    SDVAR_CHECK_ARG(name, "debug_set_variant: null name");
+    const std::string n(name);
+    if (n == "gemm_h4_var") { SDVAR_CHECK_ARG(value <= 3, "gemm_h4_var %d", value); debug_set_h4_var(value); }
+    else if (n == "gemm_h2_stages") { SDVAR_CHECK_ARG(value < 0 || value == 2 || value == 3 || value == 4 || value == 5 || value == 6, "gemm_h2_stages %d", value); debug_set_h2_stages(value); }
+    else if (n == "gemm_small_pp") { SDVAR_CHECK_ARG(value <= 1, "gemm_small_pp %d", value); debug_set_small_pp(value); }
+    else if (n == "attn_pp_sched") { SDVAR_CHECK_ARG(value <= 3, "attn_pp_sched %d", value); debug_set_attn_pp_sched(value); }
+    else if (n == "conv_pp") { SDVAR_CHECK_ARG(value <= 2, "conv_pp %d", value); debug_set_conv_pp(value); }
+    else { set_error("debug_set_variant: unknown variant '%s'", name); return SDVAR_ERR_ARG; }
+    return SDVAR_OK;
+}
 
 int sdvar_debug_get_gemm_cfg(int32_t* out4) {
     SDVAR_CHECK_ARG(out4, "debug_get_gemm_cfg: null");

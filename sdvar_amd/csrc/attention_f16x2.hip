@@ -589,6 +589,9 @@ __global__ __launch_bounds__(512, 2) void attention_f16x2_pp_kernel(AttnHArgs a)
 #endif
 }
 
+static int g_attn_pp_sched = -1;
+void debug_set_attn_pp_sched(int v) { g_attn_pp_sched = v; }
+
 // nkp: 2 = cache format 3 (two fp16 planes per value), 1 = cache format 4 (one fp16 plane: the fp16 KV cache)
 int attention_f16x2(const float* q, const void* kc, const void* vc, int nkp, float* out, uint16_t* outp, size_t ops, int pfmt, int R, int H, int l, int Lp,
                     int Ktot, int n_chunk, const int* qbeg, const int* vis, hipStream_t stream) {
@@ -608,7 +611,8 @@ int attention_f16x2(const float* q, const void* kc, const void* vc, int nkp, flo
     a.stamps = debug_get_gemm_stamps();
     const size_t lds = ANST * (size_t)(2 * nkp * APL) * sizeof(uint16_t);       // 48 KB / 24 KB: under the 64 KB default limit
     static const int pp_min = getenv("SDVAR_ATTN_PP_MIN") ? atoi(getenv("SDVAR_ATTN_PP_MIN")) : 129;      // A/B runs: queries per (row, head) from which the 8-wave kernel runs
-    static const int pp_sched = getenv("SDVAR_ATTN_PP_SCHED") ? atoi(getenv("SDVAR_ATTN_PP_SCHED")) : 1;   // A/B runs: 0 = the four-slot schedule (S / V1 / PV / V2); 1 / 2 / 3 = two slots, ring of 4 / 6 / 8 stages
+    if (g_attn_pp_sched < 0) { const char* e = getenv("SDVAR_ATTN_PP_SCHED"); g_attn_pp_sched = e ? atoi(e) : 1; if (g_attn_pp_sched < 0 || g_attn_pp_sched > 3) g_attn_pp_sched = 1; }
+    const int pp_sched = g_attn_pp_sched;          // A/B runs and tests: 0 = the four-slot schedule (S / V1 / PV / V2); 1 (default) / 2 / 3 = two slots, ring of 4 / 6 / 8 stages
     if (l >= pp_min) {
         const size_t ldp = (pp_sched == 0 ? 3 : 2 * pp_sched + 2) * (size_t)(2 * nkp * APL) * sizeof(uint16_t);                // 48 / 64 / 96 / 128 KB (two planes)
         const dim3 grid((l + 255) / 256, H, R);

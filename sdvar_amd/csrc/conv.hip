@@ -27,6 +27,9 @@
 #endif
 
 namespace sdvar {
+static int g_conv_pp_override = -1;
+void debug_set_conv_pp(int v) { g_conv_pp_override = v; }
+
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -708,8 +711,8 @@ int conv_planes(const uint16_t* X, size_t xps, size_t x_rows, int x_row0, const 
         a.k_per_split = kps; a.split = split;
     }
     const size_t lds = F16 ? 3 * (size_t)CSTAGE_H * sizeof(uint16_t) : 2 * (size_t)CSTAGE * sizeof(uint16_t);      // 156 KB either way
-    const char* pp_s = getenv("SDVAR_CONV_PP");          // read per call (tests switch it): 0 = the round-2 loop, 1 = ping-pong on 32x32x16, 2 (default) = ping-pong on 16x16x32
-    const int pp_env = pp_s ? atoi(pp_s) : 2;
+    const char* pp_s = getenv("SDVAR_CONV_PP");          // read per call; sdvar_debug_set_variant("conv_pp", v) overrides it (tests): 0 = the round-2 loop, 1 = ping-pong on 32x32x16, 2 (default) = ping-pong on 16x16x32
+    const int pp_env = g_conv_pp_override >= 0 ? g_conv_pp_override : (pp_s ? atoi(pp_s) : 2);
     const int pp = (pp_env == 2 && N % 4 != 0) ? 1 : pp_env;                                         // the 16-byte epilogue needs whole groups of four columns
     static LdsOptIn opt_in, opt_in_h;
     if (F16) SDVAR_LDS_OPT_IN(opt_in_h, lds, (const void*)conv_f16x2_kernel<CEPI_BIAS, 0>, (const void*)conv_f16x2_kernel<CEPI_BIAS_RES, 0>, (const void*)conv_f16x2_kernel<CEPI_PARTIAL, 0>,

@@ -1739,6 +1739,8 @@ static int launch_h4_kernel(const GemmHArgs& a, int grid, hipStream_t stream) {
     return SDVAR_OK;
 }
 void debug_set_h4_var(int v) { g_h4_var = v; }
+void debug_set_h2_stages(int v) { g_h2_stages = v; }
+void debug_set_small_pp(int v) { g_small_pp = v; }
 
 static int launch_reduce_h(const GemmHArgs& a, const float* ws, int split, int epi, hipStream_t stream) {
     const size_t total = (size_t)a.M * (a.N / 4);

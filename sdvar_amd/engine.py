@@ -102,6 +102,7 @@ _SIGNATURES = {
     "sdvar_debug_set_gemm_cfg": (_I, [_I, _I]),
     "sdvar_debug_set_gemm_stamps": (_I, [_P]),
     "sdvar_debug_set_qkv_fuse": (_I, [_I]),
+    "sdvar_debug_set_variant": (_I, [C.c_char_p, _I]),
     "sdvar_debug_get_gemm_cfg": (_I, [C.POINTER(_I)]),
     "sdvar_debug_set_f16x2_guard": (_I, [_I]),
     "sdvar_debug_get_f16x2_guard": (_I, [C.POINTER(_U64), _I]),

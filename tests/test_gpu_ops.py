@@ -593,6 +593,41 @@ def test_gemm_f16x2_kernels_forced_tile(dev, M, N, K, split, epi, bm):
     assert err <= 2e-5 * max(1.0, ref.abs().max().item()), err
 
 
+VARIANTS = [("gemm_h4_var", 0, 512), ("gemm_h4_var", 1, 512), ("gemm_h4_var", 2, 512),          # the 256 x 256 kernel on 32x32x16 MFMAs, three DMA placements
+            ("gemm_h2_stages", 4, 128), ("gemm_h2_stages", 3, 128), ("gemm_h2_stages", 2, 128), ("gemm_h2_stages", 5, 128),      # the 128 x 128 kernel without the ping-pong schedule
+            ("gemm_small_pp", 0, 64)]                                                                    # 64-row tiles on the 4-wave ring kernel
+
+
+@pytest.mark.parametrize("name,value,bm", VARIANTS)
+def test_gemm_f16x2_non_default_variants(dev, name, value, bm):
+    """The kernel variants that only an environment switch selects in production (kept for A/B runs) still compute the same thing: the forced-tile shapes of
+    test_gemm_f16x2_kernels_forced_tile with the variant selected through sdvar_debug_set_variant, all three epilogues, one QKV-epilogue model run."""
+    lib = E.load_library()
+    E._check(lib.sdvar_debug_set_variant(name.encode(), value))
+    try:
+        for (M, N, K, split) in [(257, 384, 1024, 3), (4096, 256, 1024, 1), (700, 768, 160, 1), (300, 256, 96, 1)]:
+            for epi in (0, 1, 2):
+                test_gemm_f16x2_kernels_forced_tile(dev, M, N, K, split if bm != 512 else 1, epi, bm)
+        test_qkv_epilogue_forced_tiles(dev, bm, False)
+    finally:
+        E._check(lib.sdvar_debug_set_variant(name.encode(), -1))
+    assert lib.sdvar_debug_set_variant(b"no_such_variant", 0) != 0
+
+
+@pytest.mark.parametrize("sched", [0, 2, 3])
+def test_attention_pp_schedule_variants(dev, sched):
+    """The 8-wave attention kernel's other schedules (SDVAR_ATTN_PP_SCHED: 0 = four slots per tile, 2 / 3 = the two-slot schedule with 6 / 8 ring stages) against
+    fp64 SDPA on the shapes that reach it (more than 128 queries per (row, head)), both cache formats, single stage and a two-stage chunk."""
+    lib = E.load_library()
+    E._check(lib.sdvar_debug_set_variant(b"attn_pp_sched", sched))
+    try:
+        for fmt in (3, 4):
+            for (R, H, lens, prefix) in [(2, 16, [256], 424), (1, 2, [169, 256], 255), (2, 2, [324], 640), (2, 3, [64, 100, 169], 91)]:
+                test_f16_planes_kv_cache_append_and_attention(dev, R, H, lens, prefix, fmt)
+    finally:
+        E._check(lib.sdvar_debug_set_variant(b"attn_pp_sched", -1))
+
+
 @pytest.mark.parametrize("M,N,K,split", [(16, 3072, 1024, 0), (1, 16, 32, 0), (16, 768, 4096, 0), (17, 1024, 4096, 0), (33, 2304, 768, 0), (64, 4096, 1024, 0), (80, 1024, 1024, 0),
                                          (80, 768, 3072, 0), (48, 1024, 96, 0), (64, 1024, 4096, 8), (16, 528, 160, 3)])
 @pytest.mark.parametrize("epi", [0, 1, 2])

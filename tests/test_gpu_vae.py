@@ -140,14 +140,18 @@ def test_decoder_small_width_matches_pytorch(dev, cm):
 
 
 @pytest.mark.parametrize("cm", ["bf16x3", "f16x2", "f16x2:pp1", "f16x2:pp0"])
-def test_decoder_reference_width_matches_pytorch(dev, cm, monkeypatch):
+def test_decoder_reference_width_matches_pytorch(dev, cm):
     """vae_ch160v4096z32 geometry (the checkpoint the reference loads): ch = 160, widths 640/320/160, 256^2 output.  The f16x2 conv kernel has three K-loops
     (SDVAR_CONV_PP: 2 = ping-pong on v_mfma_f32_16x16x32_f16 with the 16-byte epilogue, the default; 1 = ping-pong on 32x32x16; 0 = the round-2 loop):
     all three against PyTorch, fused GroupNorm statistics and the up-sampling phase scatter included."""
+    lib = E.load_library()
     if ":pp" in cm:
-        monkeypatch.setenv("SDVAR_CONV_PP", cm[-1]); cm = "f16x2"
-    vae, ctx, f_hat = _decode_pair(dev, 160, 2, conv_mode=cm)
-    got = ctx.decode(f_hat)
+        E._check(lib.sdvar_debug_set_variant(b"conv_pp", int(cm[-1]))); cm = "f16x2"
+    try:
+        vae, ctx, f_hat = _decode_pair(dev, 160, 2, conv_mode=cm)
+        got = ctx.decode(f_hat)
+    finally:
+        E._check(lib.sdvar_debug_set_variant(b"conv_pp", -1))
     want = vae.fhat_to_img_torch(f_hat.clone())
     err = (got - want).abs().max().item()
     assert err <= 1e-4, err
