@@ -128,6 +128,44 @@ def test_wide_model_stage_forward_vs_oracle(dev, depth):
     assert max(errs) <= LOGIT_TOL, errs
 
 
+def test_ladder_1024_sampler_vs_oracle(dev):
+    """The 1024^2 ladder of the reference (utils/arg_util.py:249: 14 stages, L = 9451, a 64 x 64 final map - no BASELINE configuration uses it): plain AR and
+    the speculative loop (gamma = 2, every stage accepted: 7 chunk verifies over up to 6400 tokens) of small models against the oracle.  Only the sampler: the
+    HIP decoder's attention block holds its whole token map in LDS and stops at 32 x 32 latents."""
+    from sdvar_amd.ladder import LADDER_1024
+    from sdvar_amd.weights import var_state_dict
+    pns, B, seed = LADDER_1024, 1, 3
+    lad = as_ladder(pns)
+    assert lad.L == 9451 and lad.S == 14
+    sd_d, sd_t = var_state_dict(2, pns, "stress", 1234), var_state_dict(2, pns, "stress", 4321)
+    sd_v = vae_state_dict(pns, "stress", 1234, ch=32, with_encoder=False)
+    dc, tc, qc = E.ModelCtx(sd_d, 2, pns, B, 1, dev), E.ModelCtx(sd_t, 2, pns, B, 2, dev), E.QuantCtx(sd_v, pns, B, dev)
+    od, ot, oq = orc.OracleVAR(sd_d, 2, pns), orc.OracleVAR(sd_t, 2, pns), orc.OracleQuant(sd_v, pns)
+    labels = torch.tensor([417])
+    smp = E.Sampler(tc, qc, dc)
+    # plain AR of the target
+    res = smp.plain_ar(labels.to(dev), 1.5, 900, 0.96, E.Noise("host", seed), trace=True)
+    tr = orc.plain_ar(ot, oq, labels, 1.5, 900, 0.96, _noise_o(seed), keep=True)
+    ids, want = res.ids.cpu().numpy().copy(), torch.cat(tr.ids, 1).numpy()
+    stop = lad.S if np.array_equal(ids, want) else _first_flip(ids, want, lad)
+    if stop < lad.S:
+        assert tr.margins[stop] < 1e-3, f"ids differ from stage {stop} on although its draw was not within 1e-3 of a tie"
+    errs = [float((res.trace["logits"][s].cpu() - tr.logits[s]).abs().max()) for s in range(min(stop + 1, lad.S))]
+    assert max(errs) <= LOGIT_TOL, errs
+    assert stop >= 10, f"first flip already at stage {stop}"
+    if stop == lad.S:
+        assert (res.f_hat.cpu() - tr.f_hat).abs().max().item() <= FHAT_TOL
+    # the speculative loop, every stage accepted
+    res = smp.spec_decode(labels.to(dev), 1.5, 2, 900, 0.96, E.Noise("host", seed), thr=0.0, run_ahead=True)
+    trs = orc.spec_decode(od, ot, oq, labels, 1.5, 2, 900, 0.96, _noise_o(seed), thr=0.0, keep=False)
+    ids, want = res.ids.cpu().numpy(), torch.cat(trs.ids, 1).numpy()
+    assert res.stats["target_calls"] == trs.stats["target_calls"] == 7 and res.stats["accepted_tokens"] == lad.L
+    if not np.array_equal(ids, want):
+        flip = _first_flip(ids, want, lad)
+        assert min(trs.margins[flip:flip + 1]) < 1e-3, f"speculative ids differ from stage {flip} on without a near-tie"
+    dc.close(); tc.close(); qc.close(); torch.cuda.empty_cache()
+
+
 def test_decoder_reference_width_vs_oracle(dev):
     """The HIP VQVAE decoder at the reference width (ch = 160, 256^2) against the oracle's decode_image (vqvae.py:62-63, basic_vae.py:163-226, var.py:215) -
     not against MIOpen on the same GPU (tests/test_gpu_vae.py does that)."""
