@@ -152,11 +152,15 @@ __global__ __launch_bounds__(256) void prep_planes_kernel(const float* __restric
 //   output   thread = (4 queries, 4 channels); v rows are read straight from global memory (coalesced), p from LDS
 constexpr int VA_QT = 16, VA_SP = VA_QT + 4;     // score rows padded to 20 floats (16-byte aligned rows)
 typedef float f32x2v __attribute__((ext_vector_type(2)));
-__global__ __launch_bounds__(256) void vae_attn_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, int N) {
+// GPS = true: the probabilities of the workgroup's 16 queries live in a global scratch row block instead of LDS - token maps beyond ~1900 tokens (the 64 x 64
+// latent of the 1024^2 ladder: 4096 tokens x 80 bytes = 320 KB).  Every phase of the kernel is separated by __syncthreads(), a workgroup's waves share one CU
+// and its L1, so the same code runs on either pointer; this path is about reach, not speed.
+template <bool GPS>
+__global__ __launch_bounds__(256) void vae_attn_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, int N, float* __restrict__ gps) {
     extern __shared__ __attribute__((aligned(16))) float vsm[];
     float* ks = vsm;                       // [32][256]
     float* qs = vsm + 32 * 256;            // [32][VA_QT]
-    float* ps = qs + 32 * VA_QT;           // [N][VA_SP]
+    float* ps = GPS ? gps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (size_t)N * VA_SP : qs + 32 * VA_QT;           // [N][VA_SP]
     const int b = blockIdx.y, q0 = blockIdx.x * VA_QT, tid = threadIdx.x;
     const int tq = tid >> 6, tk = tid & 63;
     const float* base = qkv + (size_t)b * N * 3 * C;
@@ -591,11 +595,23 @@ struct Runner {
         VAE_TRY(prep(x, C, &a.n, 0, 0, v->p1, v->p1_elems, &ops, &rows, &G));
         VAE_TRY(conv(a.qkv, v->p1, ops, rows, G, nullptr, h));
         const int N = H * H;
-        const size_t lds = ((size_t)32 * 256 + 32 * VA_QT + (size_t)N * VA_SP) * sizeof(float);
-        SDVAR_CHECK_ARG(lds <= 160 * 1024 && C % 32 == 0, "vae: attention tile of %zu bytes does not fit the LDS (C=%d, %d tokens)", lds, C, N);
-        SDVAR_HIP(hipFuncSetAttribute((const void*)vae_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(vae_attn_kernel, dim3((N + VA_QT - 1) / VA_QT, B), dim3(256), lds, s, h, t, C, N);
-        SDVAR_LAUNCH_CHECK();
+        const size_t lds_fix = ((size_t)32 * 256 + 32 * VA_QT) * sizeof(float), lds = lds_fix + (size_t)N * VA_SP * sizeof(float);
+        SDVAR_CHECK_ARG(C % 32 == 0, "vae: attention over %d channels (need a multiple of 32)", C);
+        const int qgroups = (N + VA_QT - 1) / VA_QT;
+        if (lds <= 160 * 1024) {
+            SDVAR_HIP(hipFuncSetAttribute((const void*)vae_attn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(vae_attn_kernel<false>, dim3(qgroups, B), dim3(256), lds, s, h, t, C, N, (float*)nullptr);
+            SDVAR_LAUNCH_CHECK();
+        } else {            // probabilities in the split-K workspace (idle between the qkv and the proj convolution), as many images per launch as fit
+            const size_t per_img = (size_t)qgroups * N * VA_SP;
+            const int nb_max = (int)(v->ws_floats / per_img);
+            SDVAR_CHECK_ARG(nb_max >= 1, "vae: attention over %d tokens needs %zu floats of scratch per image (workspace: %zu)", N, per_img, v->ws_floats);
+            for (int b0 = 0; b0 < B; b0 += nb_max) {
+                const int nb = B - b0 < nb_max ? B - b0 : nb_max;
+                hipLaunchKernelGGL(vae_attn_kernel<true>, dim3(qgroups, nb), dim3(256), lds_fix, s, h + (size_t)b0 * N * 3 * C, t + (size_t)b0 * N * C, C, N, v->ws);
+                SDVAR_LAUNCH_CHECK();
+            }
+        }
         if (stats_src == t) stats_src = nullptr;
         VAE_TRY(prep(t, C, nullptr, 0, 0, v->p1, v->p1_elems, &ops, &rows, &G));
         VAE_TRY(conv(a.proj, v->p1, ops, rows, G, x, x));

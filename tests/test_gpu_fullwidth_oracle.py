@@ -130,8 +130,8 @@ def test_wide_model_stage_forward_vs_oracle(dev, depth):
 
 def test_ladder_1024_sampler_vs_oracle(dev):
     """The 1024^2 ladder of the reference (utils/arg_util.py:249: 14 stages, L = 9451, a 64 x 64 final map - no BASELINE configuration uses it): plain AR and
-    the speculative loop (gamma = 2, every stage accepted: 7 chunk verifies over up to 6400 tokens) of small models against the oracle.  Only the sampler: the
-    HIP decoder's attention block holds its whole token map in LDS and stops at 32 x 32 latents."""
+    the speculative loop (gamma = 2, every stage accepted: 7 chunk verifies over up to 6400 tokens) of small models against the oracle, then the 1024^2 decode of
+    the sampled f_hat (4096-token attention blocks: probabilities through the decoder's workspace) against orc.decode_image."""
     from sdvar_amd.ladder import LADDER_1024
     from sdvar_amd.weights import var_state_dict
     pns, B, seed = LADDER_1024, 1, 3
@@ -155,6 +155,10 @@ def test_ladder_1024_sampler_vs_oracle(dev):
     assert stop >= 10, f"first flip already at stage {stop}"
     if stop == lad.S:
         assert (res.f_hat.cpu() - tr.f_hat).abs().max().item() <= FHAT_TOL
+    vc = E.VaeCtx(sd_v, B, dev, latent_hw=64)
+    img = vc.decode(res.f_hat.clone()).clamp(-1, 1).add(1).mul(0.5).cpu()
+    vc.close()
+    assert img.shape == (B, 3, 1024, 1024) and (img - orc.decode_image(sd_v, res.f_hat.cpu().clone())).abs().max().item() <= 1e-4
     # the speculative loop, every stage accepted
     res = smp.spec_decode(labels.to(dev), 1.5, 2, 900, 0.96, E.Noise("host", seed), thr=0.0, run_ahead=True)
     trs = orc.spec_decode(od, ot, oq, labels, 1.5, 2, 900, 0.96, _noise_o(seed), thr=0.0, keep=False)

@@ -168,6 +168,17 @@ def test_decoder_512_geometry(dev):
     assert err <= 1e-4, err
 
 
+def test_decoder_1024_geometry(dev):
+    """The 1024^2 ladder's decode: 64 x 64 latents, 4096-token attention blocks - beyond what the attention kernel can keep in LDS, so its probabilities go
+    through the decoder's split-K workspace (vae_attn_kernel<true>)."""
+    vae, ctx, f_hat = _decode_pair(dev, 32, 1, latent=64)
+    got = ctx.decode(f_hat)
+    want = vae.fhat_to_img_torch(f_hat.clone())
+    assert got.shape == want.shape == (1, 3, 1024, 1024)
+    err = (got - want).abs().max().item()
+    assert err <= 1e-4, err
+
+
 def test_decoder_rejects_bad_shapes(dev):
     _, ctx, f_hat = _decode_pair(dev, 32, 1)
     with pytest.raises(E.SdvarError):
