@@ -233,7 +233,7 @@ int sdvar_debug_set_gemm_cfg(int32_t bm, int32_t split);
  * whenever the launch comes out unsplit on the f16x2 planes cache */
 int sdvar_debug_set_qkv_fuse(int32_t on);
 /* Select a kernel variant that otherwise only an environment variable (read at first use) selects - tests run the non-default variants in one process.
- * name: "gemm_h4_var" 0..3, "gemm_h2_stages" 2..6, "gemm_small_pp" 0/1, "attn_pp_sched" 0..3, "conv_pp" 0..2; value < 0 restores the environment / default. */
+ * name: "gemm_h4_var" 0..3, "gemm_h2_stages" 2..6, "gemm_small_pp" 0..2, "attn_pp_sched" 0..3, "conv_pp" 0..2; value < 0 restores the environment / default. */
 int sdvar_debug_set_variant(const char* name, int32_t value);
 /* test aid: out4 = {row tile (32/64/128/256) of the LAST f16x2 GEMM call of this host thread, its K split, number of launches that took the hybrid tail
  * split since the last read, number of QKV launches that finished q and k in their epilogue since the last read}; reading resets the two counters.

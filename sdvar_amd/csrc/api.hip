@@ -784,7 +784,7 @@ int sdvar_debug_set_variant(const char* name, int32_t value) {
     const std::string n(name);
     if (n == "gemm_h4_var") { SDVAR_CHECK_ARG(value <= 3, "gemm_h4_var %d", value); debug_set_h4_var(value); }
     else if (n == "gemm_h2_stages") { SDVAR_CHECK_ARG(value < 0 || value == 2 || value == 3 || value == 4 || value == 5 || value == 6, "gemm_h2_stages %d", value); debug_set_h2_stages(value); }
-    else if (n == "gemm_small_pp") { SDVAR_CHECK_ARG(value <= 1, "gemm_small_pp %d", value); debug_set_small_pp(value); }
+    else if (n == "gemm_small_pp") { SDVAR_CHECK_ARG(value <= 2, "gemm_small_pp %d", value); debug_set_small_pp(value); }
     else if (n == "attn_pp_sched") { SDVAR_CHECK_ARG(value <= 3, "attn_pp_sched %d", value); debug_set_attn_pp_sched(value); }
     else if (n == "conv_pp") { SDVAR_CHECK_ARG(value <= 2, "conv_pp %d", value); debug_set_conv_pp(value); }
     else { set_error("debug_set_variant: unknown variant '%s'", name); return SDVAR_ERR_ARG; }

@@ -650,12 +650,15 @@ __global__ __launch_bounds__(256) void gemm_f16x2_small_kernel(GemmHArgs a) {
 // so a SIMD's matrix pipe is fed by one group while the other reads LDS: two K-steps per two slots instead of one K-step per ~2.7 slot lengths.  After the loop the
 // groups swap one row tile each through LDS (32 KB) - group 0 finishes rows 0-31 of the tile, group 1 rows 32-63 (sum = group 0 + group 1 in both: deterministic) -
 // and run the epilogue of gemm_f16x2_small_kernel on it.
-constexpr int SPP_STAGE = 2 * (64 + 128) * 32;
+template <int BM> constexpr int spp_stage() { return 2 * (BM + 128) * 32; }       // fp16 elements: 24 KB (BM = 64) / 20 KB (BM = 32)
 
-template <int EPI>
+// BM = 64: as described above.  BM = 32 (one 32-row tile per wave): the groups cannot swap row tiles - group 1 hands its partial sums to group 0, whose four waves
+// run the epilogue alone (group 1 only keeps the barriers).
+template <int BM, int EPI>
 __global__ __launch_bounds__(512) void gemm_f16x2_small_pp_kernel(GemmHArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint16_t hsm[];
-    constexpr int BM = 64, XB = 4, IPS = 6;
+    constexpr int TM = BM / 32, XB = BM / 16, IPS = (2 * (XB + 8)) / 4, STAGE = spp_stage<BM>();
+    static_assert(BM == 32 || BM == 64, "tile");
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + HBN - 1) / HBN, ntile = tiles_m * tiles_n;
     const int ks = blockIdx.x / ntile;
     const int lid = xcd_remap(blockIdx.x - ks * ntile, ntile);
@@ -667,7 +670,7 @@ __global__ __launch_bounds__(512) void gemm_f16x2_small_pp_kernel(GemmHArgs a) {
     const int nk = min(a.K / HBK - kt0, a.k_per_split);
     const int n_own = (nk - g + 1) >> 1, n_it = (nk + 1) >> 1;          // K-steps of this group; iterations of the (common) loop = group 0's count
 
-    // the group's DMA instructions j = 0 .. 5 of one K-step are q = wave + 4 j of the list: q < 8: X plane q / 4, 16-row block q % 4; else W plane (q - 8) / 8, block (q - 8) % 8
+    // the group's DMA instructions j = 0 .. IPS-1 of one K-step are q = wave + 4 j of the list: q < 2 XB: X plane q / XB, 16-row block q % XB; else W plane, block
     const char* gb[IPS]; uint32_t vo[IPS], lo[IPS]; size_t sb[IPS];
 #pragma unroll
     for (int j = 0; j < IPS; ++j) {
@@ -683,19 +686,20 @@ __global__ __launch_bounds__(512) void gemm_f16x2_small_pp_kernel(GemmHArgs a) {
         sb[j] = (size_t)(isx ? a.M : a.N) * 128;                                     // two K-steps on
         lo[j] = (uint32_t)((isx ? p * BM * 32 : 2 * BM * 32 + p * 4096) + b * 512) * 2u;
     }
-    uint16_t* ring = hsm + g * 3 * SPP_STAGE;
+    uint16_t* ring = hsm + g * 3 * STAGE;
     auto issue = [&](int k) {
-        const uint32_t st = SDVAR_LDS_ADDR(ring + (k % 3) * SPP_STAGE);
+        const uint32_t st = SDVAR_LDS_ADDR(ring + (k % 3) * STAGE);
 #pragma unroll
         for (int j = 0; j < IPS; ++j) SDVAR_DMA16(vo[j], gb[j] + (size_t)k * sb[j], st + lo[j]);
     };
-    auto wait_next = [&](int k) {          // the group's K-step k + 1 landed: its K-step k + 2, if requested, may stay in flight
-        if (k + 2 < n_own) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    auto wait_next = [&](int k) {          // the group's K-step k + 1 landed: its K-step k + 2 (IPS instructions), if requested, may stay in flight
+        if (k + 2 < n_own) { if (IPS == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
 
-    f32x16 acc[2];
+    f32x16 acc[TM];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     const int sw = (li >> 2) & 3;
@@ -707,18 +711,23 @@ __global__ __launch_bounds__(512) void gemm_f16x2_small_pp_kernel(GemmHArgs a) {
     wait_next(-1);
     SDVAR_SPP_SLOT();
     if (g) SDVAR_SPP_SLOT();
-    f16x8 fa[2][2][2], fb[2][2];          // [k16 half][plane][row tile], [k16 half][plane]
+    f16x8 fa[2][2][TM], fb[2][2];          // [k16 half][plane][row tile], [k16 half][plane]
 #pragma unroll 1
     for (int k = 0; k < n_it; ++k) {
         const bool act = k < n_own;
         if (act) {
-            const uint32_t sbase = (uint32_t)(uintptr_t)(lds_ptr_t)(ring + (k % 3) * SPP_STAGE);
+            const uint32_t sbase = (uint32_t)(uintptr_t)(lds_ptr_t)(ring + (k % 3) * STAGE);
             const uint32_t aa0 = sbase + 2 * (offa + ch0), aa1 = sbase + 2 * (offa + ch1), ab0 = sbase + 2 * (offb + ch0), ab1 = sbase + 2 * (offb + ch1);
-            // X plane p at + 4096 p bytes, second 32-row tile at + 2048; W plane p at + 8192 p
-            SDVAR_LDS_RDH(fa[0][1][0], aa0, 4096); SDVAR_LDS_RDH(fb[0][0], ab0, 0); SDVAR_LDS_RDH(fa[0][0][0], aa0, 0);
-            SDVAR_LDS_RDH(fb[0][1], ab0, 8192);    SDVAR_LDS_RDH(fa[0][1][1], aa0, 6144); SDVAR_LDS_RDH(fa[0][0][1], aa0, 2048);
-            SDVAR_LDS_RDH(fa[1][1][0], aa1, 4096); SDVAR_LDS_RDH(fb[1][0], ab1, 0); SDVAR_LDS_RDH(fa[1][0][0], aa1, 0);
-            SDVAR_LDS_RDH(fb[1][1], ab1, 8192);    SDVAR_LDS_RDH(fa[1][1][1], aa1, 6144); SDVAR_LDS_RDH(fa[1][0][1], aa1, 2048);
+            // X plane p at + 64 BM p bytes, second 32-row tile at + 2048; W plane p at + 8192 p
+            if constexpr (BM == 64) {
+                SDVAR_LDS_RDH(fa[0][1][0], aa0, 4096); SDVAR_LDS_RDH(fb[0][0], ab0, 0); SDVAR_LDS_RDH(fa[0][0][0], aa0, 0);
+                SDVAR_LDS_RDH(fb[0][1], ab0, 8192);    SDVAR_LDS_RDH(fa[0][1][1], aa0, 6144); SDVAR_LDS_RDH(fa[0][0][1], aa0, 2048);
+                SDVAR_LDS_RDH(fa[1][1][0], aa1, 4096); SDVAR_LDS_RDH(fb[1][0], ab1, 0); SDVAR_LDS_RDH(fa[1][0][0], aa1, 0);
+                SDVAR_LDS_RDH(fb[1][1], ab1, 8192);    SDVAR_LDS_RDH(fa[1][1][1], aa1, 6144); SDVAR_LDS_RDH(fa[1][0][1], aa1, 2048);
+            } else {
+                SDVAR_LDS_RDH(fa[0][1][0], aa0, 2048); SDVAR_LDS_RDH(fb[0][0], ab0, 0); SDVAR_LDS_RDH(fa[0][0][0], aa0, 0); SDVAR_LDS_RDH(fb[0][1], ab0, 8192);
+                SDVAR_LDS_RDH(fa[1][1][0], aa1, 2048); SDVAR_LDS_RDH(fb[1][0], ab1, 0); SDVAR_LDS_RDH(fa[1][0][0], aa1, 0); SDVAR_LDS_RDH(fb[1][1], ab1, 8192);
+            }
             if (k + 2 < n_own) issue(k + 2);          // stage (k + 2) % 3 = (k - 1) % 3: its readers are past L(k - 1)'s lgkmcnt(0) + barrier
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -727,7 +736,7 @@ __global__ __launch_bounds__(512) void gemm_f16x2_small_pp_kernel(GemmHArgs a) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                for (int i = 0; i < 2; ++i) { SDVAR_MFMA3(acc[i], fa[s2][0][i], fa[s2][1][i], fb[s2][0], fb[s2][1]); }
+                for (int i = 0; i < TM; ++i) { SDVAR_MFMA3(acc[i], fa[s2][0][i], fa[s2][1][i], fb[s2][0], fb[s2][1]); }
             wait_next(k);
         }
         SDVAR_SPP_SLOT();
@@ -735,43 +744,63 @@ __global__ __launch_bounds__(512) void gemm_f16x2_small_pp_kernel(GemmHArgs a) {
     if (!g) SDVAR_SPP_SLOT();
 #undef SDVAR_SPP_SLOT
 
-    // the groups swap one row tile: group 0 hands over its part of rows 32-63, group 1 its part of rows 0-31; both add in the order group 0 + group 1
     float* ex = reinterpret_cast<float*>(hsm);           // [8 waves][16 registers][64 lanes]
-    __syncthreads();
-    if (g == 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ex[wave8 * 1024 + r * 64 + lane] = acc[1][r];
-    } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ex[wave8 * 1024 + r * 64 + lane] = acc[0][r];
-    }
-    __syncthreads();
     f32x16 mine;
-    const float* oth = ex + ((1 - g) * 4 + wave) * 1024 + lane;
-    if (g == 0) {
+    bool active;
+    int row;
+    __syncthreads();
+    if constexpr (TM == 2) {
+        // the groups swap one row tile: group 0 hands over its part of rows 32-63, group 1 its part of rows 0-31; both add in the order group 0 + group 1
+        if (g == 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mine[r] = acc[0][r] + oth[r * 64];
+            for (int r = 0; r < 16; ++r) ex[wave8 * 1024 + r * 64 + lane] = acc[1][r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ex[wave8 * 1024 + r * 64 + lane] = acc[0][r];
+        }
+        __syncthreads();
+        const float* oth = ex + ((1 - g) * 4 + wave) * 1024 + lane;
+        if (g == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mine[r] = acc[0][r] + oth[r * 64];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mine[r] = oth[r * 64] + acc[1][r];
+        }
+        active = true; row = m0 + g * 32 + li;
     } else {
+        if (g == 1) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mine[r] = oth[r * 64] + acc[1][r];
+            for (int r = 0; r < 16; ++r) ex[wave * 1024 + r * 64 + lane] = acc[0][r];
+        }
+        __syncthreads();
+        if (g == 0) {
+            const float* oth = ex + wave * 1024 + lane;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mine[r] = acc[0][r] + oth[r * 64];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mine[r] = 0.f;
+        }
+        active = (g == 0); row = m0 + li;
     }
-    const int row = m0 + g * 32 + li;
     const float wsi = a.wsi ? *a.wsi : 1.0f;
     if (EPI == HEPI_QKV) {             // a head is the 64 columns of the wave pair (wave, wave ^ 1) of one group
         const int Cq = a.qk.H * 64, which = n0 / Cq, nh = n0 - which * Cq + (wave >> 1) * 64, h = nh >> 6;
         f32x16 vv;
-        float sq = qk_bias_sq(a, mine, vv, wsi, n0 + wave * 32 + 4 * lh);
+        float sq = 0.f;
+        if (active) sq = qk_bias_sq(a, mine, vv, wsi, n0 + wave * 32 + 4 * lh);
         if (which == 2) {
-            qk_store_row<1>(a, &vv, 0.f, 2, h, row, lh, (wave & 1) * 32);
+            if (active) qk_store_row<1>(a, &vv, 0.f, 2, h, row, lh, (wave & 1) * 32);
         } else {
             float* exq = ex + 8 * 1024;                      // [8 waves][32 rows], behind the swap area
             sq += __shfl_xor(sq, 32, 64);
             if (lh == 0) exq[wave8 * 32 + li] = sq;
             __syncthreads();
             const float other = exq[(wave8 ^ 1) * 32 + li];
-            qk_store_row<1>(a, &vv, (wave & 1) ? other + sq : sq + other, which, h, row, lh, (wave & 1) * 32);
+            if (active) qk_store_row<1>(a, &vv, (wave & 1) ? other + sq : sq + other, which, h, row, lh, (wave & 1) * 32);
         }
-    } else {
+    } else if (active) {
         float* outp = (EPI == HEPI_PARTIAL) ? a.out + (size_t)ks * a.M * a.ldo : a.out;
         if (a.vec && n0 + HBN <= a.N) h_store_tile_fast<EPI>(a, outp, mine, wsi, row, n0 + wave * 32 + 4 * lh);
         else h_store_tile<EPI>(a, outp, mine, wsi, row, n0 + wave * 32 + 4 * lh);
@@ -1604,15 +1633,16 @@ static thread_local int g_last_cfg_h[4] = {0, 0, 0, 0};
 void debug_get_gemm_cfg_h(int* out) { for (int i = 0; i < 4; ++i) out[i] = g_last_cfg_h[i]; g_last_cfg_h[2] = g_last_cfg_h[3] = 0; }
 
 // same cost model as gemm_bf16x3.hip with half the matrix work per K-step: 3 MFMAs x 32 cycles per 16 k per 32x32 tile
-static int g_small_pp = -1;       // SDVAR_GEMM_SMALL_PP (A/B runs): 0 = the 4-wave ring kernel for 64-row tiles too, 1 (default) = the K-split ping-pong kernel
-static bool small_pp_on() {
-    if (g_small_pp < 0) { const char* e = getenv("SDVAR_GEMM_SMALL_PP"); g_small_pp = e ? atoi(e) : 1; }
-    return g_small_pp != 0;
+static int g_small_pp = -1;       // SDVAR_GEMM_SMALL_PP (A/B runs): 0 = the 4-wave ring kernel for every small tile, 1 = the K-split ping-pong kernel for 64-row tiles, 2 (default) = for 32-row tiles too
+static int small_pp_on() {          // 0 = ring kernel for every small tile, 1 = K-split ping-pong kernel for 64-row tiles, 2 = for 32-row tiles too
+    if (g_small_pp < 0) { const char* e = getenv("SDVAR_GEMM_SMALL_PP"); g_small_pp = e ? atoi(e) : 2; }          // default 2: qkv / fc1 at M = 144 / 256 16.7 -> 14.0 us, gemm_small class -2 % (profiles/r03_U_pp32_ab.log)
+    return g_small_pp;
 }
+static inline bool bm_is(int a, int b) { return a == b; }
 static void choose_cfg_h(int M, int N, int K, size_t ws_floats, int* bm_out, int* split_out, int* tail_out, bool allow_hybrid, bool deferred) {
     const int nkt = K / HBK, tiles_n = (N + HBN - 1) / HBN;
     double best = 1e30; int bbm = 128, bs = 1, btail = 0;
-    const bool spp = small_pp_on();       // the 64-row tile runs on gemm_f16x2_small_pp_kernel: 144 KB of LDS = ONE workgroup per CU, K-step ~0.8 of the ring kernel's (profiles/r03_x_smallpp_ab.log)
+    const bool spp = small_pp_on() >= 1, spp32 = small_pp_on() >= 2;       // the 64-row tile runs on gemm_f16x2_small_pp_kernel: 144 KB of LDS = ONE workgroup per CU, K-step ~0.8 of the ring kernel's (profiles/r03_x_smallpp_ab.log)
     // per row-tile constants fitted to tools/gemm_bench.py --mode bf16x3 --sweep --dump (tools/fit_gemm_model.py):
     //   resident workgroups per CU, K-step cost factor over the MFMA time, slowdown when 1 / 2 / 3 workgroups share a CU
     const int bms[4] = {256, 128, 64, 32};
@@ -1620,9 +1650,10 @@ static void choose_cfg_h(int M, int N, int K, size_t ws_floats, int* bm_out, int
     const double kfac[4] = {CM_P256, 1.0, CM_P64, CM_P32};
     const double lat[5] = {0.0, CM_L1, CM_L2, CM_L3, 1.0};
     for (int bi = 0; bi < 4; ++bi) {
-        const int bm = bms[bi], res = (bm == 64 && spp) ? 1 : resident[bi];
+        const bool ppk = (bm_is(bms[bi], 64) && spp) || (bm_is(bms[bi], 32) && spp32);
+        const int bm = bms[bi], res = ppk ? 1 : resident[bi];
         const int tiles = ((M + bm - 1) / bm) * tiles_n;
-        const double ktile = 192.0 * (bm / 32) * kfac[bi] * ((bm == 64 && spp) ? 0.8 : 1.0);              // 3 MFMAs x 32 cycles x 2 k16-steps per 32x32 sub-tile
+        const double ktile = 192.0 * (bm / 32) * kfac[bi] * (ppk ? 0.8 : 1.0);              // 3 MFMAs x 32 cycles x 2 k16-steps per 32x32 sub-tile
         for (int split = 1; split <= 32 && split <= nkt / 2; ++split) {
             if (split > 1 && ((size_t)split * M * N > ws_floats || N % 4)) break;
             const int kps = (nkt + split - 1) / split;
@@ -1877,18 +1908,18 @@ static int launch_small_kernel(const GemmHArgs& a, int grid, hipStream_t stream)
     SDVAR_LAUNCH_CHECK();
     return SDVAR_OK;
 }
-template <int EPI>
+template <int BM, int EPI>
 static int launch_small_pp(const GemmHArgs& a, int grid, hipStream_t stream) {
-    const size_t lds = (size_t)6 * SPP_STAGE * sizeof(uint16_t);
+    const size_t lds = (size_t)6 * spp_stage<BM>() * sizeof(uint16_t);          // 144 KB (BM = 64) / 120 KB (BM = 32): one workgroup per CU
     static LdsOptIn opt_in;
-    SDVAR_LDS_OPT_IN(opt_in, lds, (const void*)gemm_f16x2_small_pp_kernel<EPI>);
-    hipLaunchKernelGGL((gemm_f16x2_small_pp_kernel<EPI>), dim3(grid), dim3(512), lds, stream, a);
+    SDVAR_LDS_OPT_IN(opt_in, lds, (const void*)gemm_f16x2_small_pp_kernel<BM, EPI>);
+    hipLaunchKernelGGL((gemm_f16x2_small_pp_kernel<BM, EPI>), dim3(grid), dim3(512), lds, stream, a);
     SDVAR_LAUNCH_CHECK();
     return SDVAR_OK;
 }
 template <int BM, int EPI>
 static int launch_small_any(const GemmHArgs& a, int grid, hipStream_t stream) {
-    if (BM == 64 && small_pp_on() && !a.stamps) return launch_small_pp<EPI>(a, grid, stream);
+    if (!a.stamps && (BM == 64 ? small_pp_on() : small_pp_on() >= 2)) return launch_small_pp<BM, EPI>(a, grid, stream);          // gemm_small_pp: 1 = 64-row tiles only, 2 = 32-row tiles too
     return launch_small_kernel<BM, 3, EPI>(a, grid, stream);
 }
 

@@ -595,7 +595,8 @@ def test_gemm_f16x2_kernels_forced_tile(dev, M, N, K, split, epi, bm):
 
 VARIANTS = [("gemm_h4_var", 0, 512), ("gemm_h4_var", 1, 512), ("gemm_h4_var", 2, 512),          # the 256 x 256 kernel on 32x32x16 MFMAs, three DMA placements
             ("gemm_h2_stages", 4, 128), ("gemm_h2_stages", 3, 128), ("gemm_h2_stages", 2, 128), ("gemm_h2_stages", 5, 128),      # the 128 x 128 kernel without the ping-pong schedule
-            ("gemm_small_pp", 0, 64)]                                                                    # 64-row tiles on the 4-wave ring kernel
+            ("gemm_small_pp", 0, 64),                                                                    # 64-row tiles on the 4-wave ring kernel
+            ("gemm_small_pp", 1, 32), ("gemm_small_pp", 0, 32)]                                          # 32-row tiles on the 4-wave ring kernel
 
 
 @pytest.mark.parametrize("name,value,bm", VARIANTS)
