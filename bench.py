@@ -113,7 +113,11 @@ def main():
 
     # The VQVAE decode of batch i runs on a second HIP stream and overlaps the sampling loop of batch i+1 (whose early
     # stages leave most CUs idle); f_hat is double-buffered and every decode is finished inside the timed region.
-    decode = vae.fhat_to_img_torch if args.torch_decode else vae.fhat_to_img
+    decode = vae.fhat_to_img
+    if args.torch_decode:          # A/B only: the PyTorch/MIOpen decoder of tests/torch_ref.py (test infrastructure, not the product path)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from torch_ref import fhat_to_img_torch
+        decode = lambda f: fhat_to_img_torch(vae, f)
     if args.sampler_high_prio:
         torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1))
     main_stream = torch.cuda.current_stream()

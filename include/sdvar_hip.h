@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SDVAR_ABI_VERSION 3      /* 3 (round 3): the f16-plane KV-cache formats 3 / 4 store V row-major like K; new debug entry points (guard, gemm cfg getter) */
+#define SDVAR_ABI_VERSION 4      /* 4 (round 4): sdvar_cfg_combine; 3 (round 3): the f16-plane KV-cache formats 3 / 4 store V row-major like K; new debug entry points (guard, gemm cfg getter) */
 #define SDVAR_MAX_STAGES 16
 
 typedef struct sdvar_model sdvar_model_t;   /* one VAR transformer: weights (borrowed), KV cache, workspaces */
@@ -178,6 +178,11 @@ int sdvar_verify_accept_ex(const float* logits, int32_t B, int32_t lsum, int32_t
                            const double* t /*host*/, const int64_t* draft_ids, int32_t ids_stride, double thr, int32_t rule, int32_t match_top_k,
                            double kl_thr, const float* draft_logits, int32_t* counts, int64_t* argmax_out, uint8_t* match_out,
                            int64_t* corrected_out, void* stream);
+
+/* var.py:1062-1067 alone: out (B, lsum, V) = (1 + t_j) * logits[b] - t_j * logits[B + b] for every stage j of a verified chunk (float32 roundings of torch's
+ * scalar ops): the per-stage CFG logits SDVAR.target_verify_batch returns to a caller that drives the reference's step functions itself. */
+int sdvar_cfg_combine(const float* logits, int32_t B, int32_t lsum, int32_t V, int32_t n_stages, const int32_t* stage_lens /*host*/, const double* t /*host*/,
+                      float* out, void* stream);
 
 /* ---- single operators (kernel-level parity tests and micro-benchmarks) ---------------------------------------------- */
 /* out[M,N] = epi(X[M,K] W[N,K]^T + bias); epi 0 bias, 1 bias+GELU(tanh), 2 res + (.)*gate[row / rows_per_gate] */

@@ -57,6 +57,7 @@ int noise_fill(float* q, int B, int l, int V, uint64_t seed, uint32_t draw, uint
 int verify_accept(const float* logits, int B, int lsum, int V, int n_chunk, const int* qbeg, const float* one_plus_t, const float* t, const long long* draft_ids,
                   int ids_stride, double thr, int mode, int top_k, float kl_thr, const float* draft_logits, const long long* dl_off, int* counts,
                   long long* argmax_out, unsigned char* match_out, long long* corrected_out, hipStream_t stream);
+int cfg_combine(const float* logits, int B, int lsum, int V, int n_chunk, const int* qbeg, const float* one_plus_t, const float* t, float* out, hipStream_t stream);
 int gumbel_mix(const float* masked, int B, int l, int V, float scale, float tau, const float* e, uint64_t seed, uint32_t draw, uint32_t image_offset,
                const float* codebook, int Cv, float* h, hipStream_t stream);
 void debug_set_gemm_cfg(int bm, int split);
@@ -715,6 +716,15 @@ int sdvar_verify_accept_ex(const float* logits, int32_t B, int32_t lsum, int32_t
 int sdvar_verify_accept(const float* logits, int32_t B, int32_t lsum, int32_t V, int32_t n, const int32_t* stage_lens, const double* t,
                         const int64_t* draft_ids, int32_t ids_stride, double thr, int32_t* counts, int64_t* argmax_out, void* stream) {
     return sdvar_verify_accept_ex(logits, B, lsum, V, n, stage_lens, t, draft_ids, ids_stride, thr, 0, 0, 0.0, nullptr, counts, argmax_out, nullptr, nullptr, stream);
+}
+
+int sdvar_cfg_combine(const float* logits, int32_t B, int32_t lsum, int32_t V, int32_t n, const int32_t* stage_lens, const double* t, float* out, void* stream) {
+    SDVAR_CHECK_ARG(stage_lens && t && n >= 1 && n <= SDVAR_MAX_STAGES, "cfg_combine: bad stage table");
+    int qbeg[SDVAR_MAX_STAGES]; float opt[SDVAR_MAX_STAGES], tf[SDVAR_MAX_STAGES]; int acc = 0;
+    for (int j = 0; j < n; ++j) { qbeg[j] = acc; acc += stage_lens[j]; opt[j] = (float)(1.0 + t[j]); tf[j] = (float)t[j]; }
+    SDVAR_CHECK_ARG(acc == lsum, "cfg_combine: stage lens sum %d != lsum %d", acc, lsum);
+    ProfScope ps(5, 0, 4.0 * 3.0 * B * lsum * V, (hipStream_t)stream);
+    return cfg_combine(logits, B, lsum, V, n, qbeg, opt, tf, out, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------------- single ops

@@ -604,4 +604,37 @@ int verify_accept(const float* logits, int B, int lsum, int V, int n_chunk, cons
     return SDVAR_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ cfg_combine
+// out (B, lsum, V) = (1 + t_j) * cond - t_j * uncond per stage j of a verified chunk, with torch's roundings (var.py:1062-1067): what
+// SDVAR.target_verify_batch hands back to a caller that drives the reference's step functions itself.
+__global__ __launch_bounds__(256) void cfg_combine_kernel(AcceptArgs a, float* __restrict__ out) {
+    const int tok = blockIdx.x, b = blockIdx.y, V = a.V;
+    int st = 0;
+#pragma unroll 1
+    for (int j = 1; j < a.n_chunk; ++j) if (tok >= a.qbeg[j]) st = j;
+    const float opt = a.one_plus_t[st], tt = a.t[st];
+    const float* pc = a.logits + ((size_t)b * a.lsum + tok) * V;
+    const float* pu = a.logits + ((size_t)(a.B + b) * a.lsum + tok) * V;
+    float* po = out + ((size_t)b * a.lsum + tok) * V;
+    for (int v0 = 4 * threadIdx.x; v0 < V; v0 += 1024) {
+        const f32x4 c = *reinterpret_cast<const f32x4*>(pc + v0), u = *reinterpret_cast<const f32x4*>(pu + v0);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = __fsub_rn(__fmul_rn(opt, c[e]), __fmul_rn(tt, u[e]));
+        *reinterpret_cast<f32x4*>(po + v0) = o;
+    }
+}
+
+int cfg_combine(const float* logits, int B, int lsum, int V, int n_chunk, const int* qbeg, const float* one_plus_t, const float* t, float* out, hipStream_t stream) {
+    SDVAR_CHECK_ARG(logits && out, "cfg_combine: null operand");
+    SDVAR_CHECK_ARG(n_chunk >= 1 && n_chunk <= ACC_MAX_CHUNK && V % 4 == 0 && B >= 1 && lsum >= 1, "cfg_combine: bad chunk/V");
+    AcceptArgs a{};
+    a.logits = logits; a.B = B; a.lsum = lsum; a.V = V; a.n_chunk = n_chunk;
+    for (int j = 0; j < n_chunk; ++j) { a.qbeg[j] = qbeg[j]; a.one_plus_t[j] = one_plus_t[j]; a.t[j] = t[j]; }
+    a.qbeg[n_chunk] = lsum;
+    hipLaunchKernelGGL(cfg_combine_kernel, dim3(lsum, B), dim3(256), 0, stream, a, out);
+    SDVAR_LAUNCH_CHECK();
+    return SDVAR_OK;
+}
+
 }  // namespace sdvar

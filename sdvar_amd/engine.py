@@ -25,7 +25,7 @@ from .noise import exponential_noise
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsdvar_hip.so")
 MAX_STAGES = 16
-ABI_VERSION = 3
+ABI_VERSION = 4
 # GEMM arithmetic of the transformer blocks: 'f32' = fp32-in/fp32-accumulate MFMA; 'bf16x3' = exact 3-way bf16 split of both
 # operands, 6 bf16 MFMA products, fp32 accumulate (fp32-accurate, 2.67x the matrix-pipe throughput).  See DESIGN.md section 4.
 #   'f16x2' = two fp16 planes per operand (x ~ xh + xl to 2^-22), 3 fp16 MFMA products, fp32 accumulate: half the matrix work of bf16x3 at the same
@@ -86,6 +86,7 @@ _SIGNATURES = {
     "sdvar_vae_decode": (_I, [_P, _P, _I, _P, _P]),
     "sdvar_cfg_sample": (_I, [_P, _I, _I, _I, _D, _I, _D, _P, _U64, _U32, _U32, _P, _I, _P, _P]),
     "sdvar_verify_accept": (_I, [_P, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_D), _P, _I, _D, _P, _P, _P]),
+    "sdvar_cfg_combine": (_I, [_P, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_D), _P, _P]),
     "sdvar_verify_accept_ex": (_I, [_P, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_D), _P, _I, _D, _I, _I, _D, _P, _P, _P, _P, _P, _P]),
     "sdvar_op_gemm": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P]),
     "sdvar_op_ln_modulate": (_I, [_P, _P, _P, _P, _P, _U64, _I, _I, _I, _I, _I, _P]),
@@ -472,6 +473,14 @@ def verify_accept(logits: torch.Tensor, B: int, lens: Sequence[int], V: int, ts:
     _check(lib.sdvar_verify_accept_ex(_ptr(logits), B, int(sum(lens)), V, n, (_I * n)(*lens), (_D * n)(*[float(t) for t in ts]),
                                       C.c_void_p(ids.data_ptr() + 8 * ids_off), ids_stride, float(thr), r.code, int(r.top_k), float(r.kl_thr),
                                       o(draft_logits), _ptr(counts), o(argmax_out), o(match_out), o(corrected_out), _stream()))
+
+
+def cfg_combine(logits: torch.Tensor, B: int, lens: Sequence[int], V: int, ts: Sequence[float]) -> List[torch.Tensor]:
+    """var.py:1062-1067 on a verified chunk's raw logits (2B, sum(lens), V): the per-stage CFG logits (B, l_j, V), one kernel (csrc/sampler.hip)."""
+    n, lsum = len(lens), int(sum(lens))
+    out = torch.empty(B, lsum, V, dtype=torch.float32, device=logits.device)
+    _check(load_library().sdvar_cfg_combine(_ptr(logits), B, lsum, V, n, (_I * n)(*lens), (_D * n)(*[float(t) for t in ts]), _ptr(out), _stream()))
+    return list(out.split([int(x) for x in lens], dim=1))
 
 
 def last_gemm_cfg() -> Dict[str, int]:

@@ -313,11 +313,9 @@ class SDVAR(nn.Module):
         assert len(draft_tokens) == state.g, "target_verify_batch verifies the stages of the last draft_generate_batch"
         smp, lad, cur = state.sampler, state.sampler.lad, state.current_stage
         lg = smp.spec_verify_forward(state)
-        out, off = [], 0
-        for j in range(state.g):
-            n, t = lad.lens[cur + j], lad.cfg_t(state.cfg, cur + j)
-            out.append((1 + t) * lg[:B, off:off + n] - t * lg[B:, off:off + n])                      # var.py:1062-1067
-            off += n
+        lens = [lad.lens[cur + j] for j in range(state.g)]
+        with torch.cuda.device(lg.device):                                                           # var.py:1062-1067 (csrc/sampler.hip cfg_combine_kernel)
+            out = E.cfg_combine(lg, B, lens, lg.shape[-1], [lad.cfg_t(state.cfg, cur + j) for j in range(state.g)])
         return out, state.g
 
     def _match(self, draft_tokens, target_logits, B: int, rule: E.MatchRule, draft_logits=None):

@@ -2,9 +2,9 @@
 
 The quantizer tensors (codebook, shared Phi convs) feed sdvar_amd/csrc/quant.hip; the conv decoder `fhat_to_img`
 (/root/reference/models/vqvae.py:62-63, models/basic_vae.py:163-226) runs as hand-written HIP
-(csrc/conv.hip, csrc/vae.hip) through engine.VaeCtx.  The nn.Module graph below exists for the parameter names - they follow
-the upstream checkpoint `vae_ch160v4096z32.pth` so it loads unchanged - and as the PyTorch reference the GPU parity tests
-compare against (`fhat_to_img_torch`); the sampler never runs it.  The encoder is parameters only (sampling never encodes).
+(csrc/conv.hip, csrc/vae.hip) through engine.VaeCtx.  The nn.Module tree below exists for the parameter names only - they follow
+the upstream checkpoint `vae_ch160v4096z32.pth` so it loads unchanged.  No module here has a forward(): there is no torch math in this package
+(the PyTorch decoder the GPU parity tests compare against lives in tests/torch_ref.py).  The encoder is parameters only (sampling never encodes).
 """
 from __future__ import annotations
 
@@ -12,7 +12,6 @@ from typing import Sequence
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 
 def _gn(c): return nn.GroupNorm(32, c, eps=1e-6, affine=True)
@@ -25,11 +24,6 @@ class _Res(nn.Module):
         self.norm2, self.conv2 = _gn(cout), nn.Conv2d(cout, cout, 3, 1, 1)
         self.nin_shortcut = nn.Conv2d(cin, cout, 1) if cin != cout else nn.Identity()
 
-    def forward(self, x):
-        h = self.conv1(F.silu(self.norm1(x)))
-        h = self.conv2(F.silu(self.norm2(h)))
-        return self.nin_shortcut(x) + h
-
 
 class _Attn(nn.Module):
     def __init__(self, c):
@@ -37,21 +31,11 @@ class _Attn(nn.Module):
         self.C = c
         self.norm, self.qkv, self.proj_out = _gn(c), nn.Conv2d(c, 3 * c, 1), nn.Conv2d(c, c, 1)
 
-    def forward(self, x):
-        B, C, H, W = x.shape
-        q, k, v = self.qkv(self.norm(x)).reshape(B, 3, C, H * W).unbind(1)
-        w = torch.bmm(q.transpose(1, 2), k).mul_(C ** -0.5).softmax(dim=2)
-        h = torch.bmm(v, w.transpose(1, 2)).view(B, C, H, W)
-        return x + self.proj_out(h)
-
 
 class _Up(nn.Module):
     def __init__(self, c):
         super().__init__()
         self.conv = nn.Conv2d(c, c, 3, 1, 1)
-
-    def forward(self, x):
-        return self.conv(F.interpolate(x, scale_factor=2, mode="nearest"))
 
 
 class _Down(nn.Module):
@@ -81,18 +65,6 @@ class Decoder(nn.Module):
                 up.upsample = _Up(bi)
             self.up.insert(0, up)
         self.norm_out, self.conv_out = _gn(bi), nn.Conv2d(bi, 3, 3, 1, 1)
-
-    def forward(self, z):
-        h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(self.conv_in(z))))
-        for lv in reversed(range(len(self.up))):
-            up = self.up[lv]
-            for ib, blk in enumerate(up.block):
-                h = blk(h)
-                if len(up.attn):
-                    h = up.attn[ib](h)
-            if lv != 0:
-                h = up.upsample(h)
-        return self.conv_out(F.silu(self.norm_out(h)))
 
 
 class Encoder(nn.Module):
@@ -173,7 +145,7 @@ class VQVAE(nn.Module):
         """(B, Cvae, h, w) -> (B, 3, 16h, 16w) in [-1, 1] on the HIP decoder.  GPU tensors only: there is no CPU path."""
         from . import engine as E
         if not f_hat.is_cuda:
-            raise E.SdvarError("VQVAE.fhat_to_img runs on the HIP decoder and needs a GPU tensor (fhat_to_img_torch is the PyTorch test reference)")
+            raise E.SdvarError("VQVAE.fhat_to_img runs on the HIP decoder and needs a GPU tensor (tests/torch_ref.py holds the PyTorch test reference)")
         B, hw = f_hat.shape[0], f_hat.shape[-1]
         ctx = self._hip_ctx
         if ctx is None or ctx.device != f_hat.device or ctx.max_batch < B or ctx.latent_hw != hw:
@@ -188,11 +160,6 @@ class VQVAE(nn.Module):
         if self._hip_ctx is not None:
             self._hip_ctx.close()
         self._hip_ctx = None
-
-    @torch.no_grad()
-    def fhat_to_img_torch(self, f_hat: torch.Tensor) -> torch.Tensor:
-        """The same function on PyTorch ops (MIOpen on a GPU): test reference only."""
-        return self.decoder(self.post_quant_conv(f_hat)).clamp_(-1, 1)
 
     def load_state_dict(self, state_dict, strict=True, assign=False):  # vqvae.py:92-95
         key = "quantize.ema_vocab_hit_SV"

@@ -21,7 +21,7 @@ def test_header_symbols_exported_and_bound():
         assert hasattr(lib, s), f"{s} declared in include/sdvar_hip.h but not exported by libsdvar_hip.so"
         assert s in E._SIGNATURES, f"{s} has no ctypes prototype in sdvar_amd/engine.py"
     assert set(E._SIGNATURES) == set(syms)
-    assert lib.sdvar_abi_version() == E.ABI_VERSION == 3
+    assert lib.sdvar_abi_version() == E.ABI_VERSION == 4
 
 
 def test_argument_errors_are_reported_without_gpu():
@@ -54,6 +54,31 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f"{f} imports the oracle"
+
+
+def test_product_has_no_torch_math():
+    """sdvar_amd/ uses torch for device memory, streams and process groups only: no torch.nn.functional, matmul-like or softmax calls, and no nn.Module with a
+    forward() (the PyTorch decoder the parity tests compare against is tests/torch_ref.py)."""
+    pkg = os.path.join(ROOT, "sdvar_amd")
+    pat = re.compile(r"torch\.nn\.functional|\bF\.[a-z_]+\(|torch\.(bmm|matmul|mm|einsum|softmax|conv2d|addmm)\b|\.softmax\(|\.bmm\(|\.matmul\(")
+    import io
+    import tokenize
+    for f in sorted(os.listdir(pkg)):
+        if f.endswith(".py"):
+            src = open(os.path.join(pkg, f)).read()
+            by_line = {}
+            for tok in tokenize.generate_tokens(io.StringIO(src).readline):          # code only: strings (docstrings cite torch ops) and comments dropped
+                if tok.type not in (tokenize.STRING, tokenize.COMMENT):
+                    by_line.setdefault(tok.start[0], []).append(tok.string)
+            for ln, toks in sorted(by_line.items()):
+                code = "".join(toks)
+                assert not pat.search(code), f"sdvar_amd/{f}:{ln}: torch math in the product package: {code.strip()}"
+    import torch.nn as nn
+    from sdvar_amd import var as V, vqvae as Q
+    for mod in (V, Q):
+        for name, cls in vars(mod).items():
+            if isinstance(cls, type) and issubclass(cls, nn.Module) and cls.__module__ == mod.__name__ and "forward" in cls.__dict__:
+                assert name == "VAR", f"{mod.__name__}.{name} defines forward(): parameter containers only"      # VAR.forward raises (training is out of scope)
 
 
 def test_vae_bind_order_matches_the_state_dict_walk():

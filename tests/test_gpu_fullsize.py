@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from sdvar_amd import engine as E
+from torch_ref import fhat_to_img_torch
 from sdvar_amd.ladder import LADDER_256, LADDER_512, as_ladder
 from sdvar_amd.weights import vae_state_dict, var_state_dict_device
 
@@ -175,7 +176,7 @@ def test_P1_d12_draft_d16_verify_B8(dev):
     vae = VQVAE(vocab_size=4096, z_channels=32, ch=160, v_patch_nums=pns, with_encoder=False)
     vae.load_state_dict(sd_v); vae = vae.to(dev)
     img = vae.fhat_to_img(f_a.clone())
-    ref = vae.fhat_to_img_torch(f_a.clone())
+    ref = fhat_to_img_torch(vae, f_a.clone())
     assert torch.isfinite(img).all() and img.shape == (B, 3, 256, 256)
     assert (img - ref).abs().max().item() <= 1e-4
     _close(objs)

@@ -12,6 +12,7 @@ import torch.nn.functional as F
 
 from conftest import rnd
 from sdvar_amd import engine as E
+from torch_ref import fhat_to_img_torch
 from sdvar_amd.vqvae import VQVAE
 from sdvar_amd.weights import vae_state_dict
 
@@ -130,7 +131,7 @@ def _decode_pair(dev, ch, B, latent=16, seed=11, conv_mode=None):
 def test_decoder_small_width_matches_pytorch(dev, cm):
     vae, ctx, f_hat = _decode_pair(dev, 32, 3, conv_mode=cm)
     got = ctx.decode(f_hat)
-    want = vae.fhat_to_img_torch(f_hat.clone())
+    want = fhat_to_img_torch(vae, f_hat.clone())
     assert got.shape == want.shape == (3, 3, 256, 256)
     err = (got - want).abs().max().item()
     assert err <= 1e-4, err
@@ -152,7 +153,7 @@ def test_decoder_reference_width_matches_pytorch(dev, cm):
         got = ctx.decode(f_hat)
     finally:
         E._check(lib.sdvar_debug_set_variant(b"conv_pp", -1))
-    want = vae.fhat_to_img_torch(f_hat.clone())
+    want = fhat_to_img_torch(vae, f_hat.clone())
     err = (got - want).abs().max().item()
     assert err <= 1e-4, err
     assert float(got.min()) >= -1.0 and float(got.max()) <= 1.0
@@ -162,7 +163,7 @@ def test_decoder_512_geometry(dev):
     """BASELINE config P4 decodes 32x32 latents to 512^2: 1024-token attention blocks, 4x the rows everywhere."""
     vae, ctx, f_hat = _decode_pair(dev, 32, 1, latent=32)
     got = ctx.decode(f_hat)
-    want = vae.fhat_to_img_torch(f_hat.clone())
+    want = fhat_to_img_torch(vae, f_hat.clone())
     assert got.shape == want.shape == (1, 3, 512, 512)
     err = (got - want).abs().max().item()
     assert err <= 1e-4, err
@@ -173,7 +174,7 @@ def test_decoder_1024_geometry(dev):
     through the decoder's split-K workspace (vae_attn_kernel<true>)."""
     vae, ctx, f_hat = _decode_pair(dev, 32, 1, latent=64)
     got = ctx.decode(f_hat)
-    want = vae.fhat_to_img_torch(f_hat.clone())
+    want = fhat_to_img_torch(vae, f_hat.clone())
     assert got.shape == want.shape == (1, 3, 1024, 1024)
     err = (got - want).abs().max().item()
     assert err <= 1e-4, err
@@ -192,7 +193,7 @@ def test_module_entry_point_uses_the_hip_decoder(dev):
     vae, ctx, f_hat = _decode_pair(dev, 32, 2)
     got = vae.fhat_to_img(f_hat)
     assert torch.equal(got, ctx.decode(f_hat))
-    assert (got - vae.fhat_to_img_torch(f_hat.clone())).abs().max().item() <= 1e-4
+    assert (got - fhat_to_img_torch(vae, f_hat.clone())).abs().max().item() <= 1e-4
     with pytest.raises(E.SdvarError):
         vae.fhat_to_img(f_hat.cpu())
 
