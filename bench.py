@@ -303,7 +303,7 @@ def main():
         extra["speculation_gain"] = dict({m: extra[m]["images_per_s"] / plain for m in ("accept_all", "reject_all", "natural") if m in extra}, **{args.mode: value / plain},
                                          note="images/s of the speculative sampler / images/s of plain_target_ar, same GPU, same decode overlap; with a d12 draft in front of a d16 target "
                                               "(43 % of its flops) and the large stages matrix-pipe bound at B=8, chunked verification cannot recover the draft's cost: see DESIGN.md section 5")
-        if rank == 0 and world == 1 and args.config == "P1":
+        if rank == 0 and world == 1:
             # (d) SURVEY App. C.2: draft == target weights, top_k = 1 - the one random-weight setting whose NATURAL acceptance is not degenerate (I1: everything accepted)
             dc_same = E.ModelCtx(sd_t, args.depth_target, pns, B, 1, dev, gemm_mode=args.gemm_mode, kv_fp16=conf["kv_fp16"])
             smp_same = E.Sampler(tc, qc, dc_same)
@@ -323,6 +323,34 @@ def main():
             extra["identical_draft_top1"] = dict(images_per_s=B * n / dts, mean_accepted_tokens_per_step=stx["accepted_tokens"] / max(1, stx["target_calls"]), target_calls=stx["target_calls"],
                                                  forced_accepts=stx["forced_accepts"], note=f"draft = the d{args.depth_target} target's own weights, top_k=1 (greedy), natural threshold 0.5: every stage is accepted (invariant I1)")
             log(f"identical draft, top_k=1: {extra['identical_draft_top1']['images_per_s']:.2f} images/s, {extra['identical_draft_top1']['mean_accepted_tokens_per_step']:.1f} accepted tokens/step")
+            # (d') where speculation pays: the speculative sampler against plain target AR at B = 1, 2, 4, 8 (the reference's own harness measures at B = 4,
+            # sdvar_colab_test.py:129,193,267-329, and expects 1.3-1.7x, PROJECT_STATUS_SUMMARY.md:33).  Sampler only (the decode is the same work on both sides and is
+            # left out), same model objects, gamma = 2 and 3 (a target context with room for 3-stage chunks shares nothing but the weights' source tensors).
+            tc3 = E.ModelCtx(sd_t, args.depth_target, pns, B, 3, dev, gemm_mode=args.gemm_mode, kv_fp16=conf["kv_fp16"])
+            smp3, smp_same3 = E.Sampler(tc3, qc, dc), E.Sampler(tc3, qc, dc_same)
+            byb = {}
+            for Bx in [b_ for b_ in (1, 2, 4, 8, 16) if b_ <= B]:
+                lb = labels[:Bx].contiguous()
+                def srate(fn, steps=max(3, args.steps // 3)):
+                    fn(0); torch.cuda.synchronize(); t0 = time.perf_counter()
+                    for i in range(steps):
+                        fn(200 + i)
+                    torch.cuda.synchronize()
+                    return Bx * steps / (time.perf_counter() - t0)
+                nz = lambda sd_: E.Noise("device", sd_, image_offset=lo)
+                row = dict(plain_target_ar=srate(lambda sd_: smp_t.plain_ar(lb, CFG, 900, 0.96, nz(sd_))))
+                for gmm, sa, ss in ((2, smp, smp_same), (3, smp3, smp_same3)):
+                    row[f"accept_all_gamma{gmm}"] = srate(lambda sd_: sa.spec_decode(lb, CFG, gmm, 900, 0.96, nz(sd_), thr=0.0, run_ahead=not args.no_run_ahead))
+                    row[f"identical_draft_top1_gamma{gmm}"] = srate(lambda sd_: ss.spec_decode(lb, CFG, gmm, 1, 0.0, nz(sd_), thr=0.5))
+                row["gain"] = {k: v / row["plain_target_ar"] for k, v in row.items() if k != "plain_target_ar"}
+                byb[str(Bx)] = row
+                log(f"B={Bx}: plain {row['plain_target_ar']:.1f} images/s; gain " + ", ".join(f"{k} {v:.2f}" for k, v in row["gain"].items()))
+            best = max(((g_, k, bx) for bx, r in byb.items() for k, g_ in r["gain"].items()), key=lambda t_: t_[0])
+            extra["speculation_gain_by_batch"] = dict(rows=byb, best=dict(gain=best[0], mode=best[1], batch=int(best[2])),
+                note=f"sampler-only images/s (no decode on either side) of d{args.depth_draft} -> d{args.depth_target} speculation / plain d{args.depth_target} AR at each batch size; accept_all = every "
+                     f"round accepted at threshold 0 with the d{args.depth_draft} draft (the loop's best case), identical_draft_top1 = a d{args.depth_target} draft that the target accepts naturally; "
+                     "gain >= 1 means speculation pays at that batch")
+            tc3.close(); del smp3, smp_same3
             dc_same.close(); del smp_same
             # (e) the exact split-operand mode (bf16x3: no range limit on the activations; f16x2 saturates at +-65504), same loop
             if tc.gemm_mode != "bf16x3":
@@ -426,6 +454,7 @@ def main():
         "config": {"workload": f"BASELINE.json {args.config}: VAR-d{args.depth_target} {conf['ladder']}^2 B={B}/GPU, d{args.depth_draft} draft + d{args.depth_target} verify, gamma={args.gamma}, "
                                f"cfg={CFG} top_k=900 top_p=0.96, {'fp16 KV cache, ' if conf['kv_fp16'] else ''}acceptance={args.mode}, incl. VQVAE decode ({'serial' if args.serial_decode else 'overlapped with the next batch on a 2nd stream'}); "
                                f"verifier {'in lock-step with' if args.no_run_ahead else 'one round behind'} the draft once gamma = 1", "parallelism": f"{world} independent batch shards"},
+        "value_bf16x3": extra.get("bf16x3", {}).get("images_per_s"),          # the same loop in the exact-split mode (no activation range limit): quote it beside `value`
         "mean_accepted_tokens_per_step": agg["mean_accepted_tokens_per_step"],
         "target_calls": agg["target_calls"], "draft_stage_calls": agg["draft_stage_calls"], "forced_accepts": agg["forced_accepts"],
         "per_rank_counters": dict(keys=list(D.COUNTER_KEYS), rows=agg["per_rank"], note="all-gathered over the process group (RCCL on the GPU box): one row per rank"),

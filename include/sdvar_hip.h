@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SDVAR_ABI_VERSION 4      /* 4 (round 4): sdvar_cfg_combine; 3 (round 3): the f16-plane KV-cache formats 3 / 4 store V row-major like K; new debug entry points (guard, gemm cfg getter) */
+#define SDVAR_ABI_VERSION 4      /* 4 (round 4): sdvar_cfg_combine, sdvar_op_gemm_rowblk, sdvar_debug_set_rowblk; 3 (round 3): the f16-plane KV-cache formats 3 / 4 store V row-major like K; new debug entry points (guard, gemm cfg getter) */
 #define SDVAR_MAX_STAGES 16
 
 typedef struct sdvar_model sdvar_model_t;   /* one VAR transformer: weights (borrowed), KV cache, workspaces */
@@ -237,6 +237,18 @@ int sdvar_debug_set_gemm_cfg(int32_t bm, int32_t split);
 /* test aid: 0 = the QKV launch of sdvar_stage_forward never finishes q and k in its epilogue (qk_norm_append does all three), 1 (default) = it does
  * whenever the launch comes out unsplit on the f16x2 planes cache */
 int sdvar_debug_set_qkv_fuse(int32_t on);
+/* 1 (default): stage_forward calls with 32 .. 80 rows (stage 1, the first verify chunk at B = 8) in GEMM mode f16x2 run five launches per transformer block - LayerNorm +
+ * modulation in the operand prologue of the QKV / fc1 / head launch, q / k / v finished by the QKV launch, fc2 unsplit (csrc/gemm_f16x2.hip gemm_f16x2_rowblk_kernel);
+ * 0: the launch sequence of every other row count (ln_modulate, GEMM, qk_norm_append: eight launches); 2: five launches at every row count up to 80 (below 32 rows they are SLOWER than the eight: measured).
+ * Test / A-B aid (SDVAR_ROWBLK in the environment does the same). */
+int sdvar_debug_set_rowblk(int32_t on);
+/* The row-block launch alone (M <= 80).  x != NULL: out = epi( (LayerNorm(x; eps 1e-6)(1 + scale[g]) + shift[g]) W^T + bias ), g = row / rows_per_img, K <= 1024, epi 0 (-> out) or
+ * 1 (GELU -> out_planes); with q_out != NULL the QKV finish instead (N = 3 H 64; q -> (R, H, l, 64) fp32, k normalised / v -> the cache planes at pos0 + t, kv_fmt 3 | 4) and nothing
+ * goes to `out`.  x == NULL: the operand is Xp (K-blocked f16x2 planes, K <= 4096), epi 0 or 2 (gated residual). */
+int sdvar_op_gemm_rowblk(const float* x, int32_t ldx, const float* scale, const float* shift, int32_t rows_per_img, int32_t mod_stride, const uint16_t* Xp, uint64_t x_plane_stride,
+                         const uint16_t* Wp, uint64_t w_plane_stride, const float* w_scale, const float* bias, float* out, int32_t ldo, uint16_t* out_planes, uint64_t out_plane_stride,
+                         int32_t M, int32_t N, int32_t K, int32_t epilogue, const float* res, int32_t ldres, const float* gate, int32_t rows_per_gate, int32_t gate_stride,
+                         const float* scale_mul, float* q_out, void* k_cache, void* v_cache, int32_t l, int32_t H, int32_t Lp, int32_t pos0, int32_t kv_fmt, void* stream);
 /* Select a kernel variant that otherwise only an environment variable (read at first use) selects - tests run the non-default variants in one process.
  * name: "gemm_h4_var" 0..3, "gemm_h2_stages" 2..6, "gemm_small_pp" 0..2, "attn_pp_sched" 0..3, "conv_pp" 0..2; value < 0 restores the environment / default. */
 int sdvar_debug_set_variant(const char* name, int32_t value);

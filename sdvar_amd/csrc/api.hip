@@ -23,6 +23,13 @@ size_t splitk_workspace_floats();
 int qk_norm_append(const float* qkv, const float* scale_mul, float* q_out, void* k_cache, void* v_cache, int kv_f16, int R, int l, int H, int Lmax, int pos0, const PendingSplitK* pend, int v_only, hipStream_t stream);
 int gemm_f16x2_qkv(const uint16_t* X, size_t xps, const uint16_t* W, size_t wps, const float* wsi, const float* bias, float* out, int ldo, int M, int N, int K,
                    const float* scale_mul, float* q_out, void* k_cache, void* v_cache, int l, int H, int Lp, int pos0, int kv_fmt, int* defer, int* fused, hipStream_t stream);
+bool gemm_f16x2_rowblk_ok(int M, int N, int K, int ln, int qkv);
+bool gemm_f16x2_rowblk_want(int M, int C, int V);
+int gemm_f16x2_rowblk(const float* x, int ldx, const float* scale, const float* shift, int rows_per_img, int mod_stride, const uint16_t* X, size_t xps,
+                      const uint16_t* W, size_t wps, const float* wsi, const float* bias, float* out, int ldo, uint16_t* outp, size_t ops, int M, int N, int K, int epi,
+                      const float* res, int ldres, const float* gate, int rows_per_gate, int gate_stride,
+                      const float* scale_mul, float* q_out, void* k_cache, void* v_cache, int l, int H, int Lp, int pos0, int kv_fmt, hipStream_t stream);
+void debug_set_rowblk(int v);
 int silu_rows(const float* x, float* y, int n, hipStream_t stream);
 int add_row_vector(const float* src, const float* vec, float* out, int rows, int cols, hipStream_t stream);
 int ada_gather(const long long* labels, const float* tab, size_t row_floats, int depth, int C, float* ada, size_t blk_stride, float* ada_head, int B, int num_classes,
@@ -510,6 +517,35 @@ static int stage_forward_impl(sdvar_model_t* m, float* x, int32_t s0, int32_t n,
 #else
     constexpr int skip = 0;
 #endif
+    // 32 .. 80 rows in GEMM mode f16x2 (round 4; stage 1 and the first verify chunk at B = 8): FIVE launches per block instead of eight - LayerNorm + modulation run in the operand prologue of the QKV / fc1 / head
+    // launch (gemm_f16x2_rowblk_kernel), the QKV launch finishes q, k and v (no qk_norm_append), fc2 streams K = 4C unsplit (no slabs for the next LayerNorm to sum).
+    // The f16x2 guard counts the operand planes ln_modulate writes, so a guarded call keeps the old sequence.
+    const bool RB = m->d.gemm_mode == 2 && (m->kv_fmt == 3 || m->kv_fmt == 4) && !g_guard_on && skip == 0 && gemm_f16x2_rowblk_want(M, C, V);
+    for (int i = 0; i < m->d.depth && RB; ++i) {
+        const BlockW& b = m->blk[i];
+        const float* ada = m->ada + (size_t)i * m->Rmax * 6 * C;
+        { ProfScope pp(GC, 2 * dM * 3 * dC * dC, 4 * (dM * dC + 3 * dC * dC + 3 * dM * dC), s);
+          SDVAR_TRY(gemm_f16x2_rowblk(x, C, ada + 2 * C, ada + 4 * C, lsum, 6 * C, nullptr, 0, b.qkv_wp, (size_t)3 * C * C, b.wsc + 1, b.qkv_bias, nullptr, 0, nullptr, 0, M, 3 * C, C, 0,
+                                      nullptr, 0, nullptr, 1, 0, b.scale_mul, m->qbuf, b.kc, b.vc, lsum, H, m->Lkv, m->kv_len, m->kv_fmt, s)); }
+        { ProfScope pp(lsum <= 36 ? 8 : 1, 4.0 * R * H * 64.0 * lk, R * H * 64.0 * ((m->d.kv_dtype ? 4.0 : 8.0) * Ktot + 8.0 * lsum), s);
+          if (bias) SDVAR_TRY(attention_masked(m->qbuf, b.kc, b.vc, m->kv_fmt, bias, m->att, m->att_p, ps, PF, R, H, lsum, m->Lkv, Ktot, s));
+          else SDVAR_TRY(attention_f32(m->qbuf, b.kc, b.vc, m->kv_fmt, m->att, m->att_p, ps, PF, R, H, lsum, m->Lkv, Ktot, n, qbeg, vis, s)); }
+        { ProfScope pp(GC, 2 * dM * dC * dC, 4 * (3 * dM * dC + dC * dC), s);          // proj: K = C, the skinny kernel streams it unsplit
+          SDVAR_TRY(plane_gemm(m, m->att_p, ps, b.proj_wp, (size_t)C * C, b.wsc + 4, b.proj_b, x, C, nullptr, 0, M, C, C, EPI_GATED_RES, x, C, ada, lsum, 6 * C, nullptr, s)); }
+        { ProfScope pp(GC, 2 * dM * 4 * dC * dC, 4 * (dM * dC + 4 * dC * dC + 4 * dM * dC), s);
+          SDVAR_TRY(gemm_f16x2_rowblk(x, C, ada + 3 * C, ada + 5 * C, lsum, 6 * C, nullptr, 0, b.fc1_wp, (size_t)4 * C * C, b.wsc + 9, b.fc1_b, nullptr, 0, m->hid_p, 4 * ps, M, 4 * C, C, EPI_BIAS_GELU,
+                                      nullptr, 0, nullptr, 1, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, s)); }
+        { ProfScope pp(GC, 2 * dM * 4 * dC * dC, 4 * (4 * dM * dC + 4 * dC * dC + 2 * dM * dC), s);
+          SDVAR_TRY(gemm_f16x2_rowblk(nullptr, 0, nullptr, nullptr, 1, 0, m->hid_p, 4 * ps, b.fc2_wp, (size_t)4 * C * C, b.wsc + 13, b.fc2_b, x, C, nullptr, 0, M, C, 4 * C, EPI_GATED_RES,
+                                      x, C, ada + C, lsum, 6 * C, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, s)); }
+    }
+    if (RB) {
+        ProfScope pp(GC, 2 * dM * dC * V, 4 * (dM * dC + dC * V + dM * V), s);
+        SDVAR_TRY(gemm_f16x2_rowblk(x, C, m->ada_head, m->ada_head + C, lsum, 2 * C, nullptr, 0, m->head_wp, (size_t)V * C, m->head_wsc + 1, m->head_b, logits, V, nullptr, 0, M, V, C, EPI_BIAS,
+                                    nullptr, 0, nullptr, 1, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, s));
+        m->kv_len = Ktot;
+        return SDVAR_OK;
+    }
     for (int i = 0; i < m->d.depth; ++i) {
         const BlockW& b = m->blk[i];
         const float* ada = m->ada + (size_t)i * m->Rmax * 6 * C;      // (R, 6C): gamma1 gamma2 scale1 scale2 shift1 shift2
@@ -786,6 +822,16 @@ int sdvar_debug_set_gemm_cfg(int32_t bm, int32_t split) {
 }
 
 int sdvar_debug_set_qkv_fuse(int32_t on) { debug_set_qkv_fuse(on); return SDVAR_OK; }
+int sdvar_debug_set_rowblk(int32_t on) { debug_set_rowblk(on); return SDVAR_OK; }          // 0 off, 1 default (32 .. 80 rows), 2 every call of at most 80 rows
+int sdvar_op_gemm_rowblk(const float* x, int32_t ldx, const float* scale, const float* shift, int32_t rows_per_img, int32_t mod_stride, const uint16_t* Xp, uint64_t x_plane_stride,
+                         const uint16_t* Wp, uint64_t w_plane_stride, const float* w_scale, const float* bias, float* out, int32_t ldo, uint16_t* out_planes, uint64_t out_plane_stride,
+                         int32_t M, int32_t N, int32_t K, int32_t epi, const float* res, int32_t ldres, const float* gate, int32_t rows_per_gate, int32_t gate_stride,
+                         const float* scale_mul, float* q_out, void* k_cache, void* v_cache, int32_t l, int32_t H, int32_t Lp, int32_t pos0, int32_t kv_fmt, void* stream) {
+    SDVAR_CHECK_ARG(gemm_f16x2_rowblk_ok(M, N, K, x != nullptr, q_out != nullptr), "op_gemm_rowblk: M=%d N=%d K=%d outside the row-block kernel's range (M <= 80; K <= 1024 with a LayerNorm operand, <= 4096 with planes) or the kernel is switched off", M, N, K);
+    ProfScope ps(9, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), (hipStream_t)stream);
+    return gemm_f16x2_rowblk(x, ldx, scale, shift, rows_per_img, mod_stride, Xp, (size_t)x_plane_stride, Wp, (size_t)w_plane_stride, w_scale ? w_scale + 1 : nullptr, bias, out, ldo, out_planes,
+                             (size_t)out_plane_stride, M, N, K, epi, res, ldres, gate, rows_per_gate, gate_stride, scale_mul, q_out, k_cache, v_cache, l, H, Lp, pos0, kv_fmt, (hipStream_t)stream);
+}
 
 // Kernel variants that otherwise only an environment variable read at first use selects (A/B runs): tests switch them inside one process.  value < 0 = back to the
 // environment / default.

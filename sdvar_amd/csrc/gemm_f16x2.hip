@@ -1458,6 +1458,197 @@ __global__ __launch_bounds__(64 * NW) void gemm_f16x2_skinny_kernel(GemmHArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Row-block kernel for M <= 80 rows (round 4): ONE launch per GEMM of a transformer block where stages 0 - 1 ran three - LayerNorm + modulation in the operand
+// prologue, the product, and for QKV the per-head finish (bias, q / k L2 norm, q scale, k / v rows into the cache planes: basic_var.py:101-109, 157-158).
+//   workgroup = 16 rows x 16 NT columns x ALL of K; 8 waves, wave w takes K-steps w, w + 8, ... (at most KS of them); grid = (N / (16 NT), ceil(M / 16)).
+//   W fragments global -> VGPR, all in flight at once (one HBM round trip per launch, as in the skinny kernel above).
+//   LN = 1 (QKV, fc1, head; K = C): the X operand is built from the fp32 residual stream.  A lane holds its row's 8 k of every K-step of its wave (row l15, k
+//       32 t + 8 lq ..: exactly its MFMA B fragment), the row statistics meet through LDS (sum, then sum of squared deviations: the two-pass form of
+//       ln_modulate_kernel; waves summed in order: deterministic), then ((x - mean) rstd)(1 + scale) + shift is split into the two fp16 planes in registers.  The
+//       stand-alone ln_modulate launch, its planes in HBM and their re-read are gone; every column block redoes its 16 rows' LayerNorm (16 K values per workgroup).
+//   LN = 0 (proj, fc2): X planes from global as before; with KS = 16 a workgroup streams K = 4096 unsplit - no slabs, no pending residual for a later kernel to sum.
+//   The waves' partial tiles meet in LDS; wave j finishes column tile j.  HEPI_QKV (NT = 4: the 64 columns of one head of q, k or v): the head's sum of squares
+//   goes through LDS once more, then q -> (R, H, l, 64) fp32, k (normalised) / v -> the cache planes at pos0 + t.
+struct RowBlkArgs {
+    GemmHArgs g;
+    const float* x; int ldx;                          // LN = 1: fp32 (M, K) activations
+    const float* scale; const float* shift;           // modulation vectors of CFG row m / rows_per_img, stride mod_stride
+    int rows_per_img, mod_stride;
+    float eps;
+};
+
+__device__ __forceinline__ void split8h_pk(const float* v, f16x8& h, f16x8& l) {
+    uint2 h0, l0, h1, l1;
+    split4h_pk(v, h0, l0); split4h_pk(v + 4, h1, l1);
+    const u32x4 hh = {h0.x, h0.y, h1.x, h1.y}, ll = {l0.x, l0.y, l1.x, l1.y};
+    h = __builtin_bit_cast(f16x8, hh); l = __builtin_bit_cast(f16x8, ll);
+}
+
+template <int NT, int KS, int EPI, int LN>
+__global__ __launch_bounds__(512) void gemm_f16x2_rowblk_kernel(RowBlkArgs ra) {
+    __shared__ f32x4v red_acc[8 * NT * 64];            // partial tiles of the 8 waves
+    __shared__ float red_st[2][8][16];                 // LN: per-wave row sums / squared deviations
+    __shared__ float red_sq[NT][16];                   // HEPI_QKV: per column tile sum of squares of a row
+    const GemmHArgs& a = ra.g;
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n0 = blockIdx.x * (16 * NT), m0 = blockIdx.y * 16;
+    const int nk = a.K / HBK;
+    const int row = min(m0 + l15, a.M - 1);
+    // K-steps of this wave: t = wave + 8 s.  Straight-line code: a K-step past the end is CLAMPED for the loads and its X fragment is zero (a branch per K-step
+    // made the compiler wait for each step's loads inside its branch: four serialised round trips, 13 us per launch instead of 7).
+    int tc[KS]; bool tv[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) { const int t = wave + 8 * s; tv[s] = t < nk; tc[s] = tv[s] ? t : nk - 1; }
+    f32x4v acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[j][r] = 0.f;
+    f16x8 fw[NT][KS][2];
+    // W fragments: column n0 + 16 j + l15, k 8 lq .. of K-step t; requested AFTER the short-latency operand loads of the LN prologue (vmcnt counts in order:
+    // the prologue then waits for its own loads only while the weight stream stays in flight)
+    auto load_w = [&]() {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const uint16_t* pw = a.W + (size_t)min(n0 + 16 * j + l15, a.N - 1) * 32 + 8 * lq;
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) fw[j][s][p] = __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(pw + (size_t)tc[s] * a.N * 32 + p * a.wps));
+        }
+    };
+    if (LN) {
+        f32x4 xa[KS][2], sa[KS][2], ha[KS][2];
+        const float* px = ra.x + (size_t)row * ra.ldx + 8 * lq;
+        const size_t mo = (size_t)(row / ra.rows_per_img) * ra.mod_stride + 8 * lq;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) { xa[s][0] = *reinterpret_cast<const f32x4*>(px + 32 * tc[s]); xa[s][1] = *reinterpret_cast<const f32x4*>(px + 32 * tc[s] + 4); }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            sa[s][0] = *reinterpret_cast<const f32x4*>(ra.scale + mo + 32 * tc[s]); sa[s][1] = *reinterpret_cast<const f32x4*>(ra.scale + mo + 32 * tc[s] + 4);
+            ha[s][0] = *reinterpret_cast<const f32x4*>(ra.shift + mo + 32 * tc[s]); ha[s][1] = *reinterpret_cast<const f32x4*>(ra.shift + mo + 32 * tc[s] + 4);
+        }
+        load_w();
+        float sum = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const float ps = ((xa[s][0][0] + xa[s][0][1]) + (xa[s][0][2] + xa[s][0][3])) + ((xa[s][1][0] + xa[s][1][1]) + (xa[s][1][2] + xa[s][1][3]));
+            sum += tv[s] ? ps : 0.f;
+        }
+        sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
+        if (lq == 0) red_st[0][wave][l15] = sum;
+        __syncthreads();
+        float tot = red_st[0][0][l15];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) tot += red_st[0][w][l15];
+        const float mean = tot / (float)a.K;
+        float ss = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            float ps = 0.f;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = xa[s][h][e] - mean; ps += d * d; }
+            ss += tv[s] ? ps : 0.f;
+        }
+        ss += __shfl_xor(ss, 16, 64); ss += __shfl_xor(ss, 32, 64);
+        if (lq == 0) red_st[1][wave][l15] = ss;
+        __syncthreads();
+        float tot2 = red_st[1][0][l15];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) tot2 += red_st[1][w][l15];
+        const float rstd = 1.0f / sqrtf(tot2 / (float)a.K + ra.eps);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            float o[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float v = ((xa[s][h][e] - mean) * rstd) * (sa[s][h][e] + 1.0f) + ha[s][h][e]; o[4 * h + e] = tv[s] ? v : 0.f; }
+            f16x8 xh, xl;
+            split8h_pk(o, xh, xl);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) { SDVAR_MFMA3_16(acc[j], xh, xl, fw[j][s][0], fw[j][s][1]); }
+        }
+    } else {
+        load_w();
+        const uint16_t* pxp = a.X + (size_t)row * 32 + 8 * lq;
+        constexpr int XB = KS < 8 ? KS : 8;
+        const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int b0 = 0; b0 < KS; b0 += XB) {
+            f16x8 fb[XB][2];
+#pragma unroll
+            for (int s = 0; s < XB; ++s)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) fb[s][p] = *reinterpret_cast<const f16x8*>(pxp + (size_t)tc[b0 + s] * a.M * 32 + p * a.xps);
+#pragma unroll
+            for (int s = 0; s < XB; ++s) {
+                const f16x8 xh = tv[b0 + s] ? fb[s][0] : zero8, xl = tv[b0 + s] ? fb[s][1] : zero8;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) { SDVAR_MFMA3_16(acc[j], xh, xl, fw[j][b0 + s][0], fw[j][b0 + s][1]); }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) red_acc[(wave * NT + j) * 64 + lane] = acc[j];
+    __syncthreads();
+    // ---- wave j finishes column tile j (summed in wave order)
+    const float wsi = a.wsi ? *a.wsi : 1.0f;
+    const int m = m0 + l15;
+    f32x4v sum4 = {0.f, 0.f, 0.f, 0.f};
+    if (wave < NT) {
+        sum4 = red_acc[wave * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) { const f32x4v q = red_acc[(w * NT + wave) * 64 + lane]; sum4[0] += q[0]; sum4[1] += q[1]; sum4[2] += q[2]; sum4[3] += q[3]; }
+    }
+    if (EPI == HEPI_QKV) {                 // NT = 4, n0 = 64 x (head of q | k | v): all eight waves reach the barrier
+        const QkvEpi& e = a.qk;
+        const int cb = n0 >> 6, which = cb / e.H, h = cb - which * e.H;
+        const bool l2 = e.scale_mul != nullptr;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (wave < NT) {
+            const int n = n0 + 16 * wave + 4 * lq;
+            const f32x4 bv = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+            float sq = 0.f;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) { v[x] = sum4[x] * wsi + bv[x]; sq += v[x] * v[x]; }
+            sq += __shfl_xor(sq, 16, 64); sq += __shfl_xor(sq, 32, 64);
+            if (lq == 0) red_sq[wave][l15] = sq;
+        }
+        __syncthreads();
+        if (wave >= NT || m >= a.M) return;
+        const float sqt = (red_sq[0][l15] + red_sq[1][l15]) + (red_sq[2 % NT][l15] + red_sq[3 % NT][l15]);
+        const float nrm = (l2 && which < 2) ? fmaxf(sqrtf(sqt), 1e-12f) : 1.0f;
+        const int r = m / e.l, t = m - r * e.l, c = 16 * wave + 4 * lq;
+        if (which == 0) {
+            const float sm = l2 ? expf(fminf(e.scale_mul[h], 4.605170249938965f)) : 0.03125f;
+            f32x4 o;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) o[x] = l2 ? (v[x] / nrm) * sm : v[x] * sm;
+            *reinterpret_cast<f32x4*>(e.q_out + (((size_t)r * e.H + h) * e.l + t) * 64 + c) = o;
+        } else {
+            const int NP = e.fmt == 3 ? 2 : 1;
+            const size_t ps = (size_t)e.Lp * 64;
+            uint16_t* pk = (which == 1 ? e.k_cache : e.v_cache) + ((size_t)r * e.H + h) * NP * ps + (size_t)(e.pos0 + t) * 64 + c;
+            float kv[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) kv[x] = (l2 && which == 1) ? v[x] / nrm : v[x];
+            uint2 wh, wl;
+            split4h_pk(kv, wh, wl);
+            *reinterpret_cast<uint2*>(pk) = wh;
+            if (e.fmt == 3) *reinterpret_cast<uint2*>(pk + ps) = wl;
+        }
+        return;
+    }
+    if (wave >= NT) return;
+    constexpr int SEPI = EPI == HEPI_QKV ? HEPI_BIAS : EPI;
+    h_store4<SEPI>(a, a.out, sum4, wsi, m, n0 + 16 * wave + 4 * lq, a.vec && n0 + 16 * NT <= a.N);
+}
+
 // out = epi( sum_s slab[s] + bias ) for the split-K path; the GELU variant writes planes
 template <int EPI>
 __global__ __launch_bounds__(256) void splitk_reduce_h_kernel(const float* __restrict__ ws, int split, const float* __restrict__ bias, float* out,
@@ -1948,6 +2139,83 @@ static int launch_h(GemmHArgs a, int epi, int split, hipStream_t stream) {
         case HEPI_BIAS_GELU_PLANES: return v2 ? launch_h2_kernel<HEPI_BIAS_GELU_PLANES>(a, tiles, stream) : launch_small_any<SB, HEPI_BIAS_GELU_PLANES>(a, tiles, stream);
         default: return v2 ? launch_h2_kernel<HEPI_GATED_RES>(a, tiles, stream) : launch_small_any<SB, HEPI_GATED_RES>(a, tiles, stream);
     }
+}
+
+// ---- row-block launches (gemm_f16x2_rowblk_kernel): M <= 80 ---------------------------------------------------------------------------
+static thread_local bool g_rowblk_floor = false;   // set around the model's query (gemm_f16x2_rowblk_want)
+static int g_rowblk = -1;          // SDVAR_ROWBLK (A/B runs): 0 = the round-3 launch sequence (ln_modulate + skinny / small_pp + qk_norm_append) at every M
+void debug_set_rowblk(int v) { g_rowblk = v; }
+// can the (LayerNorm +) GEMM (+ QKV finish) of this shape run as one row-block launch?  ln: the operand is the fp32 residual stream (K = C)
+bool gemm_f16x2_rowblk_ok(int M, int N, int K, int ln, int qkv) {
+    if (g_rowblk < 0) { const char* e = getenv("SDVAR_ROWBLK"); g_rowblk = e ? atoi(e) : 1; }
+    if (!g_rowblk || g_force_bm_h) return false;                 // a forced tile (tests of the other kernels) keeps the old sequence
+    if (M < 1 || M > 80 || K % HBK) return false;
+    // the model's own calls (not the op-level tests) come with a floor: below 32 rows the old sequence wins.  A 16-row call is ONE row block: its QKV launch has
+    // H x 3 workgroups pulling 256 KB of W each, and with one image per row every workgroup also reads 16 x 8 KB of modulation vectors - a CU takes in only
+    // ~45 GB/s of L2 hits / ~20 GB/s of HBM misses, so bytes per workgroup decide (d16 stage 0: 0.84 ms fused against 0.78 ms; stage 1, M = 64: 0.84 against 0.96)
+    if (g_rowblk_floor && M < 32) return false;
+    if (ln ? K > 1024 : K > 4096) return false;
+    return qkv ? N % 64 == 0 : N % 16 == 0;
+}
+
+// stage_forward's question: should a call with M rows take the row-block sequence?  (2 forces it at every M <= 80: A/B runs and the tests of the 16-row shapes)
+bool gemm_f16x2_rowblk_want(int M, int C, int V) {
+    g_rowblk_floor = true;
+    if (g_rowblk < 0) { const char* e = getenv("SDVAR_ROWBLK"); g_rowblk = e ? atoi(e) : 1; }
+    if (g_rowblk == 2) g_rowblk_floor = false;
+    // ... and a width floor: at C = 768 (d12) the QKV launch has only 36 x ceil(M / 16) workgroups and fc1 falls between one and two rounds - stage 1 of d12 ran
+    // 0.68 ms fused against 0.62 ms (profiles/r04_g_stage_d12.log); at C = 1024 (d16) 0.86 against 0.96
+    const bool ok = (!g_rowblk_floor || C >= 1024) && gemm_f16x2_rowblk_ok(M, 3 * C, C, 1, 1) && gemm_f16x2_rowblk_ok(M, C, 4 * C, 0, 0) && gemm_f16x2_rowblk_ok(M, V, C, 1, 0);
+    g_rowblk_floor = false;
+    return ok;
+}
+
+template <int NT, int KS, int EPI, int LN>
+static int launch_rowblk_kernel(const RowBlkArgs& ra, hipStream_t stream) {
+    const dim3 grid(ra.g.N / (16 * NT), (ra.g.M + 15) / 16);
+    hipLaunchKernelGGL((gemm_f16x2_rowblk_kernel<NT, KS, EPI, LN>), grid, dim3(512), 0, stream, ra);
+    SDVAR_LAUNCH_CHECK();
+    return SDVAR_OK;
+}
+
+// x != null: out = epi( (LN(x) (1 + scale) + shift) W^T + bias ), epi = HEPI_BIAS | HEPI_BIAS_GELU_PLANES, or the QKV finish when q_out != null (then N = 3 H 64 and
+// nothing is written to `out`); x == null: X planes, epi = HEPI_GATED_RES | HEPI_BIAS.  gemm_f16x2_rowblk_ok(M, N, K, x != null, q_out != null) must hold.
+int gemm_f16x2_rowblk(const float* x, int ldx, const float* scale, const float* shift, int rows_per_img, int mod_stride, const uint16_t* X, size_t xps,
+                      const uint16_t* W, size_t wps, const float* wsi, const float* bias, float* out, int ldo, uint16_t* outp, size_t ops, int M, int N, int K, int epi,
+                      const float* res, int ldres, const float* gate, int rows_per_gate, int gate_stride,
+                      const float* scale_mul, float* q_out, void* k_cache, void* v_cache, int l, int H, int Lp, int pos0, int kv_fmt, hipStream_t stream) {
+    const bool ln = x != nullptr, qkv = q_out != nullptr;
+    SDVAR_CHECK_ARG(W && (ln || X) && gemm_f16x2_rowblk_ok(M, N, K, ln, qkv), "gemm_f16x2_rowblk: shape M=%d N=%d K=%d (ln %d, qkv %d) not supported", M, N, K, (int)ln, (int)qkv);
+    SDVAR_CHECK_ARG(!ln || (scale && shift && rows_per_img > 0 && ldx >= K && ldx % 4 == 0 && mod_stride % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)scale % 16) == 0 && ((uintptr_t)shift % 16) == 0),
+                    "gemm_f16x2_rowblk: bad LayerNorm operand");
+    SDVAR_CHECK_ARG(((uintptr_t)W % 16) == 0 && wps % 8 == 0 && (ln || (((uintptr_t)X % 16) == 0 && xps % 8 == 0)), "gemm_f16x2_rowblk: planes must be 16-byte aligned");
+    if (qkv) SDVAR_CHECK_ARG(ln && k_cache && v_cache && l > 0 && H > 0 && N == 3 * H * 64 && M % l == 0 && (kv_fmt == 3 || kv_fmt == 4) && Lp % 8 == 0 && ((uintptr_t)q_out % 16) == 0 &&
+                             ((uintptr_t)k_cache % 16) == 0 && ((uintptr_t)v_cache % 16) == 0 && (!bias || ((uintptr_t)bias % 16) == 0), "gemm_f16x2_rowblk: bad QKV finish arguments");
+    else SDVAR_CHECK_ARG(epi == HEPI_BIAS_GELU_PLANES ? (outp != nullptr && ln) : (out != nullptr && ldo >= N && (epi == HEPI_BIAS || (epi == HEPI_GATED_RES && !ln && res && gate && rows_per_gate > 0 && ldres >= N))),
+                         "gemm_f16x2_rowblk: epilogue %d not available here", epi);
+    RowBlkArgs ra;
+    ra.g = GemmHArgs{X, W, xps, wps, wsi, bias, out, outp, ops, res, gate, M, N, K, ldo, ldres, rows_per_gate > 0 ? rows_per_gate : 1, gate_stride, 1, K / HBK, 0, 0, nullptr,
+                     QkvEpi{scale_mul, q_out, (uint16_t*)k_cache, (uint16_t*)v_cache, l, H, Lp, pos0, kv_fmt}, 0, 0};
+    auto al16 = [](const void* q) { return ((uintptr_t)q % 16) == 0; };
+    ra.g.vec = N % 4 == 0 && al16(bias) && al16(out) && al16(outp) && al16(res) && al16(gate) && ldo % 4 == 0 && ops % 4 == 0 && (epi != HEPI_GATED_RES || (ldres % 4 == 0 && gate_stride % 4 == 0));
+    ra.x = x; ra.ldx = ldx; ra.scale = scale; ra.shift = shift; ra.rows_per_img = rows_per_img > 0 ? rows_per_img : 1; ra.mod_stride = mod_stride; ra.eps = 1e-6f;
+    static const bool trace = getenv("SDVAR_GEMM_TRACE") != nullptr;
+    const int rb = (M + 15) / 16;
+    // column tiles per workgroup: as many workgroups as the chip holds in about one round (<= 384), i.e. the narrowest block that does not exceed it
+    int nt = 1;
+    while (nt < 4 && (long)(N / (16 * nt)) * rb > 384 && N % (32 * nt) == 0) nt *= 2;
+    if (!ln) nt = 1;
+    if (trace) fprintf(stderr, "[gemm_f16x2] M=%d N=%d K=%d epi=%d -> rowblk ln=%d qkv=%d nt=%d\n", M, N, K, epi, (int)ln, (int)qkv, qkv ? 4 : nt);
+    g_last_cfg_h[0] = 17; g_last_cfg_h[1] = 1;
+    if (qkv) return launch_rowblk_kernel<4, 4, HEPI_QKV, 1>(ra, stream);
+    if (ln) {
+        if (epi == HEPI_BIAS_GELU_PLANES) return nt == 1 ? launch_rowblk_kernel<1, 4, HEPI_BIAS_GELU_PLANES, 1>(ra, stream) : nt == 2 ? launch_rowblk_kernel<2, 4, HEPI_BIAS_GELU_PLANES, 1>(ra, stream)
+                                                                                                                                      : launch_rowblk_kernel<4, 4, HEPI_BIAS_GELU_PLANES, 1>(ra, stream);
+        return nt == 1 ? launch_rowblk_kernel<1, 4, HEPI_BIAS, 1>(ra, stream) : nt == 2 ? launch_rowblk_kernel<2, 4, HEPI_BIAS, 1>(ra, stream) : launch_rowblk_kernel<4, 4, HEPI_BIAS, 1>(ra, stream);
+    }
+    // plane operand, K up to 4096 unsplit: 16 K-steps of W per wave in flight (128 VGPRs) leave room for one column tile only
+    if (epi == HEPI_GATED_RES) return launch_rowblk_kernel<1, 16, HEPI_GATED_RES, 0>(ra, stream);
+    return launch_rowblk_kernel<1, 16, HEPI_BIAS, 0>(ra, stream);
 }
 
 // X planes [2][K/32][M][32] (plane stride xps), W planes [2][K/32][N][32] of W * 2^S (plane stride wps), wsi -> 2^-S on the device (null: 1).

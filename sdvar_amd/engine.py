@@ -103,6 +103,8 @@ _SIGNATURES = {
     "sdvar_debug_set_gemm_cfg": (_I, [_I, _I]),
     "sdvar_debug_set_gemm_stamps": (_I, [_P]),
     "sdvar_debug_set_qkv_fuse": (_I, [_I]),
+    "sdvar_debug_set_rowblk": (_I, [_I]),
+    "sdvar_op_gemm_rowblk": (_I, [_P, _I, _P, _P, _I, _I, _P, _U64, _P, _U64, _P, _P, _P, _I, _P, _U64, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sdvar_debug_set_variant": (_I, [C.c_char_p, _I]),
     "sdvar_debug_get_gemm_cfg": (_I, [C.POINTER(_I)]),
     "sdvar_debug_set_f16x2_guard": (_I, [_I]),

@@ -895,3 +895,131 @@ def test_f16_planes_attention_forced_online_rescale(dev, fmt):
     kr, vr = (k, v) if fmt == 3 else (k.half().float(), v.half().float())
     ref = _attn_ref(q, kr, vr, [0], [Ktot]).transpose(1, 2).reshape(R, l, 64)
     assert (out.cpu().double() - ref).abs().max().item() <= (2e-5 if fmt == 4 else 6e-5)      # scores of 50: the 2^-22 of K moves the exponent by 50 * 2^-22
+
+
+# ------------------------------------------------------------------------------------------------ row-block launches (M <= 80, round 4)
+def _ln_mod_ref(x, mod, K, rpi):
+    """fp64 LayerNorm(eps 1e-6) * (1 + scale[g]) + shift[g], g = row / rpi; mod rows hold (.., scale at 2K, .., shift at 4K, ..) as the adaLN table does."""
+    xd = x.double()
+    n = (xd - xd.mean(-1, keepdim=True)) / torch.sqrt(xd.var(-1, unbiased=False, keepdim=True) + 1e-6)
+    g = torch.arange(x.shape[0]) // rpi
+    return n * (1 + mod[g, 2 * K:3 * K].double()) + mod[g, 4 * K:5 * K].double()
+
+
+@pytest.mark.parametrize("M,N,K,rpi", [(16, 3072, 1024, 1), (64, 4096, 1024, 4), (80, 2304, 768, 5), (2, 768, 256, 1), (50, 4096, 1024, 25), (72, 1024, 256, 36), (33, 4096, 1024, 33)])
+@pytest.mark.parametrize("epi", [0, 1])
+def test_gemm_rowblk_layernorm_operand(dev, M, N, K, rpi, epi):
+    """gemm_f16x2_rowblk_kernel with the LayerNorm + modulation prologue (basic_var.py:157-158 / 172-174 in front of the QKV / fc1 / head GEMM): against fp64 at the bar
+    of the stand-alone GEMM tests, with an outlier channel in every row (the statistics are the two-pass form) and ragged last row blocks."""
+    lib = E.load_library()
+    x = rnd(1, (M, K), 2.0); x[:, 5] *= 300.0
+    R = (M + rpi - 1) // rpi
+    mod, W, b = rnd(2, (R, 6 * K)), rnd(3, (N, K), 1 / math.sqrt(K)), rnd(4, (N,)).to(dev)
+    Wp, sc = _planes_h(W, dev, scaled=True)
+    xd, md = x.to(dev), mod.to(dev)
+    out = torch.empty(M, N, device=dev) if epi == 0 else None
+    outp = torch.empty(2, N // 32, M, 32, dtype=torch.int16, device=dev) if epi == 1 else None
+    E._check(lib.sdvar_op_gemm_rowblk(_p(xd), K, C_void(md, 2 * K), C_void(md, 4 * K), rpi, 6 * K, None, 0, _p(Wp), N * K, _p(sc), _p(b), _p(out), N, _p(outp), M * N, M, N, K, epi,
+                                      None, 0, None, 1, 0, None, None, None, None, 0, 0, 0, 0, 0, _st()))
+    ref = _ln_mod_ref(x, mod, K, rpi) @ W.double().t() + b.cpu().double()
+    if epi == 1:
+        ref = F.gelu(ref, approximate="tanh"); got = _unplanes_h(outp).cpu()
+    else:
+        got = out.cpu().double()
+    err = (got - ref).abs().max().item()
+    assert err <= 2e-5 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("M,N,K", [(16, 1024, 4096), (80, 768, 3072), (33, 1024, 1024), (64, 256, 1024), (1, 16, 32)])
+@pytest.mark.parametrize("epi", [0, 2])
+def test_gemm_rowblk_plane_operand(dev, M, N, K, epi):
+    """The same kernel on operand planes with K up to 4096 streamed UNSPLIT by one workgroup per 16 x 16 output tile (fc2 of stages 0-1: no slabs, no pending
+    residual), bias and gated-residual epilogues, against fp64."""
+    lib = E.load_library()
+    X, W, b = rnd(1, (M, K)), rnd(2, (N, K), 1 / math.sqrt(K)), rnd(3, (N,)).to(dev)
+    (Xp, _), (Wp, sc) = _planes_h(X, dev), _planes_h(W, dev, scaled=True)
+    rows_per_gate = 7 if M > 7 else 1
+    R = (M + rows_per_gate - 1) // rows_per_gate
+    res, gate = rnd(4, (M, N)).to(dev), rnd(5, (R, 2 * N)).to(dev)
+    out = res.clone() if epi == 2 else torch.empty(M, N, device=dev)
+    E._check(lib.sdvar_op_gemm_rowblk(None, 0, None, None, 1, 0, _p(Xp), M * K, _p(Wp), N * K, _p(sc), _p(b), _p(out), N, None, 0, M, N, K, epi, _p(out) if epi == 2 else None, N,
+                                      _p(gate) if epi == 2 else None, rows_per_gate, 2 * N, None, None, None, None, 0, 0, 0, 0, 0, _st()))
+    ref = X.double() @ W.double().t() + b.cpu().double()
+    if epi == 2:
+        ref = res.cpu().double() + ref * gate.cpu()[:, :N].double().repeat_interleave(rows_per_gate, 0)[:M]
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err <= 2e-5 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("fmt", [3, 4])
+@pytest.mark.parametrize("R,l,H,pos0,l2", [(16, 1, 16, 0, True), (16, 4, 12, 1, True), (16, 5, 4, 0, True), (2, 36, 6, 55, True), (4, 9, 4, 5, False)])
+def test_gemm_rowblk_qkv_finish(dev, R, l, H, pos0, l2, fmt):
+    """LayerNorm -> QKV -> bias, per-head L2 norm of q and k, q scale, k / v rows into the cache planes (basic_var.py:93-109) in ONE launch: q, and the cache rows read back
+    from the planes, against fp64; rows of the cache outside [pos0, pos0 + l) stay untouched."""
+    lib = E.load_library()
+    Cw, M, NP, Lp = 64 * H, R * l, (2 if fmt == 3 else 1), 128
+    x, mod = rnd(1, (M, Cw), 1.5), rnd(2, (R, 6 * Cw))
+    W, b, sm = rnd(3, (3 * Cw, Cw), 1 / math.sqrt(Cw)), rnd(4, (3 * Cw,), 0.1), (rnd(5, (H,), 0.3) + math.log(4.0))
+    b[Cw:2 * Cw] = 0.0                                                     # zero_k_bias (basic_var.py:93)
+    Wp, sc = _planes_h(W, dev, scaled=True)
+    xd, md, bd, smd = x.to(dev), mod.to(dev), b.to(dev), sm.to(dev)
+    q = torch.zeros(R, H, l, 64, device=dev)
+    kc = torch.full((R, H, NP, Lp, 64), 0x3c00, dtype=torch.int16, device=dev); vc = kc.clone()          # fp16 1.0 everywhere: untouched rows must keep it
+    E._check(lib.sdvar_op_gemm_rowblk(_p(xd), Cw, C_void(md, 2 * Cw), C_void(md, 4 * Cw), l, 6 * Cw, None, 0, _p(Wp), 3 * Cw * Cw, _p(sc), _p(bd), None, 0, None, 0, M, 3 * Cw, Cw, 0,
+                                      None, 0, None, 1, 0, _p(smd) if l2 else None, _p(q), _p(kc), _p(vc), l, H, Lp, pos0, fmt, _st()))
+    qkv = (_ln_mod_ref(x, mod, Cw, l) @ W.double().t() + b.double()).view(R, l, 3, H, 64).permute(2, 0, 3, 1, 4)
+    qr, kr, vr = qkv[0], qkv[1], qkv[2]
+    if l2:
+        qr = F.normalize(qr, dim=-1) * sm.double().clamp_max(math.log(100.0)).exp().view(1, H, 1, 1); kr = F.normalize(kr, dim=-1)
+    else:
+        qr = qr * 0.03125
+    unp = lambda c: c.view(torch.float16).double().sum(2).cpu()             # (R, H, Lp, 64)
+    gk, gv = unp(kc), unp(vc)
+    tol = 2e-5 if fmt == 3 else 1.1e-3                                     # one fp16 plane (config P4's cache) holds 11 bits
+    assert (q.cpu().double() - qr).abs().max().item() <= 2e-5 * max(1.0, qr.abs().max().item())
+    assert (gk[:, :, pos0:pos0 + l] - kr).abs().max().item() <= tol * max(1.0, kr.abs().max().item())
+    assert (gv[:, :, pos0:pos0 + l] - vr).abs().max().item() <= tol * max(1.0, vr.abs().max().item())
+    keep = torch.ones(Lp, dtype=torch.bool); keep[pos0:pos0 + l] = False
+    assert bool((gk[:, :, keep] == NP).all()) and bool((gv[:, :, keep] == NP).all())
+
+
+@pytest.mark.parametrize("kv_fp16", [False, True])
+def test_rowblk_stage_forward_equals_the_unfused_sequence(dev, kv_fp16):
+    """stage_forward at M <= 80 (five launches per block: LayerNorm in the GEMM prologues, QKV finish, unsplit fc2) against the eight-launch sequence every other row count
+    runs, on one model: stages 0-3 one at a time and stages 0-1 as one chunk, then stage 4 / the chunk 2-3 (M > 80: unfused in both runs) on the caches the fused launches
+    wrote.  The kernel id of the last GEMM proves which path ran."""
+    pns, B, depth = LADDER_256, 2, 4
+    lad = as_ladder(pns)
+    sd, _ = state_dicts(depth, pns)
+    tc = E.ModelCtx(sd, depth, pns, B, 2, dev, kv_fp16=kv_fp16)
+    assert tc.gemm_mode == "f16x2"
+    labels = torch.tensor([3, 977], device=dev)
+    xs = [rnd(40 + s, (2 * B * lad.lens[s] * tc.Cw,)).to(dev) for s in range(5)]
+    lg = torch.empty(2 * B * (lad.lens[2] + lad.lens[3]) * tc.V, device=dev)
+    cat = lambda a, b: torch.cat([xs[a].view(2 * B, -1), xs[b].view(2 * B, -1)], 1).contiguous().view(-1)
+
+    def run(on):
+        E._check(tc.lib.sdvar_debug_set_rowblk(on if isinstance(on, int) and not isinstance(on, bool) else (2 if on else 0)))      # 2: the row-block sequence at EVERY call of at most 80 rows (default 1: from 32 rows)
+        try:
+            out, ids = [], []
+            tc.begin(labels)
+            for s in range(5):                                                 # M = 4, 16, 36, 64 fused; 100 not
+                tc.forward(xs[s].clone(), s, 1, lg); out.append(lg[:2 * B * lad.lens[s] * tc.V].clone()); ids.append(E.last_gemm_cfg()["bm"])
+            tc.kv_set_len(0); tc.begin(labels)
+            tc.forward(cat(0, 1), 0, 2, lg); out.append(lg[:2 * B * 5 * tc.V].clone()); ids.append(E.last_gemm_cfg()["bm"])       # M = 20
+            tc.forward(cat(2, 3), 2, 2, lg); out.append(lg[:2 * B * 25 * tc.V].clone()); ids.append(E.last_gemm_cfg()["bm"])      # M = 100
+            tc.kv_set_len(0)
+            return out, ids
+        finally:
+            E._check(tc.lib.sdvar_debug_set_rowblk(1))
+    a, ia = run(True)
+    b, ib = run(False)
+    _, idf = run(1)                                                            # the default: 32 .. 80 rows only (below, the eight-launch sequence is faster)
+    assert [i == 17 for i in idf] == [False, False, True, True, False, False, False], idf
+    assert ia[:4] == [17] * 4 and ia[5] == 17 and ia[4] != 17 and ia[6] != 17 and 17 not in ib, (ia, ib)
+    # the two sequences sum the LayerNorm statistics in different orders: k and v differ by an ulp of fp32 before the cache rounds them - invisible in the two-plane cache,
+    # but the ONE-plane fp16 cache of config P4 may round such a pair to different fp16 neighbours (2^-11 relative on one element): the fp16-cache bar of the other tests
+    tol = 2e-3 if kv_fp16 else 2e-5
+    for x, y in zip(a, b):
+        assert torch.isfinite(x).all() and (x - y).abs().max().item() <= tol * max(1.0, y.abs().max().item())
+    tc.close(); torch.cuda.empty_cache()
