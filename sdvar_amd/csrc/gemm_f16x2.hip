@@ -2201,9 +2201,19 @@ int gemm_f16x2_rowblk(const float* x, int ldx, const float* scale, const float* 
     ra.x = x; ra.ldx = ldx; ra.scale = scale; ra.shift = shift; ra.rows_per_img = rows_per_img > 0 ? rows_per_img : 1; ra.mod_stride = mod_stride; ra.eps = 1e-6f;
     static const bool trace = getenv("SDVAR_GEMM_TRACE") != nullptr;
     const int rb = (M + 15) / 16;
-    // column tiles per workgroup: as many workgroups as the chip holds in about one round (<= 384), i.e. the narrowest block that does not exceed it
+    // column tiles per workgroup: bytes a workgroup pulls through its CU (W 16 nt columns + its 16 rows of x + their modulation vectors, all K long) x rounds of 256
+    // workgroups - a CU takes in ~45 GB/s of L2 hits, so this product is what a launch costs (the fixed part is the same for every nt)
     int nt = 1;
-    while (nt < 4 && (long)(N / (16 * nt)) * rb > 384 && N % (32 * nt) == 0) nt *= 2;
+    {
+        const int imgs = (16 + rows_per_img - 1) / (rows_per_img > 0 ? rows_per_img : 1) + 1;       // images a 16-row block touches (upper bound)
+        double best = 1e30;
+        for (int c = 1; c <= 4; c *= 2) {
+            if (N % (16 * c)) break;
+            const long blocks = (long)(N / (16 * c)) * rb;
+            const double cost = (double)((blocks + 255) / 256) * (16.0 * c + 16.0 + 2.0 * (imgs < 16 ? imgs : 16));
+            if (cost < best) { best = cost; nt = c; }
+        }
+    }
     if (!ln) nt = 1;
     if (trace) fprintf(stderr, "[gemm_f16x2] M=%d N=%d K=%d epi=%d -> rowblk ln=%d qkv=%d nt=%d\n", M, N, K, epi, (int)ln, (int)qkv, qkv ? 4 : nt);
     g_last_cfg_h[0] = 17; g_last_cfg_h[1] = 1;

@@ -49,17 +49,20 @@ def _first_flip(ids, want, lad):
     return next(i for i in range(lad.S) if t < lad.cum[i])
 
 
-@pytest.mark.parametrize("mode,thr", [("accept_all", 0.0), ("natural", 0.5)])
-def test_P1_spec_decode_vs_oracle(dev, p1, mode, thr):
-    """d12 -> d16, B = 8 (16 CFG rows: the 256-row tiles, the unsplit-QKV fused epilogue and the hybrid tail split all run), gamma = 2.
-    A seed passes when ids, counters, per-round logits and f_hat agree; a seed whose ids differ must differ FIRST at a draw the oracle itself
-    had within 1e-3 of a tie (the rule of test_unselected_seeds_flip_only_on_sub_margin_ties), with the logits still in tolerance up to there.
-    At least one of the seeds must agree completely."""
+@pytest.mark.parametrize("mode,thr,seeds", [("accept_all", 0.0, (5,)), ("natural", 0.5, ())])
+def test_P1_spec_decode_vs_oracle(dev, p1, mode, thr, seeds):
+    """d12 -> d16, B = 8 (16 CFG rows: the 256-row tiles, the unsplit-QKV fused epilogue and the hybrid tail split all run), gamma = 2, against the LIVE oracle with
+    the FULL per-round logit tensors (device-drawn weights).  One seed of one mode: a P1-size oracle run costs 40 - 120 s of host time, and round 3 spent 200 s of
+    the suite here; the seeds x modes matrix is test_P1_spec_decode_vs_oracle_fixture below (same oracle, run ahead of time: tests/golden/make_p1_oracle.py).
+    The seed passes when ids, counters, per-round logits and f_hat agree; if its ids differ they must differ FIRST at a draw the oracle itself had within 1e-3 of a
+    tie (the rule of test_unselected_seeds_flip_only_on_sub_margin_ties), with the logits still in tolerance up to there."""
+    if not seeds:
+        pytest.skip("natural acceptance at P1 size: covered by the fixture matrix (4 seeds); the live oracle runs accept_all only")
     smp, (od, ot, oq) = p1
     lad, B, V = smp.lad, 8, 4096
     labels = (torch.arange(B) * 113 + 5) % 1000
     clean = 0
-    for seed in (5, 6):
+    for seed in seeds:
         tr = oracle_memo(("P1", mode, seed), lambda: orc.spec_decode(od, ot, oq, labels, 1.5, 2, 900, 0.96, _noise_o(seed), thr=thr, keep=True))
         want = torch.cat(tr.ids, 1).numpy()
         res = smp.spec_decode(labels.to(dev), 1.5, 2, 900, 0.96, E.Noise("host", seed), thr=thr, run_ahead=True)         # the benched loop
@@ -97,7 +100,79 @@ def test_P1_spec_decode_vs_oracle(dev, p1, mode, thr):
                     draws.append(d)
                 d += 1
         assert draws and min(tr.margins[x] for x in draws) < 1e-3, f"seed {seed}: ids differ from stage {flip_stage} on although no draw of that stage was within 1e-3 of a tie"
-    assert clean >= 1, "no seed reproduced the oracle's ids completely"
+    print(f"\n[P1 live oracle, {mode}] clean seeds {clean} of {len(seeds)}")
+
+
+@pytest.fixture(scope="module")
+def p1_host(dev):
+    """The P1 pair on the PORTABLE host-stream weights tests/golden/make_p1_oracle.py used (sdvar_amd.weights.var_state_dict, 'stress')."""
+    from sdvar_amd.weights import var_state_dict
+    pns, B = LADDER_256, 8
+    sd_d, sd_t = var_state_dict(12, pns, "stress"), var_state_dict(16, pns, "stress")
+    sd_v = vae_state_dict(pns, "stress", with_encoder=False)
+    dc, tc, qc = E.ModelCtx(sd_d, 12, pns, B, 1, dev), E.ModelCtx(sd_t, 16, pns, B, 2, dev), E.QuantCtx(sd_v, pns, B, dev)
+    assert tc.gemm_mode == "f16x2"
+    del sd_d, sd_t
+    yield E.Sampler(tc, qc, dc)
+    dc.close(); tc.close(); qc.close(); torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("mode,thr", [("accept_all", 0.0), ("natural", 0.5)])
+def test_P1_spec_decode_vs_oracle_fixture(dev, p1_host, mode, thr):
+    """Config P1 at full size in the BENCHED arithmetic against the oracle's golden vectors (tests/golden/p1_oracle.npz: 4 seeds x 2 acceptance modes): per seed the token
+    ids (bit-exact, or a first flip on a draw the oracle had within 1e-3 of a tie), the per-round CFG logits of the target at the sampled columns (the 8 largest and 8
+    pseudo-random entries of every token: <= 1e-3), f_hat <= 1e-4, every counter and the per-round acceptance record; run-ahead == lock-step on every seed.
+    The NUMBER of fully clean seeds is asserted (>= 3 of 4) and the per-seed record is printed, so a regression that turns a clean seed into a 'tie flip' shows."""
+    from conftest import golden
+    g = golden("p1_oracle")
+    smp = p1_host
+    lad, B = smp.lad, int(g["B"])
+    labels = torch.from_numpy(g["labels"]).long()
+    cfg, gamma, top_k, top_p = float(g["cfg"]), int(g["gamma"]), int(g["top_k"]), float(g["top_p"])
+    record, clean = [], 0
+    for seed in (int(x) for x in g["seeds"]):
+        k = f"{mode}_{seed}_"
+        want, margins, rounds_o = g[k + "ids"].astype(np.int64), g[k + "margins"], g[k + "rounds"]
+        res = smp.spec_decode(labels.to(dev), cfg, gamma, top_k, top_p, E.Noise("host", seed), thr=thr, run_ahead=True)            # the benched loop
+        ids_ra, f_ra, st_ra = res.ids.cpu().numpy().copy(), res.f_hat.cpu().clone(), dict(res.stats)
+        res = smp.spec_decode(labels.to(dev), cfg, gamma, top_k, top_p, E.Noise("host", seed), thr=thr, trace=True)                 # lock-step, logits kept
+        ids = res.ids.cpu().numpy()
+        assert np.array_equal(ids, ids_ra) and torch.equal(res.f_hat.cpu(), f_ra)
+        flip_stage = None if np.array_equal(ids, want) else _first_flip(ids, want, lad)
+        max_err = 0.0
+        for ri, (cur, gg, lg) in enumerate(res.trace["target_logits"]):
+            if ri >= len(rounds_o) or rounds_o[ri][0] != cur or (flip_stage is not None and cur + gg > flip_stage):
+                break
+            lg, off, cls = lg.cpu(), 0, []
+            for j in range(gg):
+                n = lad.lens[cur + j]
+                cls.append(orc.cfg_combine(lg[:, off:off + n], B, cfg * ((cur + j) / (lad.S - 1)))); off += n
+            got = torch.gather(torch.cat(cls, 1), -1, torch.from_numpy(g[k + f"r{ri}_idx"].astype(np.int64)))
+            err = float((got - torch.from_numpy(g[k + f"r{ri}_val"])).abs().max())
+            max_err = max(max_err, err)
+            assert err <= LOGIT_TOL, (seed, ri, cur, err)
+        flip_margin = None
+        if flip_stage is None:
+            clean += 1
+            assert (res.f_hat.cpu() - torch.from_numpy(g[k + "f_hat"])).abs().max().item() <= FHAT_TOL
+            cnt = [res.stats[x] for x in ("target_calls", "draft_stage_calls", "forced_accepts", "accepted_tokens", "gamma_final")]
+            assert cnt == list(g[k + "counters"]) == [st_ra[x] for x in ("target_calls", "draft_stage_calls", "forced_accepts", "accepted_tokens", "gamma_final")], (seed, cnt)
+            got_r = [[r["stage"], r["g"], r["n_accept"], int(r["forced"])] + list(r["matched"]) + [0] * (gamma - len(r["matched"])) for r in res.stats["rounds"]]
+            assert got_r == rounds_o.tolist(), seed
+        else:
+            draws, d = [], 0
+            for r in rounds_o:
+                for j in range(int(r[1])):
+                    if int(r[0]) + j == flip_stage:
+                        draws.append(d)
+                    d += 1
+            flip_margin = float(min(margins[x] for x in draws)) if draws else None
+            assert flip_margin is not None and flip_margin < 1e-3, f"seed {seed}: ids differ from stage {flip_stage} on although no draw of that stage was within 1e-3 of a tie"
+        record.append(dict(seed=seed, clean=flip_stage is None, first_flip_stage=flip_stage, flip_margin=flip_margin, oracle_min_margin=float(margins.min()), max_logit_err=max_err))
+    print(f"\n[P1 fixture, {mode}] clean seeds {clean} of {len(record)}: " + "; ".join(
+        f"seed {r['seed']}: {'clean' if r['clean'] else 'flip at stage %d (margin %.1e)' % (r['first_flip_stage'], r['flip_margin'])}, oracle min margin {r['oracle_min_margin']:.1e}, max|dlogit| {r['max_logit_err']:.1e}"
+        for r in record))
+    assert clean >= 3, record
 
 
 @pytest.mark.parametrize("depth", [24, 30])

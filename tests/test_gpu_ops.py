@@ -1014,12 +1014,34 @@ def test_rowblk_stage_forward_equals_the_unfused_sequence(dev, kv_fp16):
             E._check(tc.lib.sdvar_debug_set_rowblk(1))
     a, ia = run(True)
     b, ib = run(False)
-    _, idf = run(1)                                                            # the default: 32 .. 80 rows only (below, the eight-launch sequence is faster)
-    assert [i == 17 for i in idf] == [False, False, True, True, False, False, False], idf
+    _, idf = run(1)                                                            # the default also has a width floor (C >= 1024): this C = 256 model stays on the old sequence
+    assert 17 not in idf, idf
     assert ia[:4] == [17] * 4 and ia[5] == 17 and ia[4] != 17 and ia[6] != 17 and 17 not in ib, (ia, ib)
     # the two sequences sum the LayerNorm statistics in different orders: k and v differ by an ulp of fp32 before the cache rounds them - invisible in the two-plane cache,
     # but the ONE-plane fp16 cache of config P4 may round such a pair to different fp16 neighbours (2^-11 relative on one element): the fp16-cache bar of the other tests
     tol = 2e-3 if kv_fp16 else 2e-5
     for x, y in zip(a, b):
         assert torch.isfinite(x).all() and (x - y).abs().max().item() <= tol * max(1.0, y.abs().max().item())
+    tc.close(); torch.cuda.empty_cache()
+
+
+def test_rowblk_default_gate_at_d16_width(dev):
+    """The default gate of the row-block sequence (measured): C >= 1024 and 32 <= M <= 80 - at d16 / B = 8 that is stage 1 (M = 64) and the
+    first verify chunk (M = 80), not stage 0 (M = 16, where the eight-launch sequence is faster) and not stage 2 (M = 144)."""
+    from sdvar_amd.weights import var_state_dict_device
+    pns, B = LADDER_256, 8
+    lad = as_ladder(pns)
+    tc = E.ModelCtx(var_state_dict_device(16, pns, dev, mode="stress"), 16, pns, B, 2, dev)
+    assert tc.gemm_mode == "f16x2"
+    labels = (torch.arange(B, device=dev) * 7) % 1000
+    lg = torch.empty(2 * B * (lad.lens[0] + lad.lens[1] + lad.lens[2]) * tc.V, device=dev)
+    got = []
+    tc.begin(labels)
+    for s in range(3):
+        tc.forward(rnd(60 + s, (2 * B * lad.lens[s] * tc.Cw,)).to(dev), s, 1, lg); got.append(E.last_gemm_cfg()["bm"] == 17)
+    tc.kv_set_len(0); tc.begin(labels)
+    tc.forward(rnd(70, (2 * B * 5 * tc.Cw,)).to(dev), 0, 2, lg); got.append(E.last_gemm_cfg()["bm"] == 17)
+    tc.kv_set_len(0)
+    assert torch.isfinite(lg[:2 * B * 5 * tc.V]).all()
+    assert got == [False, True, False, True], got
     tc.close(); torch.cuda.empty_cache()

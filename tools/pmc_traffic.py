@@ -8,7 +8,7 @@ requests of wide streaming reads at 64 bytes and is doubled; WRITE_SIZE is exact
 import csv, glob, json, sys, collections
 
 # "gemm_small" = the 32- / 64-row kernels (ring and K-split ping-pong) and the skinny (M <= 80) kernel (the launches with M < 1024 rows, bench.py's gemm_small class); "gemm" = the 128 x 128, 256 x 128 and 256 x 256 kernels
-CLASSES = [("gemm_small", ("gemm_f16x2_small_kernel", "gemm_f16x2_small_pp_kernel", "gemm_f16x2_skinny_kernel")), ("gemm", ("gemm_f16x2", "gemm_bf16x3", "gemm_f32_nt")), ("splitk_reduce", ("splitk_reduce",)), ("ln_modulate", ("ln_modulate",)),
+CLASSES = [("gemm_small", ("gemm_f16x2_small_kernel", "gemm_f16x2_small_pp_kernel", "gemm_f16x2_skinny_kernel", "gemm_f16x2_rowblk_kernel")), ("gemm", ("gemm_f16x2", "gemm_bf16x3", "gemm_f32_nt")), ("splitk_reduce", ("splitk_reduce",)), ("ln_modulate", ("ln_modulate",)),
            ("qk_norm_append", ("qk_norm_append",)), ("attention", ("attention_f16x2", "attention_bf16x3", "attention_f32")), ("sampler", ("cfg_sample",)),
            ("decoder_conv", ("conv_f16x2", "conv_bf16x3", "conv_reduce")), ("decoder_rows", ("prep_planes", "gn_partial", "gn_finalize", "vae_attn", "convout", "rows_from_nchw"))]
 
