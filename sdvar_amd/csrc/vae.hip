@@ -82,21 +82,44 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
 // ---------------------------------------------------------------------------------------------------- planes producer
 // in: fp32 rows [B Hi Wi][C] of a (B, C, Hi, Wi) tensor.  out: planes [3][C/32][G + M_out + G][32] of the (B, C, Ho, Wo) tensor,
 // Ho = Hi << up.  mode bit 0: GroupNorm (stats, gamma, beta); bit 1: SiLU.  Thread = (output row incl. guards, 8 channels).
+// Index arithmetic (round 4): the flat index is 32-bit and the three divisions (by C / 8, W + 2, H + 2) are multiply-high + shift with host-made magic numbers
+// (Granlund / Montgomery, the branch-free form) - the 64-bit / and % of the first version cost more vector instructions per thread than the normalisation,
+// the SiLU and the split together (the kernel ran at 1.9 TB/s of the ~3 GB a decode moves through it).
+struct FastDiv { uint32_t mul, sh; };        // n / d = (((n - t) >> 1) + t) >> sh, t = mulhi(n, mul); d >= 2
+static FastDiv fastdiv_make(uint32_t d) {
+    FastDiv f{0u, 0u};
+    uint32_t l = 31;
+    while (!((d >> l) & 1u)) --l;             // floor(log2 d)
+    if ((d & (d - 1)) == 0) { f.mul = 0; f.sh = l - 1; return f; }
+    const uint64_t num = (uint64_t)1 << (32 + l);
+    uint64_t m = num / d;
+    const uint64_t rem = num - m * d;
+    m += m;
+    const uint64_t twice = rem + rem;
+    if (twice >= d || twice < rem) m += 1;
+    f.mul = (uint32_t)(m + 1); f.sh = l;
+    return f;
+}
+__device__ __forceinline__ uint32_t fastdiv(uint32_t n, FastDiv f) {
+    const uint32_t t = __umulhi(n, f.mul);
+    return (((n - t) >> 1) + t) >> f.sh;
+}
+
 __global__ __launch_bounds__(256) void prep_planes_kernel(const float* __restrict__ in, const float* __restrict__ stats, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, uint16_t* __restrict__ outp, size_t ops, int B, int C, int Hi, int Wi,
-                                                          int up, int mode, int G, int pfmt) {
+                                                          int up, int mode, int G, int pfmt, FastDiv dc8, FastDiv dw, FastDiv dh, FastDiv dg) {
     const int Ho = Hi << up, Wo = Wi << up, w2o = Wo + 2, h2o = Ho + 2;
-    const size_t Mo = (size_t)B * h2o * w2o, R = Mo + 2 * (size_t)G;
-    const int c8n = C >> 3, cpg = C / 32;
-    const size_t total = R * c8n;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int c8 = (int)(i % c8n);
-        const size_t r = i / c8n;
+    const uint32_t Mo = (uint32_t)B * h2o * w2o, R = Mo + 2u * (uint32_t)G;
+    const uint32_t c8n = (uint32_t)C >> 3, cpg = C / 32;
+    const uint32_t total = R * c8n;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const uint32_t r = fastdiv(i, dc8), c8 = i - r * c8n;
         float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         bool live = false;
-        if (r >= (size_t)G && r < (size_t)G + Mo) {
-            const size_t row = r - G;
-            const int x = (int)(row % w2o) - 1, y = (int)((row / w2o) % h2o) - 1, b = (int)(row / ((size_t)w2o * h2o));
+        if (r >= (uint32_t)G && r < (uint32_t)G + Mo) {
+            const uint32_t row = r - G;
+            const uint32_t ry = fastdiv(row, dw), b = fastdiv(ry, dh);
+            const int x = (int)(row - ry * w2o) - 1, y = (int)(ry - b * h2o) - 1;
             if (x >= 0 && x < Wo && y >= 0 && y < Ho) {
                 live = true;
                 const float* p = in + (((size_t)b * Hi + (y >> up)) * Wi + (x >> up)) * C + 8 * c8;
@@ -109,7 +132,7 @@ __global__ __launch_bounds__(256) void prep_planes_kernel(const float* __restric
                     const float* st = stats + (size_t)b * 64;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const int g = (8 * c8 + e) / cpg;
+                        const uint32_t g = cpg == 1 ? 8 * c8 + e : fastdiv(8 * c8 + e, dg);
                         const f32x2p mr = *reinterpret_cast<const f32x2p*>(st + 2 * g);                 // {mean, rstd} of the group
                         v[e] = ((v[e] - mr[0]) * mr[1]) * (e < 4 ? g0[e & 3] : g1[e & 3]) + (e < 4 ? b0[e & 3] : b1[e & 3]);
                     }
@@ -140,6 +163,16 @@ __global__ __launch_bounds__(256) void prep_planes_kernel(const float* __restric
         if (live) split8_packed(v, a, bq, cq);
         *reinterpret_cast<u32x4*>(outp + o) = a; *reinterpret_cast<u32x4*>(outp + ops + o) = bq; *reinterpret_cast<u32x4*>(outp + 2 * ops + o) = cq;
     }
+}
+static int launch_prep_planes(const float* in, const float* stats, const float* gamma, const float* beta, uint16_t* outp, size_t ops, int B, int C, int Hi, int Wi, int up, int mode,
+                              int G, int pfmt, hipStream_t s) {
+    const size_t rows = (size_t)B * ((Hi << up) + 2) * ((Wi << up) + 2) + 2 * (size_t)G, total = rows * (C / 8);
+    SDVAR_CHECK_ARG(total < ((size_t)1 << 31) && C >= 16 && C % 32 == 0, "vae prep: %zu (row, 8-channel) items exceed the 32-bit index range, or C = %d", total, C);
+    const unsigned grid = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(prep_planes_kernel, dim3(grid), dim3(256), 0, s, in, stats, gamma, beta, outp, ops, B, C, Hi, Wi, up, mode, G, pfmt, fastdiv_make((uint32_t)C / 8),
+                       fastdiv_make((uint32_t)(Wi << up) + 2), fastdiv_make((uint32_t)(Hi << up) + 2), fastdiv_make(C / 32 >= 2 ? (uint32_t)C / 32 : 2u));
+    SDVAR_LAUNCH_CHECK();
+    return SDVAR_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------- AttnBlock core
@@ -559,12 +592,7 @@ struct Runner {
         *G = guard_rows(Ho); *rows = plane_rows(B, Ho, Ho); *ops = *rows * (size_t)C;
         SDVAR_CHECK_ARG(v->npl * *ops <= dst_elems, "vae: plane buffer too small");
         if (nw) VAE_TRY(stats_of(src, C));
-        const size_t total = *rows * (C / 8);
-        const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-        hipLaunchKernelGGL(prep_planes_kernel, dim3(grid), dim3(256), 0, s, src, v->stats, nw ? nw->gamma : nullptr, nw ? nw->beta : nullptr, dst, *ops, B, C, H, H,
-                           up, (nw ? 1 : 0) | (silu ? 2 : 0), *G, v->pfmt);
-        SDVAR_LAUNCH_CHECK();
-        return SDVAR_OK;
+        return launch_prep_planes(src, v->stats, nw ? nw->gamma : nullptr, nw ? nw->beta : nullptr, dst, *ops, B, C, H, H, up, (nw ? 1 : 0) | (silu ? 2 : 0), *G, v->pfmt, s);
     }
     int conv(const ConvW& c, const uint16_t* xp, size_t ops, size_t rows, int G, const float* res, float* out) {
         SDVAR_CHECK_ARG(M() * c.cout <= v->f_floats, "vae: activation buffer too small");
@@ -686,11 +714,7 @@ int sdvar_op_conv_weight_planes(const float* w, uint16_t* planes, int32_t Cout, 
 int sdvar_op_vae_prep(const float* in, const float* stats, const float* gamma, const float* beta, uint16_t* planes, uint64_t plane_stride, int32_t plane_format, int32_t B,
                       int32_t C, int32_t H, int32_t W, int32_t up, int32_t mode, int32_t guard, void* stream) {
     SDVAR_CHECK_ARG(in && planes && C % 32 == 0 && (!(mode & 1) || (stats && gamma && beta)), "vae_prep: bad arguments");
-    const size_t rows = (size_t)B * ((H << up) + 2) * ((W << up) + 2) + 2 * (size_t)guard, total = rows * (C / 8);
-    hipLaunchKernelGGL(prep_planes_kernel, dim3((unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192)), dim3(256), 0, (hipStream_t)stream, in, stats, gamma,
-                       beta, planes, (size_t)plane_stride, B, C, H, W, up, mode, guard, plane_format);
-    SDVAR_LAUNCH_CHECK();
-    return SDVAR_OK;
+    return launch_prep_planes(in, stats, gamma, beta, planes, (size_t)plane_stride, B, C, H, W, up, mode, guard, plane_format, (hipStream_t)stream);
 }
 int sdvar_op_conv_planes(const uint16_t* x_planes, uint64_t x_plane_stride, uint64_t x_rows, int32_t x_row0, const uint16_t* w_planes, uint64_t w_plane_stride,
                          int32_t plane_format, const float* w_scale, const float* bias, const float* res, float* out, int32_t B, int32_t H, int32_t W, int32_t N, int32_t Cin,
