@@ -812,11 +812,11 @@ int sdvar_op_noise_fill(float* q, int32_t B, int32_t l, int32_t V, uint64_t seed
 }
 
 int sdvar_debug_set_gemm_cfg(int32_t bm, int32_t split) {
-    // f16x2 only: bm 512 = the 256 x 256 tile kernel; bm 16 = the skinny kernel (M <= 80); bm 256 with split -T = hybrid tail split T ways (the other modes take their nearest tile)
-    SDVAR_CHECK_ARG(bm == 0 || bm == 16 || bm == 32 || bm == 64 || bm == 128 || bm == 256 || bm == 512, "debug_set_gemm_cfg: bm %d", bm);
+    // f16x2 only: bm 512 = the 256 x 256 tile kernel, 768 = the 256 x 192 one; bm 16 = the skinny kernel (M <= 80); bm 256 with split -T = hybrid tail split T ways (the other modes take their nearest tile)
+    SDVAR_CHECK_ARG(bm == 0 || bm == 16 || bm == 32 || bm == 64 || bm == 128 || bm == 256 || bm == 512 || bm == 768, "debug_set_gemm_cfg: bm %d", bm);
     SDVAR_CHECK_ARG(split >= -64 && split <= 64 && (split >= 0 || bm == 256), "debug_set_gemm_cfg: split %d", split);
-    debug_set_gemm_cfg(bm == 512 ? 256 : bm == 16 ? 32 : bm, split < 0 ? 0 : split);
-    debug_set_gemm_cfg_p(bm == 512 ? 256 : bm == 16 ? 32 : bm, split < 0 ? 0 : split);
+    debug_set_gemm_cfg(bm >= 512 ? 256 : bm == 16 ? 32 : bm, split < 0 ? 0 : split);
+    debug_set_gemm_cfg_p(bm >= 512 ? 256 : bm == 16 ? 32 : bm, split < 0 ? 0 : split);
     debug_set_gemm_cfg_h(bm, split);
     return SDVAR_OK;
 }

@@ -1378,6 +1378,181 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_v5_kernel(GemmHArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// 256 x 192 tile (round 4): the 256 x 256 kernel above fills whole rounds of 256 workgroups only where N is a multiple of 256 and M / 256 x N / 256 is near 256; the
+// QKV launches (N = 3 C: 3072 for d16, 2304 for d12) and d12's fc1 (N = 3072) run 132 - 192 tiles on 256 CUs at M = 2704 / 4096.  With 192 columns per tile N = 3072 gives
+// 16 column tiles (256 tiles at M = 4096, 176 at M = 2704) and N = 2304 gives 12 (192 / 132), each with 3/4 of the matrix work.
+//   waves   8 x 1: wave w owns rows 32 w .. 32 w + 31 (2 row tiles of 16) x ALL 192 columns (12 column tiles = 3 whole heads: the fused QKV epilogue keeps one head
+//           inside a wave); acc[2][12] = 96 VGPRs; W is the A operand (a lane holds 4 consecutive columns of one row), as in the 256 x 256 kernel
+//   LDS     X ring of 2 stages (2 planes x 256 rows x 64 B = 32 KB), W ring of 3 stages (2 planes x 192 rows x 64 B = 24 KB): 136 KB.  W of K-step t + 2 is requested in
+//           L0(t) - the stage K-step t - 1 left - and X of K-step t + 2 in L1(t): both two K-steps ahead
+//   slots   (ping-pong: waves 4-7 run one slot behind waves 0-3)  L0 = 4 X + 12 W fragment reads (W column tiles 0-5) + 3 DMA; M0 = 2 x 6 x 3 = 36 MFMAs;
+//           L1 = 12 W fragment reads (tiles 6-11) + 4 DMA + the counted wait for K-step t + 1; M1 = 36 MFMAs
+constexpr int H7_XSTAGE = 2 * 256 * 32, H7_WSTAGE = 2 * 192 * 32;          // fp16 elements per X / W stage
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_f16x2_v7_kernel(GemmHArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t hsm[];
+    constexpr int BM = 256, BN = 192;
+    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN, ntile = tiles_m * tiles_n;
+    const int ks = blockIdx.x / ntile;
+    const int lid = xcd_remap(blockIdx.x - ks * ntile, ntile);
+    const int G = 4, per_group = tiles_m * G;
+    const int g = lid / per_group, rem = lid - g * per_group;
+    const int gw = min(G, tiles_n - g * G);
+    const int tm = rem / gw, tn = g * G + rem % gw;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int late = wave >> 2;
+    const int kt0 = ks * a.k_per_split;
+    const int nk = min(a.K / HBK - kt0, a.k_per_split);
+
+    // DMA: waves 0-3 bring plane 0, waves 4-7 plane 1; a wave's instruction = 16 rows x 64 B; X: rows 64 (wave & 3) + 16 e (e < 4); W: rows 48 (wave & 3) + 16 e (e < 3)
+    const int dpl = wave >> 2, dr = lane >> 2;
+    const int dch = (lane & 3) ^ ((lane >> 4) & 3);
+    uint32_t vx[4], vw[3];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) vx[e] = (uint32_t)(min(m0 + 64 * (wave & 3) + 16 * e + dr, a.M - 1) * 32 + 8 * dch) * 2u;
+#pragma unroll
+    for (int e = 0; e < 3; ++e) vw[e] = (uint32_t)(min(n0 + 48 * (wave & 3) + 16 * e + dr, a.N - 1) * 32 + 8 * dch) * 2u;
+    const char* const bx = reinterpret_cast<const char*>(a.X + (size_t)kt0 * a.M * 32 + (size_t)dpl * a.xps);
+    const char* const bw = reinterpret_cast<const char*>(a.W + (size_t)kt0 * a.N * 32 + (size_t)dpl * a.wps);
+    const uint32_t lds0 = SDVAR_LDS_ADDR(hsm);
+    const uint32_t ldx = lds0 + (uint32_t)(dpl * 16384 + 64 * (wave & 3) * 64);
+    const uint32_t ldw = lds0 + 65536u + (uint32_t)(dpl * 12288 + 48 * (wave & 3) * 64);
+    auto issue_x = [&](int t) {
+        const char* src = bx + (size_t)t * a.M * 64;
+        const uint32_t dst = ldx + (uint32_t)(t & 1) * 32768u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) SDVAR_DMA16(vx[e], src, dst + 1024u * e);
+    };
+    auto issue_w = [&](int t) {
+        const char* src = bw + (size_t)t * a.N * 64;
+        const uint32_t dst = ldw + (uint32_t)(t % 3) * 24576u;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) SDVAR_DMA16(vw[e], src, dst + 1024u * e);
+    };
+
+    f32x4v acc[2][12];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 12; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+    const uint32_t fro = (uint32_t)(l15 * 64 + 16 * (lq ^ ((l15 >> 2) & 3)));
+    const uint32_t ax = lds0 + (uint32_t)(wave * 32 * 64) + fro, aw = lds0 + 65536u + fro;
+
+    issue_w(0); issue_x(0);
+    if (nk > 1) { issue_w(1); issue_x(1); asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (late) __builtin_amdgcn_s_barrier();
+
+    f16x8 fx[2][2], fw[6][2];
+#define SDVAR_H7_SLOT() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define SDVAR_H7_MFMA(J0)                                                                                                  \
+    do {                                                                                                                   \
+        _Pragma("unroll") for (int j_ = 0; j_ < 6; ++j_)                                                                   \
+            _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) { SDVAR_MFMA3_16(acc[i_][(J0) + j_], fx[i_][0], fx[i_][1], fw[j_][0], fw[j_][1]); } \
+    } while (0)
+#pragma unroll 1
+    for (int t = 0; t < nk; ++t) {
+        const uint32_t x0 = ax + (uint32_t)(t & 1) * 32768u, w0 = aw + (uint32_t)(t % 3) * 24576u;
+        const bool p2 = t + 2 < nk;
+        // ---- L0: the wave's two X row tiles, W column tiles 0-5; W of K-step t + 2 into the stage K-step t - 1 left (every wave is past its L1(t - 1))
+        SDVAR_LDS_RDH(fx[0][0], x0, 0);     SDVAR_LDS_RDH(fx[0][1], x0, 16384); SDVAR_LDS_RDH(fw[0][0], w0, 0);     SDVAR_LDS_RDH(fw[0][1], w0, 12288);
+        SDVAR_LDS_RDH(fx[1][0], x0, 1024);  SDVAR_LDS_RDH(fx[1][1], x0, 17408); SDVAR_LDS_RDH(fw[1][0], w0, 1024);  SDVAR_LDS_RDH(fw[1][1], w0, 13312);
+        SDVAR_LDS_RDH(fw[2][0], w0, 2048);  SDVAR_LDS_RDH(fw[2][1], w0, 14336); SDVAR_LDS_RDH(fw[3][0], w0, 3072);  SDVAR_LDS_RDH(fw[3][1], w0, 15360);
+        SDVAR_LDS_RDH(fw[4][0], w0, 4096);  SDVAR_LDS_RDH(fw[4][1], w0, 16384); SDVAR_LDS_RDH(fw[5][0], w0, 5120);  SDVAR_LDS_RDH(fw[5][1], w0, 17408);
+        if (p2) issue_w(t + 2);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SDVAR_H7_SLOT();
+        SDVAR_H7_MFMA(0);                                                                                     // M0: 32 rows x columns 0-95
+        SDVAR_H7_SLOT();
+        // ---- L1: W column tiles 6-11; the X stage is free (both halves read it in their L0): refill it with K-step t + 2
+        SDVAR_LDS_RDH(fw[0][0], w0, 6144);  SDVAR_LDS_RDH(fw[0][1], w0, 18432); SDVAR_LDS_RDH(fw[1][0], w0, 7168);  SDVAR_LDS_RDH(fw[1][1], w0, 19456);
+        SDVAR_LDS_RDH(fw[2][0], w0, 8192);  SDVAR_LDS_RDH(fw[2][1], w0, 20480); SDVAR_LDS_RDH(fw[3][0], w0, 9216);  SDVAR_LDS_RDH(fw[3][1], w0, 21504);
+        SDVAR_LDS_RDH(fw[4][0], w0, 10240); SDVAR_LDS_RDH(fw[4][1], w0, 22528); SDVAR_LDS_RDH(fw[5][0], w0, 11264); SDVAR_LDS_RDH(fw[5][1], w0, 23552);
+        // K-step t + 1 must have landed before ANY wave starts it: the early half reads it two slots from here, when the late half has just left this segment - so the
+        // counted wait stands HERE, not behind M1 (this wave's share; the barriers make it everybody's): the 7 instructions of K-step t + 2 may stay in flight
+        if (p2) { issue_x(t + 2); asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SDVAR_H7_SLOT();
+        SDVAR_H7_MFMA(6);                                                                                     // M1: 32 rows x columns 96-191
+        SDVAR_H7_SLOT();
+    }
+    if (!late) __builtin_amdgcn_s_barrier();
+#undef SDVAR_H7_MFMA
+#undef SDVAR_H7_SLOT
+
+    const float wsi = a.wsi ? *a.wsi : 1.0f;
+    const int mrow = m0 + wave * 32 + l15, ncol = n0 + 4 * lq;                        // + 16 i (row tile), + 16 j (column tile)
+    if (EPI == HEPI_QKV) {             // the wave's 192 columns are three whole heads of q, k or v (N = 3 H 64, n0 a multiple of 64)
+        const QkvEpi& e = a.qk;
+        const int Cq = e.H * 64;
+        const bool l2 = e.scale_mul != nullptr;
+        const int NP = e.fmt == 3 ? 2 : 1;
+        const size_t ps = (size_t)e.Lp * 64;
+#pragma unroll
+        for (int hh = 0; hh < 3; ++hh) {
+            const int nw = n0 + 64 * hh;
+            if (nw >= a.N) break;
+            const int which = nw / Cq, h = (nw - which * Cq) >> 6;
+            const float sm = (which == 0) ? (l2 ? expf(fminf(e.scale_mul[h], 4.605170249938965f)) : 0.03125f) : 1.0f;
+            f32x4 bv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[j] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + nw + 4 * lq + 16 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int m = mrow + 16 * i;
+                float v[4][4], sq = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) { v[j][x] = acc[i][4 * hh + j][x] * wsi + bv[j][x]; sq += v[j][x] * v[j][x]; }
+                if (which != 2 && l2) { sq += __shfl_xor(sq, 16, 64); sq += __shfl_xor(sq, 32, 64); }
+                if (m >= a.M) continue;
+                const float nrm = l2 ? fmaxf(sqrtf(sq), 1e-12f) : 1.0f;
+                const int r = m / e.l, tt = m - r * e.l;
+                if (which == 0) {
+                    float* pq = e.q_out + (((size_t)r * e.H + h) * e.l + tt) * 64 + 4 * lq;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        f32x4 o;
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) o[x] = l2 ? (v[j][x] / nrm) * sm : v[j][x] * sm;
+                        *reinterpret_cast<f32x4*>(pq + 16 * j) = o;
+                    }
+                } else {
+                    const bool nkk = l2 && which == 1;
+                    uint16_t* pk = (which == 1 ? e.k_cache : e.v_cache) + ((size_t)r * e.H + h) * NP * ps + (size_t)(e.pos0 + tt) * 64 + 4 * lq;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float kv[4];
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) kv[x] = nkk ? v[j][x] / nrm : v[j][x];
+                        uint2 wh, wl;
+                        split4h_pk(kv, wh, wl);
+                        *reinterpret_cast<uint2*>(pk + 16 * j) = wh;
+                        if (e.fmt == 3) *reinterpret_cast<uint2*>(pk + ps + 16 * j) = wl;
+                    }
+                }
+            }
+        }
+        return;
+    }
+    float* outp = (EPI == HEPI_PARTIAL) ? a.out + (size_t)ks * a.M * a.ldo : a.out;
+    const bool fast = a.vec && n0 + BN <= a.N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 12; ++j) h_store4<EPI>(a, outp, acc[i][j], wsi, mrow + 16 * i, ncol + 16 * j, fast);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Skinny kernel for M <= 80 rows (stages 0 - 1 and the first verify chunk: 16 - 80 CFG rows): these launches are weight streams - 4 - 17 MB of planes read once for
 // 0.1 - 0.8 GFLOP - and the LDS-ring kernels above spend their time on everything else: split-K over 6 - 24 workgroups per column panel, slabs, a reduce launch
 // or a slab-summing consumer, a DMA ring that never fills (9 - 12 us per launch against a 2 - 3 us stream: profiles/r02_gemm_sweep_cold_full.jsonl).
@@ -1885,6 +2060,15 @@ static void choose_cfg_h(int M, int N, int K, size_t ws_floats, int* bm_out, int
         const double cyc = rounds * (nkt * CM_K4 + CM_FIX4);
         if (cyc < best) { best = cyc; bbm = 512; bs = 1; btail = 0; }
     }
+    // the 256 x 192 ping-pong kernel (bm code 768): 3/4 of the 256 x 256 tile's matrix work per K-step and whole rounds where N / 192 x M / 256 fills the chip better
+    // than N / 256 does (N = 3 C); same conditions.  Constants: the 256 x 256 kernel's scaled by the MFMA count (72 of 96 per wave and K-step) and
+    // the epilogue's share of the fixed part; checked against tools/gemm_bench.py --force on the d12 / d16 shapes (profiles/r04_n_v7_ab.log)
+    static const bool no_v7 = getenv("SDVAR_GEMM_NO_V7") != nullptr;       // A/B runs only
+    if (!no_v4 && !no_v7 && N >= 192 && N % 64 == 0 && M > 512) {      // a ragged last column tile is fine (N = 4096: 22 tiles; d16 fc1 at M = 2704: 68.7 against 78.0 us)
+        const long tiles7 = (long)((M + 255) / 256) * ((N + 191) / 192), rounds = (tiles7 + 255) / 256;
+        const double cyc = rounds * (nkt * (0.75 * CM_K4) + 0.85 * CM_FIX4);
+        if (cyc < best) { best = cyc; bbm = 768; bs = 1; btail = 0; }
+    }
     *bm_out = bbm; *split_out = bs; *tail_out = btail;
 }
 
@@ -2019,6 +2203,37 @@ static int launch_h4(GemmHArgs a, int epi, int split, hipStream_t stream) {
         case HEPI_BIAS: return launch_h4_kernel<HEPI_BIAS>(a, tiles, stream);
         case HEPI_BIAS_GELU_PLANES: return launch_h4_kernel<HEPI_BIAS_GELU_PLANES>(a, tiles, stream);
         default: return launch_h4_kernel<HEPI_GATED_RES>(a, tiles, stream);
+    }
+}
+
+template <int EPI>
+static int launch_h7_kernel(const GemmHArgs& a, int grid, hipStream_t stream) {
+    const size_t lds = (2 * (size_t)H7_XSTAGE + 3 * (size_t)H7_WSTAGE) * sizeof(uint16_t);      // 136 KB
+    static LdsOptIn opt_in;
+    SDVAR_LDS_OPT_IN(opt_in, lds, (const void*)gemm_f16x2_v7_kernel<EPI>);
+    hipLaunchKernelGGL((gemm_f16x2_v7_kernel<EPI>), dim3(grid), dim3(512), lds, stream, a);
+    SDVAR_LAUNCH_CHECK();
+    return SDVAR_OK;
+}
+static int launch_h7(GemmHArgs a, int epi, int split, hipStream_t stream) {
+    const int tiles = ((a.M + 255) / 256) * ((a.N + 191) / 192);
+    const int nkt = a.K / HBK;
+    if (split > 1) {
+        size_t wsf = 0;
+        float* ws = splitk_workspace(&wsf);
+        if (!ws) return SDVAR_ERR_HIP;
+        GemmHArgs p = a;
+        p.out = ws; p.ldo = a.N; p.split = split; p.k_per_split = (nkt + split - 1) / split;
+        int rc = launch_h7_kernel<HEPI_PARTIAL>(p, tiles * split, stream);
+        if (rc) return rc;
+        if (g_defer_h) { *g_defer_h = split; return SDVAR_OK; }
+        return launch_reduce_h(a, ws, split, epi, stream);
+    }
+    a.split = 1; a.k_per_split = nkt;
+    switch (epi) {
+        case HEPI_BIAS: return launch_h7_kernel<HEPI_BIAS>(a, tiles, stream);
+        case HEPI_BIAS_GELU_PLANES: return launch_h7_kernel<HEPI_BIAS_GELU_PLANES>(a, tiles, stream);
+        default: return launch_h7_kernel<HEPI_GATED_RES>(a, tiles, stream);
     }
 }
 
@@ -2325,12 +2540,14 @@ int gemm_f16x2_nt(const uint16_t* X, size_t xps, const uint16_t* W, size_t wps, 
     if (qkv && split == 1 && tail == 0) {
         a.qk = *g_qkv_epi; a.split = 1; a.k_per_split = K / HBK;
         *g_qkv_fused = 1;
+        if (bm == 768) return launch_h7_kernel<HEPI_QKV>(a, ((M + 255) / 256) * ((N + 191) / 192), stream);
         if (bm == 512) return launch_h4_kernel<HEPI_QKV>(a, ((M + 255) / 256) * ((N + 255) / 256), stream);
         if (bm == 256) return launch_h3_kernel<HEPI_QKV>(a, ((M + 255) / 256) * ((N + HBN - 1) / HBN), stream);
         if (bm == 128) return launch_h2_kernel<HEPI_QKV>(a, ((M + 127) / 128) * ((N + HBN - 1) / HBN), stream);
         if (bm == 64) return launch_small_any<64, HEPI_QKV>(a, ((M + 63) / 64) * ((N + HBN - 1) / HBN), stream);
         return launch_small_any<32, HEPI_QKV>(a, ((M + 31) / 32) * ((N + HBN - 1) / HBN), stream);
     }
+    if (bm == 768) return launch_h7(a, epi, split, stream);
     if (bm == 512) return launch_h4(a, epi, split, stream);
     if (bm == 256 && tail > 0) return launch_h3_hybrid(a, epi, tail, stream);
     if (bm == 256) return launch_h3(a, epi, split, stream);

@@ -563,7 +563,7 @@ def test_gemm_f16x2_epilogues(dev, M, N, K, epi):
     assert err <= 2e-5 * max(1.0, ref.abs().max().item()), err
 
 
-@pytest.mark.parametrize("bm", [32, 64, 128, 256, 512])
+@pytest.mark.parametrize("bm", [32, 64, 128, 256, 512, 768])
 @pytest.mark.parametrize("M,N,K,split", [(130, 192, 64, 1), (1, 128, 32, 1), (257, 384, 1024, 3), (4096, 256, 1024, 1), (2704, 1024, 4096, 5), (100, 4096, 1024, 2),
                                          (300, 256, 96, 1), (300, 256, 96, 3), (700, 768, 160, 1)])
 @pytest.mark.parametrize("epi", [0, 1, 2])
@@ -669,7 +669,7 @@ def test_gemm_f16x2_skinny_kernel(dev, M, N, K, split, epi):
         assert err <= 2e-5 * max(1.0, ref.abs().max().item()), (force, err)
 
 
-@pytest.mark.parametrize("bm", [32, 64, 128, 256, 512])
+@pytest.mark.parametrize("bm", [32, 64, 128, 256, 512, 768])
 @pytest.mark.parametrize("epi", [0, 2])
 def test_gemm_f16x2_unaligned_epilogue(dev, bm, epi):
     """The epilogues move 16 bytes per access when every pointer and leading dimension allows it; odd leading dimensions and a bias / gate / res pointer off
@@ -767,7 +767,7 @@ def test_split_gemm_outlier_and_tiny_activations(dev, mode):
         assert (err[tiny] / rowmax[tiny]).max().item() <= 5e-3             # the documented loss of relative precision, bounded
 
 
-@pytest.mark.parametrize("bm", [32, 64, 128, 256, 512])
+@pytest.mark.parametrize("bm", [32, 64, 128, 256, 512, 768])
 @pytest.mark.parametrize("kv_fp16", [False, True])
 def test_qkv_epilogue_forced_tiles(dev, bm, kv_fp16):
     """The HEPI_QKV epilogue of EVERY f16x2 kernel (32- / 64-row ring kernel, 128 x 128, 256 x 128), forced through sdvar_debug_set_gemm_cfg(bm, 1), against
