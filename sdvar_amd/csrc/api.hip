@@ -24,7 +24,7 @@ int qk_norm_append(const float* qkv, const float* scale_mul, float* q_out, void*
 int gemm_f16x2_qkv(const uint16_t* X, size_t xps, const uint16_t* W, size_t wps, const float* wsi, const float* bias, float* out, int ldo, int M, int N, int K,
                    const float* scale_mul, float* q_out, void* k_cache, void* v_cache, int l, int H, int Lp, int pos0, int kv_fmt, int* defer, int* fused, hipStream_t stream);
 bool gemm_f16x2_rowblk_ok(int M, int N, int K, int ln, int qkv);
-bool gemm_f16x2_rowblk_want(int M, int C, int V);
+bool gemm_f16x2_rowblk_want(int M, int C, int V, int rows_per_img);
 int gemm_f16x2_rowblk(const float* x, int ldx, const float* scale, const float* shift, int rows_per_img, int mod_stride, const uint16_t* X, size_t xps,
                       const uint16_t* W, size_t wps, const float* wsi, const float* bias, float* out, int ldo, uint16_t* outp, size_t ops, int M, int N, int K, int epi,
                       const float* res, int ldres, const float* gate, int rows_per_gate, int gate_stride,
@@ -520,7 +520,7 @@ static int stage_forward_impl(sdvar_model_t* m, float* x, int32_t s0, int32_t n,
     // 32 .. 80 rows in GEMM mode f16x2 (round 4; stage 1 and the first verify chunk at B = 8): FIVE launches per block instead of eight - LayerNorm + modulation run in the operand prologue of the QKV / fc1 / head
     // launch (gemm_f16x2_rowblk_kernel), the QKV launch finishes q, k and v (no qk_norm_append), fc2 streams K = 4C unsplit (no slabs for the next LayerNorm to sum).
     // The f16x2 guard counts the operand planes ln_modulate writes, so a guarded call keeps the old sequence.
-    const bool RB = m->d.gemm_mode == 2 && (m->kv_fmt == 3 || m->kv_fmt == 4) && !g_guard_on && skip == 0 && gemm_f16x2_rowblk_want(M, C, V);
+    const bool RB = m->d.gemm_mode == 2 && (m->kv_fmt == 3 || m->kv_fmt == 4) && !g_guard_on && skip == 0 && gemm_f16x2_rowblk_want(M, C, V, lsum);
     for (int i = 0; i < m->d.depth && RB; ++i) {
         const BlockW& b = m->blk[i];
         const float* ada = m->ada + (size_t)i * m->Rmax * 6 * C;

@@ -2374,13 +2374,14 @@ bool gemm_f16x2_rowblk_ok(int M, int N, int K, int ln, int qkv) {
 }
 
 // stage_forward's question: should a call with M rows take the row-block sequence?  (2 forces it at every M <= 80: A/B runs and the tests of the 16-row shapes)
-bool gemm_f16x2_rowblk_want(int M, int C, int V) {
+bool gemm_f16x2_rowblk_want(int M, int C, int V, int rows_per_img) {
     g_rowblk_floor = true;
     if (g_rowblk < 0) { const char* e = getenv("SDVAR_ROWBLK"); g_rowblk = e ? atoi(e) : 1; }
     if (g_rowblk == 2) g_rowblk_floor = false;
     // ... and a width floor: at C = 768 (d12) the QKV launch has only 36 x ceil(M / 16) workgroups and fc1 falls between one and two rounds - stage 1 of d12 ran
     // 0.68 ms fused against 0.62 ms (profiles/r04_g_stage_d12.log); at C = 1024 (d16) 0.86 against 0.96
-    const bool ok = (!g_rowblk_floor || C >= 1024) && gemm_f16x2_rowblk_ok(M, 3 * C, C, 1, 1) && gemm_f16x2_rowblk_ok(M, C, 4 * C, 0, 0) && gemm_f16x2_rowblk_ok(M, V, C, 1, 0);
+    // ... and at least 4 rows per image (the measured cases: l = 4, 5): with one image per row (stage 0 of a large batch) a row block reads 16 x 8 KB of modulation vectors
+    const bool ok = (!g_rowblk_floor || (C >= 1024 && rows_per_img >= 4)) && gemm_f16x2_rowblk_ok(M, 3 * C, C, 1, 1) && gemm_f16x2_rowblk_ok(M, C, 4 * C, 0, 0) && gemm_f16x2_rowblk_ok(M, V, C, 1, 0);
     g_rowblk_floor = false;
     return ok;
 }
