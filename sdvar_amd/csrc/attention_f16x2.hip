@@ -143,16 +143,48 @@ __device__ __forceinline__ void softmax_tile(f32x16& s, int k0, int vis_q, int l
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         u32x4 ph, pl;
+#if defined(SDVAR_ATTN_P1)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { uint32_t hw; asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hw) : "v"(pr[4 * j + e][0]), "v"(pr[4 * j + e][1])); ph[e] = hw; pl[e] = 0u; }
+#elif !defined(SDVAR_ATTN_FMA_MIX)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {                                    // p in [0, 2^ATT_DEFER]: inside the fp16 range, no clamp
             uint32_t hw, lw;
-#ifdef SDVAR_ATTN_P1
-            asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hw) : "v"(pr[4 * j + e][0]), "v"(pr[4 * j + e][1])); lw = 0u;
-#else
             split2h_pk_raw(pr[4 * j + e][0], pr[4 * j + e][1], hw, lw);
-#endif
             ph[e] = hw; pl[e] = lw;
         }
+#else
+        // -DSDVAR_ATTN_FMA_MIX (an EXPERIMENT of round 4, measured and not adopted: bit-identical, deterministic, 16 vector instructions fewer per tile and wave - and not a
+        // microsecond faster, profiles/r04_r_attn_valu_experiment.log: the slot is not bound by vector issue).
+        // h = fp16(p) by the compiler's v_cvt_pk_f16_f32; l = fp16(p - h) in ONE instruction per value: v_fma_mixlo / mixhi_f16 take h as an fp16 source and p as an fp32
+        // source (h * -1.0 + p, computed exactly, rounded once: bit-identical to the convert-subtract-convert sequence on 1 M random pairs incl. subnormal low planes,
+        // tools/micro/fma_mix_probe.hip) - 3 instead of 5 vector instructions per pair, 16 fewer per tile and wave in a slot whose length IS its vector instruction count
+        // (profiles/r04_h_attn_counters.json).  hipcc pads no hazards around asm statements (cdna_hip_programming.md 5.7), so the block carries its own: s_nop 1 in front
+        // (the p values come out of v_exp_f32: transcendental-result forwarding), the four mixlo before the four mixhi (a partial write is not read by the next
+        // instruction: dst_sel forwarding), s_nop 0 behind (the consumer may be a compiler-made copy).
+        {
+            uint32_t h0, h1, h2, h3, l0, l1, l2, l3;
+            const f32x2 q0 = pr[4 * j], q1 = pr[4 * j + 1], q2 = pr[4 * j + 2], q3 = pr[4 * j + 3];
+            {
+                const f16x2v c0 = __builtin_convertvector(q0, f16x2v), c1 = __builtin_convertvector(q1, f16x2v), c2 = __builtin_convertvector(q2, f16x2v),
+                             c3 = __builtin_convertvector(q3, f16x2v);
+                h0 = __builtin_bit_cast(uint32_t, c0); h1 = __builtin_bit_cast(uint32_t, c1); h2 = __builtin_bit_cast(uint32_t, c2); h3 = __builtin_bit_cast(uint32_t, c3);
+            }
+            asm volatile("s_nop 1\n\t"
+                         "v_fma_mixlo_f16 %0, %4, -1.0, %8 op_sel_hi:[1,0,0]\n\t"
+                         "v_fma_mixlo_f16 %1, %5, -1.0, %10 op_sel_hi:[1,0,0]\n\t"
+                         "v_fma_mixlo_f16 %2, %6, -1.0, %12 op_sel_hi:[1,0,0]\n\t"
+                         "v_fma_mixlo_f16 %3, %7, -1.0, %14 op_sel_hi:[1,0,0]\n\t"
+                         "v_fma_mixhi_f16 %0, %4, -1.0, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                         "v_fma_mixhi_f16 %1, %5, -1.0, %11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                         "v_fma_mixhi_f16 %2, %6, -1.0, %13 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                         "v_fma_mixhi_f16 %3, %7, -1.0, %15 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                         "s_nop 0"
+                         : "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3)
+                         : "v"(h0), "v"(h1), "v"(h2), "v"(h3), "v"(q0[0]), "v"(q0[1]), "v"(q1[0]), "v"(q1[1]), "v"(q2[0]), "v"(q2[1]), "v"(q3[0]), "v"(q3[1]));
+            ph = u32x4{h0, h1, h2, h3}; pl = u32x4{l0, l1, l2, l3};
+        }
+#endif
         pp[j][0] = __builtin_bit_cast(f16x8, ph); pp[j][1] = __builtin_bit_cast(f16x8, pl);
     }
 }
@@ -457,9 +489,7 @@ __global__ __launch_bounds__(512, 2) void attention_f16x2_pp_kernel(AttnHArgs a)
             const int k0 = t * AKT;
             SDVAR_PP_STAMP(0);
             // ---------------- M(t): PV(t-1), S(t)
-            f32x16 s;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) s[i] = 0.f;
+            f32x16 s;                                   // an inactive wave never reads it
             if (wave_active) {
                 if (t > 0) {
 #pragma unroll
@@ -468,8 +498,13 @@ __global__ __launch_bounds__(512, 2) void attention_f16x2_pp_kernel(AttnHArgs a)
                         mfma_pv<NKP>(o1, vf[j][1], pp[j]);
                     }
                 }
+                // the first product takes a ZERO C operand (an inline constant of the instruction) instead of a zeroed accumulator: the 16 + 7 register moves that cleared
+                // s stood in this slot of every tile, and matrix and vector instructions of a SIMD's two waves do not overlap (section 4a of DESIGN.md)
+                const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                s = zero16;
+                mfma_planes<NKP>(s, kf[0], qp[0]);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) mfma_planes<NKP>(s, kf[c], qp[c]);
+                for (int c = 1; c < 4; ++c) mfma_planes<NKP>(s, kf[c], qp[c]);
             }
             if (t + 1 < ntiles) wait_tiles(min(D - 2, ntiles - 2 - t));          // tile t + 1 landed; the tiles requested after it stay in flight
             SDVAR_PP_SLOT(); SDVAR_PP_STAMP(1);
