@@ -490,7 +490,11 @@ __global__ __launch_bounds__(512, 2) void attention_f16x2_pp_kernel(AttnHArgs a)
             SDVAR_PP_STAMP(0);
             // ---------------- M(t): PV(t-1), S(t)
             f32x16 s;                                   // an inactive wave never reads it
+#ifdef SDVAR_ATT_EXP          // timing experiments only (results wrong; tools/micro/attn_lds_exp.sh): bit 0 no V fragment reads, 1 no K fragment reads, 2 no softmax arithmetic, 3 no MFMAs
+            if (wave_active && !((SDVAR_ATT_EXP) & 8)) {
+#else
             if (wave_active) {
+#endif
                 if (t > 0) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
@@ -509,12 +513,21 @@ __global__ __launch_bounds__(512, 2) void attention_f16x2_pp_kernel(AttnHArgs a)
             if (t + 1 < ntiles) wait_tiles(min(D - 2, ntiles - 2 - t));          // tile t + 1 landed; the tiles requested after it stay in flight
             SDVAR_PP_SLOT(); SDVAR_PP_STAMP(1);
             // ---------------- V(t): reads first, then the arithmetic
+#ifdef SDVAR_ATT_EXP
+            if (t + 1 < ntiles && !(((SDVAR_ATT_EXP) & 2) && t > 0)) read_k(t + 1);
+            if (t + D < ntiles) issue(t + D);
+            __builtin_amdgcn_sched_barrier(0);
+            auto mid = [&]() { __builtin_amdgcn_sched_barrier(0); if (!(((SDVAR_ATT_EXP) & 1) && t > 0)) read_v(t); __builtin_amdgcn_sched_barrier(0); };
+            if (wave_active && !(((SDVAR_ATT_EXP) & 4) && t > 0)) { if ((SDVAR_ATT_EXP) & 8) { for (int i = 0; i < 16; ++i) s[i] = (float)(i + t); } softmax_tile(s, k0, vis_q, lh, M_run, l_run, o0, o1, pp, mid); }
+            else mid();
+#else
             if (t + 1 < ntiles) read_k(t + 1);
             if (t + D < ntiles) issue(t + D);
             __builtin_amdgcn_sched_barrier(0);
             auto mid = [&]() { __builtin_amdgcn_sched_barrier(0); read_v(t); __builtin_amdgcn_sched_barrier(0); };
             if (wave_active) softmax_tile(s, k0, vis_q, lh, M_run, l_run, o0, o1, pp, mid);
             else mid();
+#endif
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             SDVAR_PP_SLOT(); SDVAR_PP_STAMP(2);
         }
