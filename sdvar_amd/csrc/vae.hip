@@ -188,6 +188,84 @@ typedef float f32x2v __attribute__((ext_vector_type(2)));
 // GPS = true: the probabilities of the workgroup's 16 queries live in a global scratch row block instead of LDS - token maps beyond ~1900 tokens (the 64 x 64
 // latent of the 1024^2 ladder: 4096 tokens x 80 bytes = 320 KB).  Every phase of the kernel is separated by __syncthreads(), a workgroup's waves share one CU
 // and its L1, so the same code runs on either pointer; this path is about reach, not speed.
+// The same attention on the fp32 matrix cores (round 4; v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulate - no operand splitting needed at 1.3 GFLOP per
+// launch), for N = 256 / 1024 tokens and C % 64 == 0.  Workgroup = 16 queries of one image, 8 waves:
+//   scores   wave w owns keys [w N / 8, (w + 1) N / 8): S = Q K^T in 16 x 16 tiles; per 16 channels a lane loads ONE float4 of its query row and one of each key row
+//            (channels 16 s + 4 (l >> 4) ..) and feeds four MFMAs - the k index of MFMA j is channel 16 s + 4 g + j, the same permutation on both operands
+//   softmax  as in vae_attn_kernel (expf of the shifted scores, sum, scale), one wave per 2 queries, probabilities in LDS [16][N + 4]
+//   output   wave w owns 64-channel groups w, w + 8, ...: O = P V; per 16 keys one float4 of P from LDS and four float4 of V rows (channels 4 j .. 4 j + 3 of the group:
+//            column tile e of the group holds channels {4 j + e}), sixteen MFMAs; a lane ends with 4 consecutive channels of 4 queries: float4 stores
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+template <int NKT>          // key tiles of 16 per wave = N / 128
+__global__ __launch_bounds__(512) void vae_attn_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, int N) {
+    extern __shared__ __attribute__((aligned(16))) float vps[];      // [16][N + 4]
+    const int b = blockIdx.y, q0 = blockIdx.x * 16, tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int SP = N + 4;
+    const float* base = qkv + (size_t)b * N * 3 * C;
+    const float scale = 1.0f / sqrtf((float)C);
+    {
+        f32x4m acc[NKT];
+#pragma unroll
+        for (int t = 0; t < NKT; ++t) acc[t] = f32x4m{0.f, 0.f, 0.f, 0.f};
+        const float* pq = base + (size_t)(q0 + j) * 3 * C + 4 * g;
+        const float* pk = base + (size_t)(wave * (N / 8) + j) * 3 * C + C + 4 * g;
+#pragma unroll 4
+        for (int c0 = 0; c0 < C; c0 += 16) {
+            const f32x4 qv = *reinterpret_cast<const f32x4*>(pq + c0);
+            f32x4 kv[NKT];
+#pragma unroll
+            for (int t = 0; t < NKT; ++t) kv[t] = *reinterpret_cast<const f32x4*>(pk + (size_t)(16 * t) * 3 * C + c0);
+#pragma unroll
+            for (int t = 0; t < NKT; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[e], kv[t][e], acc[t], 0, 0, 0);
+        }
+        // D: lane holds S[query 4 g + r][key tile column j]
+#pragma unroll
+        for (int t = 0; t < NKT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vps[(4 * g + r) * SP + wave * (N / 8) + 16 * t + j] = acc[t][r] * scale;
+    }
+    __syncthreads();
+    for (int qi = 2 * wave; qi < 2 * wave + 2; ++qi) {
+        float* row = vps + qi * SP;
+        float m = -INFINITY;
+        for (int k = lane; k < N; k += 64) m = fmaxf(m, row[k]);
+        m = wave_max(m);
+        float sum = 0.f;
+        for (int k = lane; k < N; k += 64) { const float e = expf(row[k] - m); row[k] = e; sum += e; }
+        sum = wave_sum(sum);
+        const float inv = 1.0f / sum;
+        for (int k = lane; k < N; k += 64) row[k] *= inv;
+    }
+    __syncthreads();
+    const float* pp = vps + j * SP + 4 * g;                              // A operand: P[query j][key k0 + 4 g + e]
+    for (int grp = wave; grp < C / 64; grp += 8) {
+        f32x4m acc[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = f32x4m{0.f, 0.f, 0.f, 0.f};
+        const float* pv = base + 2 * C + 64 * grp + 4 * j;                // B operand: V[key][channels 64 grp + 4 j .. + 3]
+#pragma unroll 4
+        for (int k0 = 0; k0 < N; k0 += 16) {
+            const f32x4 pr = *reinterpret_cast<const f32x4*>(pp + k0);
+            f32x4 vv[4];
+#pragma unroll
+            for (int mm = 0; mm < 4; ++mm) vv[mm] = *reinterpret_cast<const f32x4*>(pv + (size_t)(k0 + 4 * g + mm) * 3 * C);
+#pragma unroll
+            for (int mm = 0; mm < 4; ++mm)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(pr[mm], vv[mm][e], acc[e], 0, 0, 0);
+        }
+        // D of column tile e: lane holds O[query 4 g + r][channel 64 grp + 4 j + e]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int qi = q0 + 4 * g + r;
+            *reinterpret_cast<f32x4*>(out + ((size_t)b * N + qi) * C + 64 * grp + 4 * j) = f32x4{acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+        }
+    }
+}
+
 template <bool GPS>
 __global__ __launch_bounds__(256) void vae_attn_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, int N, float* __restrict__ gps) {
     extern __shared__ __attribute__((aligned(16))) float vsm[];
@@ -626,7 +704,17 @@ struct Runner {
         const size_t lds_fix = ((size_t)32 * 256 + 32 * VA_QT) * sizeof(float), lds = lds_fix + (size_t)N * VA_SP * sizeof(float);
         SDVAR_CHECK_ARG(C % 32 == 0, "vae: attention over %d channels (need a multiple of 32)", C);
         const int qgroups = (N + VA_QT - 1) / VA_QT;
-        if (lds <= 160 * 1024) {
+        static const bool no_mfma = getenv("SDVAR_VAE_ATTN_FMA") != nullptr;       // A/B runs: the fp32-FMA kernel
+        if (!no_mfma && (N == 256 || N == 1024) && C % 64 == 0) {                  // 16^2 / 32^2 latents: the matrix-core kernel
+            const size_t lm = (size_t)16 * (N + 4) * sizeof(float);
+            if (N == 256) {
+                hipLaunchKernelGGL(vae_attn_mfma_kernel<2>, dim3(N / 16, B), dim3(512), lm, s, h, t, C, N);
+            } else {
+                SDVAR_HIP(hipFuncSetAttribute((const void*)vae_attn_mfma_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm));
+                hipLaunchKernelGGL(vae_attn_mfma_kernel<8>, dim3(N / 16, B), dim3(512), lm, s, h, t, C, N);
+            }
+            SDVAR_LAUNCH_CHECK();
+        } else if (lds <= 160 * 1024) {
             SDVAR_HIP(hipFuncSetAttribute((const void*)vae_attn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(vae_attn_kernel<false>, dim3(qgroups, B), dim3(256), lds, s, h, t, C, N, (float*)nullptr);
             SDVAR_LAUNCH_CHECK();
