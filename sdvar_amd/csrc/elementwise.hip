@@ -30,9 +30,15 @@ struct PendingSplitK {
 // the shared_aln checkpoint of var.py:16-19, has C = 2304) so that narrow models do not pay the registers of wide ones.
 constexpr int LN_MAX_C = 3072;
 
-// the modulation vectors of a row, float4 number lane + 64 i: loaded FIRST by both kernels (these launches are latency bound at small M: every load
+// Which float4 of the row a lane holds in v[i].  PAIR (C % 8 == 0, every model width; round 4): lane l holds the two ADJACENT float4 2 l, 2 l + 1 (+ 128 per pair) - eight consecutive
+// values, so that an operand plane receives 16 bytes per lane and store (half the store instructions of the 8-byte form, whole 64-byte K-block segments per 4 lanes);
+// otherwise float4 number l + 64 i.
+template <bool PAIR>
+__device__ __forceinline__ int ln_idx(int lane, int i) { return PAIR ? 2 * lane + (i & 1) + 128 * (i >> 1) : lane + 64 * i; }
+
+// the modulation vectors of a row, float4 number ln_idx(lane, i): loaded FIRST by both kernels (these launches are latency bound at small M: every load
 // that does not depend on another must be in flight with it)
-template <int LN_MAX_V4>
+template <int LN_MAX_V4, bool PAIR>
 __device__ __forceinline__ void ln_load_mod(f32x4* scv, f32x4* shv, int lane, int row, const float* __restrict__ scale, const float* __restrict__ shift,
                                             int C, int rows_per_img, int mod_stride) {
     const int nv = C >> 2;
@@ -41,23 +47,23 @@ __device__ __forceinline__ void ln_load_mod(f32x4* scv, f32x4* shv, int lane, in
     const f32x4* psh = reinterpret_cast<const f32x4*>(shift + mo);
 #pragma unroll
     for (int i = 0; i < LN_MAX_V4; ++i)
-        if (lane + 64 * i < nv) { scv[i] = psc[lane + 64 * i]; shv[i] = psh[lane + 64 * i]; }
+        if (ln_idx<PAIR>(lane, i) < nv) { scv[i] = psc[ln_idx<PAIR>(lane, i)]; shv[i] = psh[ln_idx<PAIR>(lane, i)]; }
 }
 
 // LayerNorm + modulation of one row held by one wave (v[i] = float4 number lane + 64 i of the row)
-template <int LN_MAX_V4>
+template <int LN_MAX_V4, bool PAIR>
 __device__ __forceinline__ void ln_row_finish(const f32x4* v, const f32x4* scv, const f32x4* shv, int lane, int row,
                                               float* __restrict__ out, uint16_t* __restrict__ outp, size_t ops, int rows, int C, float eps, int pfmt) {
     const int nv = C >> 2;
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < LN_MAX_V4; ++i)
-        if (lane + 64 * i < nv) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        if (ln_idx<PAIR>(lane, i) < nv) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     const float mean = wave_sum(s) / (float)C;
     float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < LN_MAX_V4; ++i) {
-        const int idx = lane + 64 * i;
+        const int idx = ln_idx<PAIR>(lane, i);
         if (idx < nv) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; ss += d * d; }
@@ -65,9 +71,36 @@ __device__ __forceinline__ void ln_row_finish(const f32x4* v, const f32x4* scv, 
     }
     const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)C + eps);
     f32x4* po = reinterpret_cast<f32x4*>(out + (size_t)row * C);
+    if (PAIR && outp) {                      // eight consecutive values per lane and store: 16 bytes per plane
+#pragma unroll
+        for (int p = 0; p < LN_MAX_V4 / 2; ++p) {
+            const int idx = ln_idx<PAIR>(lane, 2 * p);
+            if (idx < nv) {
+                float ov[8];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f32x4 sc = scv[2 * p + h], sh = shv[2 * p + h];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ov[4 * h + e] = ((v[2 * p + h][e] - mean) * rstd) * (sc[e] + 1.0f) + sh[e];
+                }
+                const size_t o = kb_index(row, 4 * idx, rows);
+                if (pfmt == PLANES_F16X2) {
+                    uint2 h0, l0, h1, l1;
+                    split4h_pk(ov, h0, l0); split4h_pk(ov + 4, h1, l1);
+                    *reinterpret_cast<u32x4*>(outp + o) = u32x4{h0.x, h0.y, h1.x, h1.y};
+                    *reinterpret_cast<u32x4*>(outp + ops + o) = u32x4{l0.x, l0.y, l1.x, l1.y};
+                } else {
+                    u32x4 a, b, c;
+                    split8_packed(ov, a, b, c);
+                    *reinterpret_cast<u32x4*>(outp + o) = a; *reinterpret_cast<u32x4*>(outp + ops + o) = b; *reinterpret_cast<u32x4*>(outp + 2 * ops + o) = c;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < LN_MAX_V4; ++i) {
-        const int idx = lane + 64 * i;
+        const int idx = ln_idx<PAIR>(lane, i);
         if (idx < nv) {
             const f32x4 sc = scv[i], sh = shv[i];
             f32x4 o;
@@ -120,7 +153,7 @@ __device__ __forceinline__ f32x4 pending_residual(const PendingSplitK& pend, f32
     return xv;
 }
 
-template <int LN_MAX_V4>
+template <int LN_MAX_V4, bool PAIR>
 __global__ __launch_bounds__(256) void ln_modulate_kernel(float* __restrict__ x, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, float* __restrict__ out, uint16_t* __restrict__ outp,
                                                           size_t ops, int rows, int C, int rows_per_img, int mod_stride, float eps, PendingSplitK pend, int pfmt) {
@@ -129,10 +162,10 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(float* __restrict__ x,
     const int nv = C >> 2;
     f32x4* px = reinterpret_cast<f32x4*>(x + (size_t)row * C);
     f32x4 v[LN_MAX_V4], scv[LN_MAX_V4], shv[LN_MAX_V4];
-    ln_load_mod<LN_MAX_V4>(scv, shv, lane, row, scale, shift, C, rows_per_img, mod_stride);
+    ln_load_mod<LN_MAX_V4, PAIR>(scv, shv, lane, row, scale, shift, C, rows_per_img, mod_stride);
 #pragma unroll
     for (int i = 0; i < LN_MAX_V4; ++i) {
-        const int idx = lane + 64 * i;
+        const int idx = ln_idx<PAIR>(lane, i);
         if (idx < nv) {
             v[i] = px[idx];
             if (pend.ws) {          // finish the previous block's gated residual, written back
@@ -141,13 +174,13 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(float* __restrict__ x,
             }
         }
     }
-    ln_row_finish<LN_MAX_V4>(v, scv, shv, lane, row, out, outp, ops, rows, C, eps, pfmt);
+    ln_row_finish<LN_MAX_V4, PAIR>(v, scv, shv, lane, row, out, outp, ops, rows, C, eps, pfmt);
 }
 
 // Same result bit for bit, one WORKGROUP per row, for a pending split-K residual at small row counts: with one wave per row
 // a 16-row stage has 16 waves on the whole chip summing up to 32 slabs each (37 us measured); here 256 threads share the
 // slab sum of one row (phase 1, through LDS) and wave 0 then normalises it exactly as above.
-template <int LN_MAX_V4>
+template <int LN_MAX_V4, bool PAIR>
 __global__ __launch_bounds__(256) void ln_modulate_row_kernel(float* __restrict__ x, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, float* __restrict__ out, uint16_t* __restrict__ outp,
                                                               size_t ops, int rows, int C, int rows_per_img, int mod_stride, float eps, PendingSplitK pend, int pfmt) {
@@ -156,7 +189,7 @@ __global__ __launch_bounds__(256) void ln_modulate_row_kernel(float* __restrict_
     const int nv = C >> 2;
     f32x4* px = reinterpret_cast<f32x4*>(x + (size_t)row * C);
     f32x4 scv[LN_MAX_V4], shv[LN_MAX_V4];
-    if (tid < 64) ln_load_mod<LN_MAX_V4>(scv, shv, tid, row, scale, shift, C, rows_per_img, mod_stride);     // in flight with the slab loads below
+    if (tid < 64) ln_load_mod<LN_MAX_V4, PAIR>(scv, shv, tid, row, scale, shift, C, rows_per_img, mod_stride);     // in flight with the slab loads below
     for (int idx = tid; idx < nv; idx += 256) {
         const f32x4 nvv = pending_residual<16>(pend, px[idx], row, idx, rows, C);
         px[idx] = nvv;
@@ -167,8 +200,8 @@ __global__ __launch_bounds__(256) void ln_modulate_row_kernel(float* __restrict_
     f32x4 v[LN_MAX_V4];
 #pragma unroll
     for (int i = 0; i < LN_MAX_V4; ++i)
-        if (tid + 64 * i < nv) v[i] = vsm[tid + 64 * i];
-    ln_row_finish<LN_MAX_V4>(v, scv, shv, tid, row, out, outp, ops, rows, C, eps, pfmt);
+        if (ln_idx<PAIR>(tid, i) < nv) v[i] = vsm[ln_idx<PAIR>(tid, i)];
+    ln_row_finish<LN_MAX_V4, PAIR>(v, scv, shv, tid, row, out, outp, ops, rows, C, eps, pfmt);
 }
 
 int ln_modulate(float* x, const float* scale, const float* shift, float* out, uint16_t* outp, size_t ops, int rows, int C, int rows_per_img,
@@ -182,15 +215,19 @@ int ln_modulate(float* x, const float* scale, const float* shift, float* out, ui
     SDVAR_CHECK_ARG(mod_stride % 4 == 0, "ln_modulate: mod_stride must be a multiple of 4");
     SDVAR_CHECK_ARG(!outp || pfmt == PLANES_BF16X3 || pfmt == PLANES_F16X2, "ln_modulate: plane format %d", pfmt);
     const bool by_row = pd.ws && rows < 1024;
-#define SDVAR_LN_LAUNCH(NV4)                                                                                                                   \
+    static const bool pair_off = getenv("SDVAR_LN_PAIR") && atoi(getenv("SDVAR_LN_PAIR")) == 0;          // A/B runs
+    const bool pair = !pair_off && C % 8 == 0;
+#define SDVAR_LN_LAUNCH2(NV4, PR)                                                                                                              \
     do {                                                                                                                                       \
-        if (by_row) hipLaunchKernelGGL(ln_modulate_row_kernel<NV4>, dim3(rows), dim3(256), 0, stream, x, scale, shift, out, outp, ops, rows, C, rows_per_img, mod_stride, 1e-6f, pd, pfmt); \
-        else hipLaunchKernelGGL(ln_modulate_kernel<NV4>, dim3((rows + 3) / 4), dim3(256), 0, stream, x, scale, shift, out, outp, ops, rows, C, rows_per_img, mod_stride, 1e-6f, pd, pfmt);  \
+        if (by_row) hipLaunchKernelGGL((ln_modulate_row_kernel<NV4, PR>), dim3(rows), dim3(256), 0, stream, x, scale, shift, out, outp, ops, rows, C, rows_per_img, mod_stride, 1e-6f, pd, pfmt); \
+        else hipLaunchKernelGGL((ln_modulate_kernel<NV4, PR>), dim3((rows + 3) / 4), dim3(256), 0, stream, x, scale, shift, out, outp, ops, rows, C, rows_per_img, mod_stride, 1e-6f, pd, pfmt);  \
     } while (0)
+#define SDVAR_LN_LAUNCH(NV4) do { if (pair) SDVAR_LN_LAUNCH2(NV4, true); else SDVAR_LN_LAUNCH2(NV4, false); } while (0)
     if (C <= 1024) SDVAR_LN_LAUNCH(4);
     else if (C <= 2048) SDVAR_LN_LAUNCH(8);
     else SDVAR_LN_LAUNCH(12);
 #undef SDVAR_LN_LAUNCH
+#undef SDVAR_LN_LAUNCH2
     SDVAR_LAUNCH_CHECK();
     return SDVAR_OK;
 }
